@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (authoring container only).
+
+This is the only file in the repository that touches ``/root/reference``.  It
+imports the reference's own ``RGBF_EmbeddingModel``, ``ModelTrainer``, ``FCNet``
+and ``step`` and drives them on seeded inputs; the outputs are committed as
+small fixtures so that they travel to the GPU box, where the reference does
+not exist.  Three third-party imports of the reference are absent from this
+image and are stubbed before import:
+
+* ``cv2``, ``efficientnet_pytorch`` -- never reached on synthetic batches;
+* ``torchvision`` -- ``transforms`` (unused on synthetic batches) and
+  ``models.resnet.{BasicBlock, Bottleneck, conv1x1}``.  The topology and
+  initialisation come from the reference's OWN in-repo ``models.module.ResNet``
+  (models/module.py:35-130); only the residual block (conv3x3-BN-ReLU-conv3x3-
+  BN-add-ReLU, expansion 1) is supplied here, written from its published
+  definition.
+
+Usage:  python oracle/gen_golden.py          (writes tests/golden/)
+"""
+import json
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import vpd_oracle as O  # noqa: E402  (schemas / procedural weights / synthetic inputs)
+
+
+# ---------------------------------------------------------------------------
+# stubs for the three absent third-party modules
+# ---------------------------------------------------------------------------
+def _install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.setNumThreads = lambda n: None
+    sys.modules["cv2"] = cv2
+
+    eff = types.ModuleType("efficientnet_pytorch")
+    eff.EfficientNet = type("EfficientNet", (), {})
+    eff.model = types.ModuleType("efficientnet_pytorch.model")
+    sys.modules["efficientnet_pytorch"] = eff
+    sys.modules["efficientnet_pytorch.model"] = eff.model
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    for name in ("Normalize", "Compose", "ColorJitter", "RandomResizedCrop"):
+        setattr(tvt, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+
+    def conv1x1(i, o, stride=1):
+        return nn.Conv2d(i, o, kernel_size=1, stride=stride, bias=False)
+
+    class BasicBlock(nn.Module):
+        expansion = 1
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1,
+                     base_width=64, dilation=1, norm_layer=None):
+            super().__init__()
+            norm_layer = norm_layer or nn.BatchNorm2d
+            self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+            self.bn1 = norm_layer(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = norm_layer(planes)
+            self.downsample = downsample
+            self.stride = stride
+
+        def forward(self, x):
+            idn = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idn)
+
+    class Bottleneck(nn.Module):  # never instantiated (out of scope)
+        expansion = 4
+
+    tvr.BasicBlock, tvr.Bottleneck, tvr.conv1x1 = BasicBlock, Bottleneck, conv1x1
+    for name in ("resnet18", "resnet34", "resnet50", "resnet101", "wide_resnet50_2", "wide_resnet101_2"):
+        setattr(tvm, name, None)
+    tvm.resnet = tvr
+    tv.transforms, tv.models = tvt, tvm
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
+                        "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+    return BasicBlock
+
+
+def _import_reference():
+    basic_block = _install_stubs()
+    sys.path.insert(0, REF)
+    import models.module as ref_module
+    import models.rgb as ref_rgb
+    import models.util as ref_util
+    import train_vpd_model as ref_train
+    import util.io as ref_io
+    import action_dataset.load as ref_load
+
+    for arch, layers in (("resnet18", [2, 2, 2, 2]), ("resnet34", [3, 4, 6, 3])):
+        cfg = ref_module.ENCODER_ARCH[arch]
+        ref_module.ENCODER_ARCH[arch] = cfg._replace(
+            pretrained_init=(lambda L: (lambda pretrained=False: ref_module.ResNet(basic_block, L, 3, 1000)))(layers))
+    return ref_module, ref_rgb, ref_util, ref_train, ref_io, ref_load
+
+
+# ---------------------------------------------------------------------------
+def sample_idx(numel: int, k: int = 16) -> np.ndarray:
+    return np.unique(np.linspace(0, numel - 1, k).astype(np.int64))
+
+
+def _samples(t: torch.Tensor) -> np.ndarray:
+    flat = t.detach().reshape(-1)
+    return flat[torch.from_numpy(sample_idx(flat.numel()))].numpy().astype(np.float32)
+
+
+CASES = [
+    # name, arch, c_in, D, motion, N, HW, lr
+    ("r34_c5_d128_m1_n8", "resnet34", 5, 128, True, 8, 128, 5e-4),
+    ("r34_c5_d128_m0_n5", "resnet34", 5, 128, False, 5, 128, 5e-4),
+    ("r34_c3_d32_m0_n8_hw64", "resnet34", 3, 32, False, 8, 64, 5e-4),
+    ("r18_c5_d32_m1_n8", "resnet18", 5, 32, True, 8, 128, 5e-4),
+    ("r18_c3_d128_m0_n5_hw64", "resnet18", 3, 128, False, 5, 64, 1e-3),
+    ("r18_c5_d128_m1_n6_hw64", "resnet18", 5, 128, True, 6, 64, 5e-4),
+]
+TAP_BNS = ["resnet.bn1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1",
+           "resnet.layer3.1.bn2", "resnet.layer4.1.bn2"]
+
+
+def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
+    ref_module, ref_rgb, ref_util, ref_train, _, _ = ref
+    enc_sd = O.procedural_state_dict(O.encoder_schema(arch, c_in, D), seed)
+    dec_sd = O.procedural_state_dict(O.decoder_schema(D), seed + 7) if motion else None
+    img = O.synthetic_crops(N, c_in, HW, seed + 1)
+    tgt = O.synthetic_targets(N, D, motion, seed + 2)
+
+    def build():
+        enc = ref_rgb.RGBF_EmbeddingModel(arch, D, c_in == 5, "cpu")
+        enc.load_state_dict(enc_sd)
+        tr = ref_train.ModelTrainer(enc, motion)
+        if motion:
+            tr.fcn_time.load_state_dict(dec_sd)
+        return enc, tr
+
+    out = {"meta": json.dumps(dict(name=name, arch=arch, c_in=c_in, emb_dim=D, motion=motion,
+                                   n=N, hw=HW, lr=lr, seed=seed))}
+
+    # (1) eval-mode embeddings through the reference's embed()  (models/rgb.py:72-86)
+    enc, tr = build()
+    out["emb_eval"] = enc.embed(img.numpy())
+    # eval-mode epoch value (optimizer=None): train_vpd_model.py:70-76
+    out["epoch_eval"] = np.float64(tr.epoch([{"img": img, "emb": tgt}]))
+
+    # (2) train-mode forward + loss + backward with the reference's modules
+    enc, tr = build()
+    enc.train()
+    taps = {}
+    hooks = []
+    mods = dict(enc.named_modules())
+    for bn_name in TAP_BNS:
+        if bn_name in mods:
+            def hk(m, inp, outp, key=bn_name):
+                x = inp[0].detach()
+                taps[key] = (x.mean(dim=(0, 2, 3)).numpy(), x.var(dim=(0, 2, 3), unbiased=False).numpy())
+            hooks.append(mods[bn_name].register_forward_hook(hk))
+    if motion:
+        tr.fcn_time.train()
+    emb = enc(img)
+    pred = tr.fcn_time(emb) if motion else emb
+    loss = torch.nn.functional.mse_loss(pred, tgt, reduction="sum")
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    out["emb_train"] = emb.detach().numpy()
+    out["loss_train"] = np.float64(loss.item())
+    for k, (m, v) in taps.items():
+        out["bnmean/" + k] = m
+        out["bnvar/" + k] = v
+    named = [("enc." + k, p) for k, p in enc.named_parameters()]
+    if motion:
+        named += [("dec." + k, p) for k, p in tr.fcn_time.named_parameters()]
+    for k, p in named:
+        out["gnorm/" + k] = np.float64(p.grad.double().norm().item())
+        out["gsamp/" + k] = _samples(p.grad)
+
+    # (3) one full reference train step: ModelTrainer.epoch + get_optimizer + step
+    enc, tr = build()
+    optimizer, scaler = tr.get_optimizer(lr)
+    assert scaler is None
+    out["epoch_train"] = np.float64(tr.epoch([{"img": img, "emb": tgt}], optimizer=optimizer, scaler=scaler))
+    for k, v in enc.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["post/" + k] = v.numpy().copy()
+        elif k.endswith("num_batches_tracked"):
+            out["post/" + k] = v.numpy().copy()
+    named = [("enc." + k, p) for k, p in enc.named_parameters()]
+    if motion:
+        named += [("dec." + k, p) for k, p in tr.fcn_time.named_parameters()]
+    for k, p in named:
+        out["psamp/" + k] = _samples(p)
+    out["emb_eval_post"] = enc.embed(img.numpy())
+    # second + third step losses (three-step trajectory, SURVEY 8c probe)
+    traj = [float(out["epoch_train"])]
+    for _ in range(2):
+        traj.append(float(tr.epoch([{"img": img, "emb": tgt}], optimizer=optimizer, scaler=scaler)))
+    out["epoch_traj"] = np.asarray(traj, np.float64)
+    return out
+
+
+def adamw_case(ref):
+    """AdamW with injected grads for t=1..3 through torch.optim.AdamW exactly
+    as get_optimizer builds it (train_vpd_model.py:100-105)."""
+    rs = np.random.RandomState(11)
+    p0 = rs.standard_normal(4096).astype(np.float32)
+    gs = (rs.standard_normal((3, 4096)) * np.array([1.0, 1e-3, 10.0])[:, None]).astype(np.float32)
+    p = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([p], lr=5e-4)
+    hist = []
+    for t in range(3):
+        p.grad = torch.from_numpy(gs[t].copy())
+        opt.step()
+        opt.zero_grad()
+        hist.append(p.detach().numpy().copy())
+    st = opt.state[p]
+    return dict(p0=p0, grads=gs, p_hist=np.stack(hist), m=st["exp_avg"].numpy(), v=st["exp_avg_sq"].numpy(),
+                lr=np.float64(5e-4), defaults=json.dumps({k: v for k, v in opt.defaults.items()
+                                                          if isinstance(v, (int, float, bool, tuple, list))}))
+
+
+def format_case(ref):
+    """Reference apply-loop body (apply_vpd_model.py:152-178) on a stub dataset
+    -> pickles via the reference's store_pickle, re-read via group_by_frame;
+    plus config.json / loss.json via the reference's store_json."""
+    ref_module, ref_rgb, ref_util, ref_train, ref_io, ref_load = ref
+    arch, D, c_in = "resnet18", 32, 5
+    enc_sd = O.procedural_state_dict(O.encoder_schema(arch, c_in, D), 5)
+    enc = ref_rgb.RGBF_EmbeddingModel(arch, D, True, "cpu")
+    enc.load_state_dict(enc_sd)
+    videos = ["vidA", "vidB", "vidC"]
+    frames = {0: [3, 1, 2, 0], 1: [10, 12, 11, 14], 2: [5, 6, 8, 7]}
+    fdir = os.path.join(OUT, "format")
+    os.makedirs(fdir, exist_ok=True)
+    res = {}
+    for k, tag in ((2, "k2"), (1, "k1")):
+        tasks = [(vid, fr) for vid in range(3) for fr in frames[vid]]
+        imgs = O.synthetic_crops(len(tasks) * k, c_in, 64, 21).reshape(len(tasks), k, c_in, 64, 64)
+        all_embs = [list() for _ in videos]
+        bs = 5
+        for s in range(0, len(tasks), bs):
+            batch_img = imgs[s:s + bs]
+            n_batch, kk, w, h, d = batch_img.shape
+            batch_embs = enc.embed(batch_img.view(-1, w, h, d)).reshape((n_batch, kk, -1))
+            for i in range(n_batch):
+                vid, fr = tasks[s + i]
+                all_embs[vid].append((fr, batch_embs[i, :, :] if kk > 1 else batch_embs[i, 0, :], {}))
+        for video_name, embs in zip(videos, all_embs):
+            embs.sort()
+            path = os.path.join(fdir, "%s.%s.emb.pkl" % (video_name, tag))
+            ref_io.store_pickle(path, embs)
+            dense, mask = ref_load.group_by_frame(ref_io.load_pickle(path))
+            res["dense/%s/%s" % (tag, video_name)] = dense
+            res["mask/%s/%s" % (tag, video_name)] = mask
+    res["tasks"] = np.asarray([(vid, fr) for vid in range(3) for fr in frames[vid]], np.int64)
+    ref_io.store_json(os.path.join(fdir, "config.json"), {
+        "num_epochs": 2, "batch_size": 8, "learning_rate": 5e-4, "img_dim": 64, "use_flow": True,
+        "motion": False, "emb_dim": D, "encoder_arch": arch, "rgb_mean_std": O.DIVING48_MEAN_STD})
+    ref_io.store_json(os.path.join(fdir, "loss.json"), [
+        {"epoch": 1, "train": 1.5, "val": 2.5, "dataset_train": [("diving48", 1.5)],
+         "dataset_val": [("diving48", 2.5)]}])
+    # state_dict key/shape/dtype list of the reference's models (text fixture)
+    lines = []
+    for arch_, c_, d_ in (("resnet34", 5, 128), ("resnet18", 3, 32)):
+        m = ref_rgb.RGBF_EmbeddingModel(arch_, d_, c_ == 5, "cpu")
+        for k_, v_ in m.state_dict().items():
+            lines.append("%s c%d d%d | %s | %s | %s" % (arch_, c_, d_, k_, list(v_.shape), str(v_.dtype)))
+    fc = ref_module.FCNet(128, [128, 128], 256, dropout=0)
+    for k_, v_ in fc.state_dict().items():
+        lines.append("fcnet d128 | %s | %s | %s" % (k_, list(v_.shape), str(v_.dtype)))
+    with open(os.path.join(fdir, "state_dict_schema.txt"), "w") as fp:
+        fp.write("\n".join(lines) + "\n")
+    return res
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    ref = _import_reference()
+    for i, case in enumerate(CASES):
+        out = run_case(ref, *case, seed=100 + 10 * i)
+        np.savez_compressed(os.path.join(OUT, case[0] + ".npz"), **out)
+        print("wrote", case[0], "loss", float(out["loss_train"]), "traj", out["epoch_traj"])
+    np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
+    np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))
+    print("done ->", OUT)
+
+
+if __name__ == "__main__":
+    main()

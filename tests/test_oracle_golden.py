@@ -1,0 +1,126 @@
+"""Pin the CPU oracle (oracle/vpd_oracle.py) against vectors produced by the
+reference itself (oracle/gen_golden.py -> tests/golden/*.npz)."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vpd_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "r*.npz")))
+
+
+def sample_idx(numel, k=16):
+    return np.unique(np.linspace(0, numel - 1, k).astype(np.int64))
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def build(meta):
+    enc = O.procedural_state_dict(O.encoder_schema(meta["arch"], meta["c_in"], meta["emb_dim"]), meta["seed"])
+    dec = O.procedural_state_dict(O.decoder_schema(meta["emb_dim"]), meta["seed"] + 7) if meta["motion"] else None
+    img = O.synthetic_crops(meta["n"], meta["c_in"], meta["hw"], meta["seed"] + 1)
+    tgt = O.synthetic_targets(meta["n"], meta["emb_dim"], meta["motion"], meta["seed"] + 2)
+    return O.StudentOracle(meta["arch"], meta["c_in"], meta["emb_dim"], meta["motion"], enc, dec), img, tgt
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_oracle_matches_reference(path):
+    g = np.load(path)
+    meta = json.loads(str(g["meta"]))
+    torch.set_num_threads(4)
+
+    # eval-mode embed() and eval epoch value
+    st, img, tgt = build(meta)
+    e = O.embed(st.enc, img.numpy(), meta["arch"], meta["c_in"] == 5)
+    assert e.dtype == np.float32 and e.shape == g["emb_eval"].shape
+    assert rel_l2(e, g["emb_eval"]) < 1e-5
+    assert abs(st.epoch([{"img": img, "emb": tgt}], train=False) - float(g["epoch_eval"])) < 1e-4 * abs(float(g["epoch_eval"]))
+
+    # train-mode forward, loss, gradients, BN batch statistics
+    st, img, tgt = build(meta)
+    taps = {}
+    loss, emb, out, grads = st.forward_loss(img, tgt, train=True, need_grad=True, taps=taps)
+    assert rel_l2(emb.numpy(), g["emb_train"]) < 1e-5
+    assert abs(loss - float(g["loss_train"])) < 1e-5 * abs(float(g["loss_train"]))
+    for k in [k for k in g.files if k.startswith("bnmean/")]:
+        name = k.split("/", 1)[1]
+        assert rel_l2(taps[name][0].numpy(), g[k]) < 1e-4
+        assert rel_l2(taps[name][1].numpy(), g["bnvar/" + name]) < 1e-4
+    n_checked = 0
+    for k in [k for k in g.files if k.startswith("gnorm/")]:
+        name = k.split("/", 1)[1]
+        gr = grads[name]
+        ref_norm = float(g[k])
+        assert abs(float(gr.double().norm()) - ref_norm) <= 2e-4 * max(ref_norm, 1e-6), name
+        samp = gr.reshape(-1)[torch.from_numpy(sample_idx(gr.numel()))].numpy()
+        assert np.allclose(samp, g["gsamp/" + name], rtol=2e-3, atol=2e-4 * max(ref_norm / np.sqrt(gr.numel()), 1e-8)), name
+        n_checked += 1
+    assert n_checked == len(st.params())
+
+    # one full train step (epoch + AdamW + BN running stats), then two more
+    st, img, tgt = build(meta)
+    st.get_optimizer(meta["lr"])
+    traj = [st.epoch([{"img": img, "emb": tgt}], train=True)]
+    for k in [k for k in g.files if k.startswith("post/")]:
+        name = k.split("/", 1)[1]
+        if name.endswith("num_batches_tracked"):
+            assert int(st.enc[name]) == int(g[k]) == 1
+        else:
+            assert rel_l2(st.enc[name].numpy(), g[k]) < 1e-5, name
+    # AdamW's first step is sign-like: compare sampled weights with
+    # an absolute tolerance of a fraction of lr rather than bitwise
+    for k in [k for k in g.files if k.startswith("psamp/")]:
+        name = k.split("/", 1)[1]
+        p = st.params()[name]
+        samp = p.reshape(-1)[torch.from_numpy(sample_idx(p.numel()))].numpy()
+        assert np.allclose(samp, g[k], rtol=0, atol=0.6 * meta["lr"]), name
+    traj += [st.epoch([{"img": img, "emb": tgt}], train=True) for _ in range(2)]
+    assert np.allclose(traj, g["epoch_traj"], rtol=2e-2), (traj, g["epoch_traj"])
+    assert abs(traj[0] - float(g["epoch_train"])) < 1e-5 * abs(traj[0])
+
+
+def test_adamw_injected_grads():
+    g = np.load(os.path.join(GOLDEN, "adamw_injected.npz"))
+    p = {"w": torch.from_numpy(g["p0"].copy())}
+    st = O.AdamWState(p)
+    for t in range(3):
+        O.adamw_update(p, {"w": torch.from_numpy(g["grads"][t].copy())}, st, float(g["lr"]))
+        assert np.allclose(p["w"].numpy(), g["p_hist"][t], rtol=1e-6, atol=1e-7)
+    assert np.allclose(st.m["w"].numpy(), g["m"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(st.v["w"].numpy(), g["v"], rtol=1e-6, atol=1e-12)
+    d = json.loads(str(g["defaults"]))
+    assert d["weight_decay"] == 0.01 and d["eps"] == 1e-8 and tuple(d["betas"]) == (0.9, 0.999)
+
+
+def test_state_dict_schema_matches_reference():
+    lines = open(os.path.join(GOLDEN, "format", "state_dict_schema.txt")).read().strip().split("\n")
+    by_model = {}
+    for ln in lines:
+        model, key, shape, dtype = [s.strip() for s in ln.split("|")]
+        by_model.setdefault(model, []).append((key, json.loads(shape), dtype))
+    for model, (arch, c, d) in {"resnet34 c5 d128": ("resnet34", 5, 128), "resnet18 c3 d32": ("resnet18", 3, 32)}.items():
+        sch = O.encoder_schema(arch, c, d)
+        ours = [(k, list(s), "torch.int64" if kind == "bn_nbt" else "torch.float32") for k, (s, kind) in sch.items()]
+        assert ours == by_model[model]
+    ours = [(k, list(s), "torch.float32") for k, (s, _) in O.decoder_schema(128).items()]
+    assert ours == by_model["fcnet d128"]
+    assert len(O.encoder_schema("resnet34", 5, 128)) == 218
+
+
+def test_embed_contract():
+    sd = O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 1)
+    x = O.synthetic_crops(1, 5, 64, 3)[0]
+    assert O.embed(sd, x, "resnet18", True).shape == (1, 32)      # 3-D input promoted
+    with pytest.raises(AssertionError):
+        O.embed(sd, x[:3], "resnet18", True)
+    with pytest.raises(AssertionError):
+        O.embed(sd, x, "resnet18", False)
