@@ -1,0 +1,127 @@
+/* libvpdhip -- C ABI of the MI355X-native VPD student train / apply path.
+ *
+ * The reference (jhong93/vpd) has no FFI: its boundary for this path is a Python
+ * object surface.  Each entry point below names the reference
+ * code whose device work it replaces; vpd_amd/ (Python) mirrors the reference
+ * classes on top of these calls and INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer owned by the caller (torch tensors'
+ *     data_ptr()); the library never allocates or frees caller-visible memory;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it (no host sync), so calls are hipGraph-capturable;
+ *   - return value 0 = ok, negative = error; vpd_last_error() gives the message
+ *     (thread-local).  Shape/channel violations are the wrapper's AssertionError
+ *     (models/rgb.py:80-82), not error codes.
+ *   - flat buffers: `params`/`grads`/`adam_m`/`adam_v` are fp32 arrays of
+ *     vpd_plan_param_numel() elements holding every trainable tensor in the
+ *     reference's state_dict order and native layout (conv OIHW, linear [out][in]):
+ *     encoder tensors first, then the motion decoder's.  `bn_running` holds
+ *     running_mean / running_var of every BatchNorm in module order.
+ */
+#ifndef VPD_HIP_H
+#define VPD_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vpd_plan vpd_plan_t;
+
+const char* vpd_last_error(void);
+int vpd_abi_version(void);
+
+/* Network + workspace description for one (arch, input, head) configuration.
+ * Replaces the module construction of RGBF_EmbeddingModel.__init__ (models/rgb.py:46-66),
+ * ResNet.__init__/_make_layer (models/module.py:35-110) and, when motion != 0,
+ * FCNet(emb_dim,[128,128],2*emb_dim) (train_vpd_model.py:61-65).
+ * arch: "resnet18" | "resnet34" (models/module.py:17-21).  train != 0 reserves
+ * the activations / gradients a train step needs. */
+int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
+                    int max_batch, int train, vpd_plan_t** out);
+void vpd_plan_destroy(vpd_plan_t* plan);
+
+/* Trainable-tensor table in reference state_dict order (SURVEY.md 8b "state_dict schema").
+ * kind: 0 conv weight OIHW, 1 BN weight, 2 BN bias, 3 linear weight [out][in], 4 linear bias.
+ * is_decoder: 1 for the motion head's tensors (state_dict keys layers.{0,2,5}.*). */
+int vpd_plan_num_tensors(const vpd_plan_t* plan);
+int vpd_plan_tensor_info(const vpd_plan_t* plan, int i, int* kind, int* is_decoder, long long* offset,
+                         long long* numel, int* ndim, int dims[4]);
+long long vpd_plan_param_numel(const vpd_plan_t* plan);        /* multiple of 4 (tail padding) */
+/* BatchNorm running statistics: BN i has C channels, running_mean at rm_off, running_var at rv_off. */
+int vpd_plan_num_bn(const vpd_plan_t* plan);
+int vpd_plan_bn_info(const vpd_plan_t* plan, int i, int* channels, long long* rm_off, long long* rv_off);
+long long vpd_plan_bn_numel(const vpd_plan_t* plan);
+
+/* Gradient buckets for data-parallel all-reduce (no reference counterpart: the
+ * reference is single-device).  Bucket 0 is complete first during backward. */
+int vpd_plan_num_buckets(const vpd_plan_t* plan);
+int vpd_plan_bucket_range(const vpd_plan_t* plan, int bucket, long long* offset, long long* numel);
+
+size_t vpd_plan_workspace_bytes(const vpd_plan_t* plan);
+/* Zero the workspace (activation borders rely on it) and upload descriptor tables. */
+int vpd_plan_init_workspace(vpd_plan_t* plan, void* workspace, void* stream);
+
+/* fp32 master weights -> packed bf16 tap-major weights (+ dgrad layout), and the
+ * eval-mode BN fold (scale/shift from running stats).  Call after every change
+ * of `params` / `bn_running` (optimizer step, load_state_dict).  Replaces the
+ * implicit weight reads of every conv/BN module call. */
+int vpd_pack_weights(vpd_plan_t* plan, const float* params, const float* bn_running, void* workspace, void* stream);
+
+/* Eval-mode forward: RGBF_EmbeddingModel.forward under eval()/no_grad, i.e. the
+ * device part of embed() (models/rgb.py:72-86) and of ModelTrainer.epoch with
+ * optimizer=None (train_vpd_model.py:70-76).  x: f32 [N][c_in][H][W] (NCHW, the
+ * DataLoader batch layout, vpd_dataset/single_frame.py:206); emb_out: f32 [N][emb_dim].
+ * If target != NULL also runs the motion head (if any) and adds sum-MSE to the
+ * loss outputs (train_vpd_model.py:85-87, :93). */
+int vpd_forward_eval(vpd_plan_t* plan, const float* params, const float* x, int n, float* emb_out,
+                     const float* target, float* loss_step, double* loss_accum, void* workspace, void* stream);
+
+/* Train-mode forward + loss: encoder(img) -> [fcn_time] -> F.mse_loss(reduction='sum')
+ * (train_vpd_model.py:83-88) with train-mode BatchNorm (batch statistics, running-stat
+ * update momentum 0.1).  target: f32 [N][emb_dim or 2*emb_dim].  loss_step[0] = this
+ * batch's sum-MSE; loss_accum[0] += it (the epoch accumulator of :93 kept on device). */
+int vpd_forward_train(vpd_plan_t* plan, const float* params, float* bn_running, const float* x,
+                      const float* target, int n, float* emb_out, float* loss_step, double* loss_accum,
+                      void* workspace, void* stream);
+
+/* loss.backward() of models/util.py:52 for the graph built by vpd_forward_train:
+ * writes d loss / d param for every trainable tensor into `grads` (overwrites;
+ * the reference zero_grad()s after every step, models/util.py:58).
+ * bucket_events: optional array of vpd_plan_num_buckets() hipEvent_t handles, each
+ * recorded on `stream` as soon as that bucket's range of `grads` is final. */
+int vpd_backward(vpd_plan_t* plan, const float* params, float* grads, int n, void** bucket_events,
+                 void* workspace, void* stream);
+
+/* optimizer.step() of models/util.py:53 for torch.optim.AdamW(lr) with torch defaults
+ * (train_vpd_model.py:104): decoupled weight decay on every tensor. `step` is 1-based. */
+int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+/* hipGraph-captured eval forward for a fixed batch size (apply_vpd_model.py:152-168 inner
+ * loop at BATCH_SIZE crops per call).  Capture binds the pointers given here. */
+int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x, int n, float* emb_out,
+                           void* workspace, void* stream);
+int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
+
+/* ---- single-operator entry points (used by the parity tests; same kernels) ---- */
+/* One implicit-GEMM conv launch on padded-NHWC bf16 tensors (forward conv or data-gradient conv).
+ * tapset9 = {nr, nc, dy0, dys, dx0, dxs, w0, wrs, wcs}: tap (ir,ic) gathers input pixel
+ * (y*istr + dy0 + ir*dys, x*istr + dx0 + ic*dxs) in padded coordinates and uses weight slice
+ * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional): [ceil(M/vpd_op_conv_bm)][2][Co]. */
+int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, float* stats, int n, int xHp, int xWp,
+                  int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
+                  int Kc, int Co, const int* tapset9, int accumulate, void* stream);
+int vpd_op_conv_bm(int M, int Co);
+/* dw[slice][Co][Kc] (fp32) += sum over output pixels of dz[m][co] * x[gather(m, tap)][kc] */
+int vpd_op_wgrad(const void* dz_bf16, const void* x_bf16, float* dw, int n, int dzHp, int dzWp, int dzC, int dzpad,
+                 int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
+                 void* stream);
+/* dumps the ds_read_b64_tr_b16 fragments of one [128][64] bf16 tile: out [4][4][64][8] bf16 */
+int vpd_op_tr_read_probe(const void* tile_bf16, void* out_bf16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""Data-parallel host logic on CPU: world_size-2 gloo processes.  Each rank
+computes gradients for its shard of the batch with the CPU oracle (per-rank BN
+statistics, as the GPU path does), the product's bucket all-reduce SUMs them,
+and the result must equal the single-process emulation."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from oracle import vpd_oracle as O  # noqa: E402
+from vpd_amd.ddp import all_reduce_buckets, shard_sizes, shard_slice  # noqa: E402
+
+ARCH, C_IN, D, HW, N = "resnet18", 5, 16, 64, 7
+
+
+def _flat_grads(orc, img, tgt, names):
+    if img.shape[0] == 0:
+        return torch.zeros(sum(orc.params()[k].numel() for k in names)), 0.0
+    loss, _, _, grads = orc.forward_loss(img, tgt, train=True, need_grad=True)
+    return torch.cat([grads[k].reshape(-1) for k in names]), loss
+
+
+def _setup():
+    enc = O.procedural_state_dict(O.encoder_schema(ARCH, C_IN, D), 3)
+    img = O.synthetic_crops(N, C_IN, HW, 4)
+    tgt = O.synthetic_targets(N, D, False, 5)
+    return enc, img, tgt
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    enc, img, tgt = _setup()
+    orc = O.StudentOracle(ARCH, C_IN, D, False, enc)
+    names = list(orc.params().keys())
+    sl = shard_slice(N, rank, world)
+    flat, loss = _flat_grads(orc, img[sl], tgt[sl], names)
+    total = flat.numel()
+    cuts = [0, total // 5, total // 2, total - 100, total]
+    ranges = [(cuts[i], cuts[i + 1] - cuts[i]) for i in reversed(range(4))]     # reverse order like backward
+    all_reduce_buckets(flat, ranges)
+    stats = torch.tensor([loss, float(sl.stop - sl.start)], dtype=torch.float64)
+    dist.all_reduce(stats)
+    if rank == 0:
+        q.put((flat.numpy(), stats.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_sizes():
+    assert shard_sizes(32, 8) == [4] * 8
+    assert shard_sizes(3616, 8) == [452] * 8                  # C4 ragged final batch
+    assert shard_sizes(3, 8) == [1, 1, 1, 0, 0, 0, 0, 0]      # zero-crop ranks still join the collective
+    assert sum(shard_sizes(20000 % 256, 4)) == 32
+    s = [shard_slice(7, r, 2) for r in range(2)]
+    assert (s[0].start, s[0].stop, s[1].start, s[1].stop) == (0, 4, 4, 7)
+
+
+def test_bucketed_sum_all_reduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, stats = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process emulation: BN per shard, gradients summed, loss summed
+    enc, img, tgt = _setup()
+    exp = None
+    loss_sum = 0.0
+    for r in range(world):
+        orc = O.StudentOracle(ARCH, C_IN, D, False, enc)
+        names = list(orc.params().keys())
+        sl = shard_slice(N, r, world)
+        f, l = _flat_grads(orc, img[sl], tgt[sl], names)
+        exp = f if exp is None else exp + f
+        loss_sum += l
+    rel = np.linalg.norm(got - exp.numpy()) / np.linalg.norm(exp.numpy())
+    assert rel < 1e-4, rel      # fp32 CPU conv reductions differ slightly with the thread count
+    assert abs(stats[0] - loss_sum) < 1e-6 * abs(loss_sum) and int(stats[1]) == N

@@ -1,0 +1,217 @@
+"""Operator-level parity of the HIP kernels (through the C ABI) against plain
+PyTorch fp32 on the CPU, on seeded inputs.  Operands are bf16 (inputs are
+rounded to bf16 first, so the comparison isolates accumulation order and the
+bf16 rounding of the output): tolerance rel-L2 <= 4e-3, stated per test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 4e-3
+
+
+def _lib():
+    from vpd_amd._lib import lib
+    return lib()
+
+
+def _check(rc):
+    from vpd_amd._lib import check
+    check(rc, "op")
+
+
+def rel_l2(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_padded_nhwc(x, pad_t, pad_l, pad_b, pad_r, slack=0):
+    """f32 NCHW (cpu) -> bf16 padded NHWC on the GPU (flat, with `slack` extra zero elements)."""
+    n, c, h, w = x.shape
+    buf = torch.zeros(n, h + pad_t + pad_b, w + pad_l + pad_r, c, dtype=torch.bfloat16)
+    buf[:, pad_t:pad_t + h, pad_l:pad_l + w, :] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    flat = torch.zeros(buf.numel() + slack, dtype=torch.bfloat16)
+    flat[:buf.numel()] = buf.flatten()
+    return flat.cuda()
+
+
+def from_nhwc(flat, n, hp, wp, c, pad):
+    t = flat[: n * hp * wp * c].view(n, hp, wp, c).float().cpu()
+    if pad:
+        t = t[:, pad:-pad, pad:-pad, :]
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def tapset(*v):
+    return (C.c_int * 9)(*v)
+
+
+def run_conv(xp, wp, n, xHp, xWp, xC, yH, yW, ypad, Hs, Ws, osub, oph, opw, istr, Kc, Co, taps, y=None,
+             accumulate=0, want_stats=False, yC=None):
+    L = _lib()
+    yC = yC or Co
+    yHp, yWp = yH + 2 * ypad, yW + 2 * ypad
+    if y is None:
+        y = torch.zeros(n * yHp * yWp * yC, dtype=torch.bfloat16, device="cuda")
+    stats = None
+    if want_stats:
+        bm = L.vpd_op_conv_bm(n * Hs * Ws, Co)
+        T = (n * Hs * Ws + bm - 1) // bm
+        stats = torch.zeros(T, 2, Co, dtype=torch.float32, device="cuda")
+    _check(L.vpd_op_conv2d(ptr(xp), ptr(wp), ptr(y), ptr(stats) if stats is not None else None, n, xHp, xWp, xC,
+                           yHp, yWp, yC, ypad, Hs, Ws, osub, oph, opw, istr, Kc, Co, taps, accumulate, stream()))
+    torch.cuda.synchronize()
+    return y, stats
+
+
+def pack_fwd(w):
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 0, 1).reshape(kh * kw, co, ci).contiguous().to(torch.bfloat16).cuda()
+
+
+def pack_dgrad(w):
+    co, ci, kh, kw = w.shape
+    return w.permute(2, 3, 1, 0).reshape(kh * kw, ci, co).contiguous().to(torch.bfloat16).cuda()
+
+
+def test_tr_read_probe():
+    """ds_read_b64_tr_b16 lane mapping used by the wgrad kernel."""
+    L = _lib()
+    tile = torch.arange(128 * 64, dtype=torch.float32).remainder(251.0).view(128, 64)
+    tile = tile + torch.arange(128).view(128, 1) * 0.0   # value = (r*64+c) % 251, exactly representable
+    d = tile.to(torch.bfloat16).cuda()
+    out = torch.zeros(4 * 4 * 64 * 8, dtype=torch.bfloat16, device="cuda")
+    _check(L.vpd_op_tr_read_probe(ptr(d), ptr(out), stream()))
+    torch.cuda.synchronize()
+    got = out.view(4, 4, 64, 8).float().cpu()
+    exp = torch.empty(4, 4, 64, 8)
+    tb = tile.to(torch.bfloat16).float()
+    for wv in range(4):
+        for ct in range(4):
+            for l in range(64):
+                for j in range(8):
+                    exp[wv, ct, l, j] = tb[wv * 32 + 8 * (l >> 4) + j, ct * 16 + (l & 15)]
+    assert torch.equal(got, exp)
+
+
+CONV_CASES = [
+    # name, N, Ci, Co, H, W, k, stride, pad
+    ("l1_3x3_s1", 3, 64, 64, 16, 16, 3, 1, 1),
+    ("l2_3x3_s2", 3, 64, 128, 16, 16, 3, 2, 1),
+    ("l2_1x1_s2", 3, 64, 128, 16, 16, 1, 2, 0),
+    ("l3_3x3_s1_ragged", 5, 256, 256, 4, 4, 3, 1, 1),
+    ("l4_3x3_s1_tiny", 2, 512, 512, 2, 2, 3, 1, 1),
+    ("l2_3x3_s1_big", 9, 128, 128, 16, 16, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(case):
+    name, n, ci, co, h, w, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = bf16_round(torch.randn(n, ci, h, w, generator=g))
+    wt = bf16_round(torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5)
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=stride, padding=pad)
+    dz = bf16_round(torch.randn(ref.shape, generator=g))
+    ref.backward(dz)
+
+    # ---- forward (+ channel statistics) ----
+    xp = to_padded_nhwc(x, 1, 1, 1, 1)
+    taps = tapset(k, k, 1 - pad, 1, 1 - pad, 1, 0, k, 1)
+    y, stats = run_conv(xp, pack_fwd(wt), n, h + 2, w + 2, ci, ho, wo, 0, ho, wo, 1, 0, 0, stride, ci, co, taps,
+                        want_stats=True)
+    got = from_nhwc(y, n, ho, wo, co, 0)
+    assert rel_l2(got, ref.detach()) < REL_TOL
+    s = stats.sum(dim=0).cpu()
+    assert rel_l2(s[0], got.sum(dim=(0, 2, 3))) < 1e-4          # stats are over the stored bf16 values
+    assert rel_l2(s[1], (got * got).sum(dim=(0, 2, 3))) < 1e-4
+
+    # ---- data gradient ----
+    dzp = to_padded_nhwc(dz, 1, 1, 1, 1)
+    wd = pack_dgrad(wt)
+    dx = torch.zeros(n * h * w * ci, dtype=torch.bfloat16, device="cuda")
+    if stride == 1:
+        taps = tapset(k, k, pad + 1, -1, pad + 1, -1, 0, k, 1)
+        run_conv(dzp, wd, n, ho + 2, wo + 2, co, h, w, 0, h, w, 1, 0, 0, 1, co, ci, taps, y=dx)
+    else:
+        for ph in range(2):
+            for pw in range(2):
+                hs, ws = (h - ph + 1) // 2, (w - pw + 1) // 2
+                rf, tf = (ph + pad) % 2, (pw + pad) % 2
+                nr = (k - rf + 1) // 2 if rf < k else 0
+                nc = (k - tf + 1) // 2 if tf < k else 0
+                if nr == 0 or nc == 0:
+                    continue
+                taps = tapset(nr, nc, (ph + pad - rf) // 2 + 1, -1, (pw + pad - tf) // 2 + 1, -1, rf * k + tf, 2 * k, 2)
+                run_conv(dzp, wd, n, ho + 2, wo + 2, co, h, w, 0, hs, ws, 2, ph, pw, 1, co, ci, taps, y=dx)
+    gotdx = from_nhwc(dx, n, h, w, ci, 0)
+    assert rel_l2(gotdx, xr.grad) < REL_TOL
+
+    # accumulate flag: running the stride-1 dgrad again on top doubles the result
+    if stride == 1:
+        taps = tapset(k, k, pad + 1, -1, pad + 1, -1, 0, k, 1)
+        run_conv(dzp, wd, n, ho + 2, wo + 2, co, h, w, 0, h, w, 1, 0, 0, 1, co, ci, taps, y=dx, accumulate=1)
+        assert rel_l2(from_nhwc(dx, n, h, w, ci, 0), 2 * xr.grad) < 2 * REL_TOL
+
+    # ---- weight gradient ----
+    L = _lib()
+    dw = torch.zeros(k * k, co, ci, dtype=torch.float32, device="cuda")
+    taps = tapset(k, k, 1 - pad, 1, 1 - pad, 1, 0, k, 1)
+    _check(L.vpd_op_wgrad(ptr(dzp), ptr(xp), ptr(dw), n, ho + 2, wo + 2, co, 1, h + 2, w + 2, ci, ho, wo, stride,
+                          ci, co, taps, stream()))
+    torch.cuda.synchronize()
+    gotdw = dw.cpu().view(k, k, co, ci).permute(2, 3, 0, 1)
+    assert rel_l2(gotdw, wr.grad) < REL_TOL
+
+
+def test_stem_conv_and_wgrad():
+    """7x7 s2 p3 stem on a 5-channel input stored as 8-channel NHWC with a 3-pixel border:
+    each kernel row is one 64-wide tap (8 column taps x 8 channels, the 8th tap / channels 5..7 zero)."""
+    n, c, h, w, co = 3, 5, 32, 32, 64
+    g = torch.Generator().manual_seed(7)
+    x = bf16_round(torch.randn(n, c, h, w, generator=g))
+    wt = bf16_round(torch.randn(co, c, 7, 7, generator=g) * (2.0 / (co * 49)) ** 0.5)
+    xr, wr = x.clone(), wt.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=2, padding=3)
+    ho, wo = ref.shape[2], ref.shape[3]
+    dz = bf16_round(torch.randn(ref.shape, generator=g))
+    ref.backward(dz)
+    x8 = torch.zeros(n, 8, h, w)
+    x8[:, :c] = x
+    xp = to_padded_nhwc(x8, 3, 3, 3, 5, slack=256)
+    wp = torch.zeros(7, co, 8, 8)
+    wp[:, :, :7, :c] = wt.permute(2, 0, 3, 1)                     # [r][co][t][c]
+    wp = wp.reshape(7, co, 64).to(torch.bfloat16).cuda()
+    taps = tapset(7, 1, 0, 1, 0, 0, 0, 1, 0)
+    y, _ = run_conv(xp, wp, n, h + 6, w + 8, 8, ho, wo, 0, ho, wo, 1, 0, 0, 2, 64, co, taps)
+    assert rel_l2(from_nhwc(y, n, ho, wo, co, 0), ref.detach()) < REL_TOL
+
+    L = _lib()
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
+    dw = torch.zeros(7, co, 64, dtype=torch.float32, device="cuda")
+    _check(L.vpd_op_wgrad(ptr(dzd), ptr(xp), ptr(dw), n, ho, wo, co, 0, h + 6, w + 8, 8, ho, wo, 2, 64, co, taps,
+                          stream()))
+    torch.cuda.synchronize()
+    got = dw.cpu().view(7, co, 8, 8)[:, :, :7, :c].permute(1, 3, 0, 2)   # -> [co][c][r][t]
+    assert rel_l2(got, wr.grad) < REL_TOL

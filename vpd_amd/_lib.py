@@ -1,0 +1,81 @@
+"""ctypes binding of libvpdhip.so (C ABI in include/vpd_hip.h).
+
+The library is the product: there is no PyTorch / CPU fallback for the hot
+path.  ``lib()`` raises if the shared object is missing or lacks a symbol.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvpdhip.so")
+ABI_VERSION = 1
+
+c_int_p = C.POINTER(C.c_int)
+c_ll_p = C.POINTER(C.c_longlong)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/vpd_hip.h one to one
+SIGNATURES = {
+    "vpd_last_error": (C.c_char_p, []),
+    "vpd_abi_version": (C.c_int, []),
+    "vpd_plan_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(vp)]),
+    "vpd_plan_destroy": (None, [vp]),
+    "vpd_plan_num_tensors": (C.c_int, [vp]),
+    "vpd_plan_tensor_info": (C.c_int, [vp, C.c_int, c_int_p, c_int_p, c_ll_p, c_ll_p, c_int_p, c_int_p]),
+    "vpd_plan_param_numel": (C.c_longlong, [vp]),
+    "vpd_plan_num_bn": (C.c_int, [vp]),
+    "vpd_plan_bn_info": (C.c_int, [vp, C.c_int, c_int_p, c_ll_p, c_ll_p]),
+    "vpd_plan_bn_numel": (C.c_longlong, [vp]),
+    "vpd_plan_num_buckets": (C.c_int, [vp]),
+    "vpd_plan_bucket_range": (C.c_int, [vp, C.c_int, c_ll_p, c_ll_p]),
+    "vpd_plan_workspace_bytes": (C.c_size_t, [vp]),
+    "vpd_plan_init_workspace": (C.c_int, [vp, vp, vp]),
+    "vpd_pack_weights": (C.c_int, [vp, vp, vp, vp, vp]),
+    "vpd_forward_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "vpd_forward_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "vpd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(vp), vp, vp]),
+    "vpd_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_int, vp]),
+    "vpd_graph_capture_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
+    "vpd_graph_launch_eval": (C.c_int, [vp, C.c_int, vp]),
+    "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),
+    "vpd_op_conv_bm": (C.c_int, [C.c_int, C.c_int]),
+    "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp]),
+    "vpd_op_tr_read_probe": (C.c_int, [vp, vp, vp]),
+}
+
+_lib = None
+
+
+class VpdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libvpdhip.so (once).  Raises -- never falls back -- when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise VpdHipError(
+            "libvpdhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vpd_amd/csrc`.  vpd_amd has no PyTorch/CPU fallback." % LIB_PATH)
+    h = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise VpdHipError("libvpdhip.so lacks symbol %s declared in include/vpd_hip.h" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if h.vpd_abi_version() != ABI_VERSION:
+        raise VpdHipError("libvpdhip.so ABI version %d != expected %d" % (h.vpd_abi_version(), ABI_VERSION))
+    _lib = h
+    return h
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().vpd_last_error()
+        raise VpdHipError("%s failed: %s" % (what or "libvpdhip call", msg.decode() if msg else "unknown error"))

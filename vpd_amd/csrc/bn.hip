@@ -1,0 +1,426 @@
+// BatchNorm (train + eval), ReLU, residual add, stem max-pool and their
+// backward passes.  All HBM-bound: 16-byte (8 x bf16) accesses per lane,
+// per-channel reductions done as per-block partials (deterministic) that a
+// tiny finalize kernel sums in double precision.
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------
+// finalize of forward statistics: partials [T][2][C] -> mean, rstd, scale,
+// shift; running-stat update (momentum, unbiased var) as nn.BatchNorm2d.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partials, int T, int C, float count,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* running_mean, float* running_var, float momentum, float eps,
+    float* mean, float* rstd, float* scale, float* shift) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = g; t < T; t += 4) {
+            s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
+            s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+        }
+    sh[0][g][cl] = s1; sh[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        const double mu = s1 / (double)count;
+        double var = s2 / (double)count - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        const float r = (float)(1.0 / sqrt(var + (double)eps));
+        mean[c] = (float)mu;
+        rstd[c] = r;
+        const float sc = gamma[c] * r;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+        if (running_mean) {
+            const double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+hipError_t vpd_launch_bn_finalize(const float* partials, int T, int C, float count, const float* gamma,
+                                  const float* beta, float* rm, float* rv, float momentum, float eps,
+                                  float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, partials, T, C, count, gamma,
+                       beta, rm, rv, momentum, eps, mean, rstd, scale, shift);
+    return hipGetLastError();
+}
+
+// eval-mode fold: scale = gamma / sqrt(rv + eps), shift = beta - rm * scale
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                               float eps, float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float sc = gamma[c] / sqrtf(rv[c] + eps);
+        scale[c] = sc;
+        shift[c] = beta[c] - rm[c] * sc;
+    }
+}
+hipError_t vpd_launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                              float* scale, float* shift, int C, hipStream_t s) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, scale, shift, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// forward apply: out(padded) = relu?( scale*z + shift (+ residual) )
+//   res_kind 0: none; 1: padded activation tensor; 2: dense z_d with its own
+//   scale/shift (the downsample branch: conv1x1 -> BN, no ReLU)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
+    const int cv = p.C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(it / cv);
+        const int c = (int)(it - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float v[8], sc[8], sh[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), v);
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + c);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(p.scale + c + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + c);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(p.shift + c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+        if (p.res_kind == 1) {
+            float rr[8];
+            const size_t ro = ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * p.C + c;
+            unpack8(*reinterpret_cast<const uint4*>(p.res + ro), rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        } else if (p.res_kind == 2) {
+            float rr[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)m * p.C + c), rr);
+            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.rscale + c);
+            *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(p.rscale + c + 4);
+            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.rshift + c);
+            *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(p.rshift + c + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j] * sc[j] + sh[j];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+        }
+        const size_t oo = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * p.C + c;
+        *reinterpret_cast<uint4*>(p.out + oo) = pack8(v);
+    }
+}
+
+static inline int ew_grid(long items) {
+    long g = (items + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+hipError_t vpd_launch_bn_apply(const BnApplyParams& p, hipStream_t s) {
+    if (p.C % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// stem: BN + ReLU + MaxPool 3x3 s2 p1 fused.  z dense [N][Hz][Wz][C] ->
+// out padded [N][Ho+2*opad][Wo+2*opad][C]; idx (train) u8 dense [N][Ho][Wo][C]
+// holds the window position r*3+t of the FIRST maximum (row-major scan, as
+// torch's max_pool2d).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolParams p) {
+    const int cv = p.C >> 3;
+    const int Ho = p.Ho, Wo = p.Wo;
+    const long total = (long)p.N * Ho * Wo * cv;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % cv) << 3;
+        long t = it / cv;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float sc[8], sh[8], best[8];
+        int bi[8];
+        *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + c);
+        *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(p.scale + c + 4);
+        *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + c);
+        *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(p.shift + c + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+        for (int r = 0; r < 3; ++r) {
+            const int y = 2 * oy - 1 + r;
+            if (y < 0 || y >= p.Hz) continue;
+            for (int tt = 0; tt < 3; ++tt) {
+                const int x = 2 * ox - 1 + tt;
+                if (x < 0 || x >= p.Wz) continue;
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.z + ((size_t)(b * p.Hz + y) * p.Wz + x) * p.C + c), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = v[j] * sc[j] + sh[j];
+                    a = a > 0.f ? a : 0.f;
+                    // compare the bf16-rounded activation (what a materialised tensor would hold)
+                    a = bf2f(f2bf(a));
+                    if (a > best[j]) { best[j] = a; bi[j] = r * 3 + tt; }
+                }
+            }
+        }
+        const size_t oo = ((size_t)(b * (Ho + 2 * p.opad) + oy + p.opad) * (Wo + 2 * p.opad) + ox + p.opad) * p.C + c;
+        *reinterpret_cast<uint4*>(p.out + oo) = pack8(best);
+        if (p.idx) {
+            uint2 iv;
+            iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+            iv.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+            *reinterpret_cast<uint2*>(p.idx + ((size_t)(b * Ho + oy) * Wo + ox) * p.C + c) = iv;
+        }
+    }
+}
+hipError_t vpd_launch_stem_pool(const StemPoolParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(ew_grid((long)p.N * p.Ho * p.Wo * (p.C / 8))), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// BN backward, pass 1: per-block partial sums of g and g*xhat, where
+//   g = dy * [act > 0]  (mask from the padded post-ReLU activation, or none)
+// Each block owns `ppb` consecutive pixels; a thread owns 8 channels.
+// partials layout [T][2][C].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
+    __shared__ float sh[256][17];
+    const int cv = p.C >> 3;
+    const int ppi = 256 / cv;                       // pixels per block iteration
+    const int c8 = threadIdx.x % cv;
+    const int pl = threadIdx.x / cv;
+    const int c = c8 << 3;
+    const int HW = p.H * p.W;
+    float mu[8], rs[8], a1[8], a2[8];
+    *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(p.mean + c);
+    *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(p.mean + c + 4);
+    *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(p.rstd + c);
+    *reinterpret_cast<float4*>(rs + 4) = *reinterpret_cast<const float4*>(p.rstd + c + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    const int mbeg = blockIdx.x * p.ppb;
+    int mend = mbeg + p.ppb;
+    mend = mend < p.M ? mend : p.M;
+    if (pl < ppi)
+        for (int m = mbeg + pl; m < mend; m += ppi) {
+            float g[8], z[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.C + c), g);
+            unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
+            if (p.act) {
+                const int b = m / HW;
+                const int r = m - b * HW;
+                const int y = r / p.W;
+                const int x = r - y * p.W;
+                float a[8];
+                unpack8(*reinterpret_cast<const uint4*>(
+                            p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * p.C + c), a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1[j] += g[j];
+                a2[j] += g[j] * ((z[j] - mu[j]) * rs[j]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = a1[j]; sh[threadIdx.x][8 + j] = a2[j]; }
+    __syncthreads();
+    // thread t < C sums channel t (c8 = t>>3, j = t&7) over the pixel groups, for both sums
+    for (int t = threadIdx.x; t < 2 * p.C; t += 256) {
+        const int which = t / p.C;
+        const int ch = t - which * p.C;
+        const int q8 = ch >> 3, j = ch & 7;
+        float tot = 0.f;
+        for (int g = 0; g < ppi; ++g) tot += sh[g * cv + q8][which * 8 + j];
+        p.partials[((size_t)blockIdx.x * 2 + which) * p.C + ch] = tot;
+    }
+}
+
+// pass 1b: partials -> dgamma, dbeta (fp32 grads) and the apply coefficients
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partials, int T, int C, float count, const float* __restrict__ gamma,
+    const float* __restrict__ rstd, float* dgamma, float* dbeta, float* coef) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = g; t < T; t += 4) {
+            s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
+            s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+        }
+    sh[0][g][cl] = s1; sh[1][g][cl] = s2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        coef[c] = gamma[c] * rstd[c];
+        coef[C + c] = (float)(s1 / (double)count);
+        coef[2 * C + c] = (float)(s2 / (double)count);
+    }
+}
+
+// pass 2: dz = c1 * (g - c2 - xhat * c3); optionally write g back over dy
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
+    const int cv = p.C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(it / cv);
+        const int c = (int)(it - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float g[8], z[8], mu[8], rs[8], c1[8], c2[8], c3[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.C + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
+        if (p.act) {
+            float a[8];
+            unpack8(*reinterpret_cast<const uint4*>(
+                        p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * p.C + c), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+            if (p.write_g) *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * p.C + c) = pack8(g);
+        }
+#define LD8(dst, src) \
+        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
+        *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+        LD8(mu, p.mean + c) LD8(rs, p.rstd + c) LD8(c1, p.coef + c) LD8(c2, p.coef + p.C + c) LD8(c3, p.coef + 2 * p.C + c)
+#undef LD8
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = c1[j] * (g[j] - c2[j] - (z[j] - mu[j]) * rs[j] * c3[j]);
+        const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * p.C + c;
+        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+    }
+}
+
+int vpd_bn_bwd_blocks(int M, int C, int* ppb_out) {
+    const int ppi = 256 / (C / 8);
+    int ppb = (M + 1023) / 1024;                  // at most ~1024 blocks
+    if (ppb < ppi * 8) ppb = ppi * 8;
+    ppb = ((ppb + ppi - 1) / ppi) * ppi;
+    if (ppb_out) *ppb_out = ppb;
+    return (M + ppb - 1) / ppb;
+}
+
+hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* gamma, float* dgamma, float* dbeta,
+                             hipStream_t s) {
+    BnBwdParams p = p0;
+    if (p.C % 8 || p.C > 2048 || 256 % (p.C / 8)) return hipErrorInvalidValue;
+    const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, T, p.C, count,
+                       gamma, p.rstd, dgamma, dbeta, p.coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// stem backward: max-pool routing + ReLU mask -> g0 (dense bf16) and the BN
+// backward partial sums in one pass.  d_pool is dense [N][Ho][Wo][C].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdParams p) {
+    __shared__ float sh[256][17];
+    const int cv = p.C >> 3;
+    const int ppi = 256 / cv;
+    const int c8 = threadIdx.x % cv;
+    const int pl = threadIdx.x / cv;
+    const int c = c8 << 3;
+    const int HWz = p.Hz * p.Wz;
+    float mu[8], rs[8], sc[8], shf[8], a1[8], a2[8];
+#define LD8(dst, src) \
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
+    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+    LD8(mu, p.mean + c) LD8(rs, p.rstd + c) LD8(sc, p.scale + c) LD8(shf, p.shift + c)
+#undef LD8
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+    const int mbeg = blockIdx.x * p.ppb;
+    int mend = mbeg + p.ppb;
+    mend = mend < p.M ? mend : p.M;
+    if (pl < ppi)
+        for (int m = mbeg + pl; m < mend; m += ppi) {
+            const int b = m / HWz;
+            const int r = m - b * HWz;
+            const int y = r / p.Wz;
+            const int x = r - y * p.Wz;
+            float z[8], g[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = 0.f;
+            // windows (oy, ox) that contain (y, x): oy in {y/2 (r=1 or 2)} and, for odd y, (y+1)/2 (r=0)
+            for (int wy = 0; wy < 2; ++wy) {
+                const int oy = (y >> 1) + wy;
+                const int rr = y - (2 * oy - 1);
+                if (rr < 0 || rr > 2 || oy >= p.Ho) continue;
+                for (int wx = 0; wx < 2; ++wx) {
+                    const int ox = (x >> 1) + wx;
+                    const int tt = x - (2 * ox - 1);
+                    if (tt < 0 || tt > 2 || ox >= p.Wo) continue;
+                    const size_t po = ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.C + c;
+                    const uint2 iv = *reinterpret_cast<const uint2*>(p.idx + po);
+                    float d[8];
+                    unpack8(*reinterpret_cast<const uint4*>(p.dpool + po), d);
+                    const unsigned want = (unsigned)(rr * 3 + tt);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned sel = ((j < 4 ? iv.x : iv.y) >> (8 * (j & 3))) & 0xffu;
+                        if (sel == want) g[j] += d[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = z[j] * sc[j] + shf[j];
+                g[j] = a > 0.f ? g[j] : 0.f;
+                // sums over the bf16-rounded g that pass 2 will read
+                g[j] = bf2f(f2bf(g[j]));
+                a1[j] += g[j];
+                a2[j] += g[j] * ((z[j] - mu[j]) * rs[j]);
+            }
+            *reinterpret_cast<uint4*>(p.g + (size_t)m * p.C + c) = pack8(g);
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = a1[j]; sh[threadIdx.x][8 + j] = a2[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * p.C; t += 256) {
+        const int which = t / p.C;
+        const int ch = t - which * p.C;
+        const int q8 = ch >> 3, j = ch & 7;
+        float tot = 0.f;
+        for (int gI = 0; gI < ppi; ++gI) tot += sh[gI * cv + q8][which * 8 + j];
+        p.partials[((size_t)blockIdx.x * 2 + which) * p.C + ch] = tot;
+    }
+}
+
+hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, const float* gamma, float* dgamma,
+                                    float* dbeta, float* coef, bf16_t* dz, hipStream_t s) {
+    StemPoolBwdParams p = p0;
+    if (p.C % 8 || 256 % (p.C / 8)) return hipErrorInvalidValue;
+    const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, T, p.C, count,
+                       gamma, p.rstd, dgamma, dbeta, coef);
+    BnBwdParams q = {};
+    q.dy = p.g; q.dy_rw = nullptr; q.z = p.z; q.act = nullptr; q.mean = p.mean; q.rstd = p.rstd; q.coef = coef;
+    q.partials = p.partials; q.dz = dz; q.dzHp = p.Hz; q.dzWp = p.Wz; q.dzpad = 0;
+    q.M = p.M; q.H = p.Hz; q.W = p.Wz; q.C = p.C; q.write_g = 0;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)q.M * (q.C / 8))), dim3(256), 0, s, q);
+    return hipGetLastError();
+}

@@ -1,0 +1,94 @@
+// Shared device helpers for the VPD student kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define VPD_WAVE 64
+
+static __device__ __forceinline__ float bf2f(unsigned short u) {
+    return __builtin_bit_cast(float, ((unsigned)u) << 16);
+}
+static __device__ __forceinline__ unsigned short f2bf(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+    return __builtin_bit_cast(unsigned short, (bf16_t)f);
+}
+static __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+static __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf2f((unsigned short)(v.x & 0xffff)); f[1] = bf2f((unsigned short)(v.x >> 16));
+    f[2] = bf2f((unsigned short)(v.y & 0xffff)); f[3] = bf2f((unsigned short)(v.y >> 16));
+    f[4] = bf2f((unsigned short)(v.z & 0xffff)); f[5] = bf2f((unsigned short)(v.z >> 16));
+    f[6] = bf2f((unsigned short)(v.w & 0xffff)); f[7] = bf2f((unsigned short)(v.w >> 16));
+}
+static __device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Activation tensor descriptor: bf16 NHWC with a zero border of `pad` pixels.
+// Element offset of interior pixel (b, y, x): ((b*Hp + y + pad)*Wp + x + pad)*C.
+struct TensorDesc {
+    int H, W, C, pad;
+};
+static __host__ __device__ __forceinline__ int td_hp(const TensorDesc& t) { return t.H + 2 * t.pad; }
+static __host__ __device__ __forceinline__ int td_wp(const TensorDesc& t) { return t.W + 2 * t.pad; }
+
+// Tap set of one conv launch: a product of an arithmetic row list and an
+// arithmetic column list (no per-tap tables, so nothing is indexed dynamically
+// out of the kernel arguments).  Tap (ir, ic), ir < nr, ic < nc:
+//   input offset  dy = dy0 + ir*dys, dx = dx0 + ic*dxs   (padded coordinates)
+//   weight slice  w0 + ir*wrs + ic*wcs
+struct TapSet {
+    int nr, nc;
+    int dy0, dys, dx0, dxs;
+    int w0, wrs, wcs;
+};
+
+// One implicit-GEMM convolution launch (forward conv, or data-gradient conv).
+// Output pixels are enumerated on a sub-grid (Hs x Ws per image); output pixel
+// (y, x) of the sub-grid lands at (y*osub+oph, x*osub+opw) of tensor Y and
+// gathers, for tap i, input pixel (y*istr + dy[i], x*istr + dx[i]) in the
+// PADDED coordinate space of X.  All gathers are in bounds by construction of
+// the zero borders ("data layout").
+struct ConvParams {
+    const bf16_t* x; int xHp, xWp, xC;          // padded dims, pixel stride (elements)
+    const bf16_t* w;                            // [tap][Co][Kc] bf16
+    bf16_t* y; int yHp, yWp, yC, ypad;
+    float* stats;                               // [mtiles][2][Co] partial sum / sumsq, or null
+    const float* ep_scale; const float* ep_shift;   // eval epilogue: y = relu?(scale*acc+shift(+res))
+    const bf16_t* res; int rHp, rWp, rC, rpad;  // residual for the eval epilogue (padded act) or null
+    int ep_relu;
+    int N, Hs, Ws, osub, oph, opw, istr;
+    int Kc, Co;
+    int M;                                      // N*Hs*Ws
+    int accumulate;                             // y += result
+    TapSet taps;
+};
+
+// One weight-gradient launch: dw[tap][co][kc] += sum_m dz[m][co] * x[gather(m,tap)][kc]
+struct WgradParams {
+    const bf16_t* dz; int dzHp, dzWp, dzC, dzpad;
+    const bf16_t* x; int xHp, xWp, xC;
+    float* dw;                                  // [ntaps][Co][Kc] fp32 (atomically accumulated)
+    int N, Hs, Ws, istr;
+    int Kc, Co;
+    int M;
+    int chunks_per_block;                       // 128-pixel chunks handled by one block
+    TapSet taps;                                // w0 + ir*wrs + ic*wcs indexes the dw slice
+};

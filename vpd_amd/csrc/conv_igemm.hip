@@ -1,0 +1,250 @@
+// Implicit-GEMM convolution on bf16 MFMA (gfx950).  One kernel serves the
+// forward convolutions (7x7 s2 stem as 7 row-taps of 64 contiguous values,
+// 3x3 s1/s2, 1x1 s2) and the data-gradient convolutions (3x3 s1 as a flipped
+// conv; stride-2 convs as one launch per output parity class).
+//
+// GEMM view: rows = output channels (Co), cols = output pixels (M), K = taps x Kc.
+// The MFMA "A" operand is the weight tile, the "B" operand the gathered pixel
+// tile, so each lane ends up with 4 consecutive channels of one pixel and the
+// NHWC store is 8 bytes per lane.
+//
+// Pipeline per 64-deep K-step: global->register prefetch of step s+1 is issued
+// before the MFMAs of step s, written to the other LDS buffer after them; one
+// barrier per step.  LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B
+// chunk index XOR-ed by (row & 7): conflict-free for ds_read_b128 fragments.
+#include "common.h"
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int WTM = BM / WM;          // pixels per wave
+    constexpr int WTN = BN / WN;          // channels per wave
+    constexpr int MI = WTM / 16;
+    constexpr int NI = WTN / 16;
+    constexpr int PR = BM / 32;           // pixel rows staged per thread
+    constexpr int WR = BN / 32;           // weight rows staged per thread
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sP = reinterpret_cast<bf16_t*>(smem);                 // [2][BM*64]
+    bf16_t* sW = sP + 2 * BM * 64;                                // [2][BN*64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int mtile = blockIdx.x;
+    const int n0 = blockIdx.y * BN;
+    const int m0 = mtile * BM;
+
+    const int piece = tid & 7;
+    const int row0 = tid >> 3;
+
+    // per-thread gather bases (element offsets into x) for its PR pixel rows
+    int pixbase[PR];
+    const int HW = p.Hs * p.Ws;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+        int m = m0 + row0 + 32 * i;
+        m = m < p.M ? m : p.M - 1;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int yy = r / p.Ws;
+        const int xx = r - yy * p.Ws;
+        pixbase[i] = ((b * p.xHp + yy * p.istr) * p.xWp + xx * p.istr) * p.xC + piece * 8;
+    }
+    const int kchunks = p.Kc >> 6;
+    const int nsteps = p.taps.nr * p.taps.nc * kchunks;
+
+    u32x4 rp[PR], rw[WR];
+    auto load_step = [&](int s) __attribute__((always_inline)) {
+        const int tap = s / kchunks;
+        const int cc = s - tap * kchunks;
+        const int ir = tap / p.taps.nc;
+        const int ic = tap - ir * p.taps.nc;
+        const int toff = ((p.taps.dy0 + ir * p.taps.dys) * p.xWp + (p.taps.dx0 + ic * p.taps.dxs)) * p.xC + cc * 64;
+        const int wsl = p.taps.w0 + ir * p.taps.wrs + ic * p.taps.wcs;
+#pragma unroll
+        for (int i = 0; i < PR; ++i)
+            rp[i] = *reinterpret_cast<const u32x4*>(p.x + pixbase[i] + toff);
+        const bf16_t* wb = p.w + ((size_t)wsl * p.Co + n0) * p.Kc + cc * 64 + piece * 8;
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            rw[i] = *reinterpret_cast<const u32x4*>(wb + (size_t)(row0 + 32 * i) * p.Kc);
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        bf16_t* dP = sP + buf * BM * 64;
+        bf16_t* dW = sW + buf * BN * 64;
+#pragma unroll
+        for (int i = 0; i < PR; ++i) {
+            const int r = row0 + 32 * i;
+            *reinterpret_cast<u32x4*>(dP + r * 64 + ((piece ^ (r & 7)) << 3)) = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            const int r = row0 + 32 * i;
+            *reinterpret_cast<u32x4*>(dW + r * 64 + ((piece ^ (r & 7)) << 3)) = rw[i];
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_step(s + 1);
+        const bf16_t* cP = sP + buf * BM * 64;
+        const bf16_t* cW = sW + buf * BN * 64;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[NI], bfm[MI];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int a = 0; a < NI; ++a) {
+                const int r = wn * WTN + a * 16 + fr;
+                af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int r = wm * WTM + b * 16 + fr;
+                bfm[b] = *reinterpret_cast<const bf16x8*>(cP + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
+
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = m0 + wm * WTM + b * 16 + fr;
+        const bool valid = m < p.M;
+        const int mc = valid ? m : p.M - 1;
+        const int bi = mc / HW;
+        const int r = mc - bi * HW;
+        const int yy = r / p.Ws;
+        const int xx = r - yy * p.Ws;
+        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + p.oph + p.ypad) * p.yWp +
+                             (xx * p.osub + p.opw + p.ypad)) * p.yC;
+        size_t roff = 0;
+        if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (p.ep_scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
+                const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (p.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+                    v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
+                    v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
+                }
+                if (p.ep_relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                }
+            }
+            bf16_t* dst = p.y + yoff + n;
+            if (p.accumulate && valid) {
+                const uint2 ov = *reinterpret_cast<const uint2*>(dst);
+                v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
+                v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
+            }
+            uint2 ov;
+            ov.x = pack2bf(v[0], v[1]);
+            ov.y = pack2bf(v[2], v[3]);
+            if (valid) {
+                *reinterpret_cast<uint2*>(dst) = ov;
+                // statistics are taken over the bf16-rounded values actually stored
+                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
+                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
+                s1[a][0] += q0; s2[a][0] += q0 * q0;
+                s1[a][1] += q1; s2[a][1] += q1 * q1;
+                s1[a][2] += q2; s2[a][2] += q2 * q2;
+                s1[a][3] += q3; s2[a][3] += q3 * q3;
+            }
+        }
+    }
+
+    if (p.stats) {
+        // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
+        float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = s1[a][j], v = s2[a][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    u += __shfl_xor(u, o, 64);
+                    v += __shfl_xor(v, o, 64);
+                }
+                if (fr == 0) {
+                    const int c = wn * WTN + a * 16 + 4 * fq + j;
+                    red[(wm * 2 + 0) * BN + c] = u;
+                    red[(wm * 2 + 1) * BN + c] = v;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN;
+            const int c = tid - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
+            p.stats[((size_t)mtile * 2 + which) * p.Co + n0 + c] = t;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
+    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// BM used for a problem: the stats partial buffer has ceil(M/BM) rows.
+extern "C" int vpd_conv_bm(int M, int Co) {
+    const int bn = (Co % 128 == 0) ? 128 : 64;
+    if (bn == 128) {
+        if ((long)((M + 127) / 128) * (Co / 128) >= 384) return 128;
+        return 64;
+    }
+    return 128;
+}
+
+hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream) {
+    if (p.Kc % 64 != 0 || p.Co % 64 != 0 || p.M <= 0) return hipErrorInvalidValue;
+    const int bm = vpd_conv_bm(p.M, p.Co);
+    if (p.Co % 128 == 0) {
+        if (bm == 128) return launch_cfg<128, 128, 2, 2>(p, stream);
+        return launch_cfg<64, 64, 2, 2>(p, stream);
+    }
+    return launch_cfg<128, 64, 2, 2>(p, stream);
+}

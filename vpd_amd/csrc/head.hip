@@ -1,0 +1,176 @@
+// Embedding head: global average pool, the fc / motion-MLP linears (small fp32
+// GEMMs, <0.1 % of the FLOPs), sum-MSE loss and its gradient.
+#include "common.h"
+#include "kernels.h"
+
+// pooled[b][c] = mean over the H*W interior pixels of a padded activation
+__global__ __launch_bounds__(256) void avgpool_kernel(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C,
+                                                      int N, float* pooled) {
+    const int cv = C >> 3;
+    const long total = (long)N * cv;
+    const float inv = 1.f / (float)(H * W);
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(it / cv);
+        const int c = (int)(it - (long)b * cv) << 3;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(act + ((size_t)(b * Hp + y + pad) * Wp + x + pad) * C + c), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            }
+        float* o = pooled + (size_t)b * C + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = acc[j] * inv;
+    }
+}
+hipError_t vpd_launch_avgpool(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, float* pooled,
+                              hipStream_t s) {
+    long items = (long)N * (C / 8);
+    int g = (int)((items + 255) / 256);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, s, act, Hp, Wp, pad, H, W, C, N, pooled);
+    return hipGetLastError();
+}
+
+// dact[b][y][x][c] (dense bf16) = dpooled[b][c] / (H*W)
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dpooled, int HW, int C, int N, bf16_t* dact) {
+    const int cv = C >> 3;
+    const long total = (long)N * HW * cv;
+    const float inv = 1.f / (float)HW;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(it % cv) << 3;
+        const long m = it / cv;
+        const int b = (int)(m / HW);
+        float v[8];
+        const float* d = dpooled + (size_t)b * C + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = d[j] * inv;
+        *reinterpret_cast<uint4*>(dact + (size_t)m * C + c) = pack8(v);
+    }
+}
+hipError_t vpd_launch_avgpool_bwd(const float* dpooled, int H, int W, int C, int N, bf16_t* dact, hipStream_t s) {
+    long items = (long)N * H * W * (C / 8);
+    long g = (items + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, dpooled, H * W, C, N, dact);
+    return hipGetLastError();
+}
+
+// Small fp32 GEMM, 32x32 output tile per block, K staged 32 at a time in LDS.
+__global__ __launch_bounds__(256) void sgemm_small_kernel(const float* A, const float* B, float* Y, const float* bias,
+                                                          int M, int N, int K, int ta, int tb, int relu) {
+    __shared__ float sA[32][33];   // [m][k]
+    __shared__ float sB[32][33];   // [k][n]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty 0..7
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[4] = {0, 0, 0, 0};                                  // rows ty, ty+8, ty+16, ty+24; col tx
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = ty + 8 * i;
+            // A tile element (m = m0 + r, k = k0 + tx)  -- or transposed assignment for coalescing
+            {
+                int m, k;
+                if (ta) { m = m0 + tx; k = k0 + r; } else { m = m0 + r; k = k0 + tx; }
+                float v = 0.f;
+                if (m < M && k < K) v = ta ? A[(size_t)k * M + m] : A[(size_t)m * K + k];
+                if (ta) sA[tx][r] = v; else sA[r][tx] = v;
+            }
+            {
+                int k, n;
+                if (tb) { n = n0 + r; k = k0 + tx; } else { k = k0 + r; n = n0 + tx; }
+                float v = 0.f;
+                if (n < N && k < K) v = tb ? B[(size_t)n * K + k] : B[(size_t)k * N + n];
+                if (tb) sB[tx][r] = v; else sB[r][tx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float bv = sB[k][tx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += sA[ty + 8 * i][k] * bv;
+        }
+        __syncthreads();
+    }
+    const int n = n0 + tx;
+    if (n < N) {
+        const float bb = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + ty + 8 * i;
+            if (m < M) {
+                float v = acc[i] + bb;
+                if (relu) v = v > 0.f ? v : 0.f;
+                Y[(size_t)m * N + n] = v;
+            }
+        }
+    }
+}
+hipError_t vpd_launch_sgemm(const float* A, const float* B, float* Y, const float* bias, int M, int N, int K, int ta,
+                            int tb, int relu, hipStream_t s) {
+    dim3 grid((N + 31) / 32, (M + 31) / 32);
+    hipLaunchKernelGGL(sgemm_small_kernel, grid, dim3(256), 0, s, A, B, Y, bias, M, N, K, ta, tb, relu);
+    return hipGetLastError();
+}
+
+// out[n] = sum_m A[m][n]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* A, int M, int N, float* out) {
+    __shared__ float sh[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + tx;
+    float a = 0.f;
+    if (n < N)
+        for (int m = ty; m < M; m += 8) a += A[(size_t)m * N + n];
+    sh[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += sh[i][tx];
+        out[n] = t;
+    }
+}
+hipError_t vpd_launch_colsum(const float* A, int M, int N, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, s, A, M, N, out);
+    return hipGetLastError();
+}
+
+__global__ void relu_mask_kernel(float* d, const float* act, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        d[i] = act[i] > 0.f ? d[i] : 0.f;
+}
+hipError_t vpd_launch_relu_mask(float* d, const float* act, long n, hipStream_t s) {
+    long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, d, act, n);
+    return hipGetLastError();
+}
+
+// loss = sum (e - t)^2 ; de = 2 (e - t).  One block: wave shuffles + LDS, no atomics.
+__global__ __launch_bounds__(1024) void mse_kernel(const float* e, const float* t, long n, float* de,
+                                                   float* loss_step, double* loss_accum) {
+    __shared__ float sh[16];
+    float a = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float d = e[i] - t[i];
+        a += d * d;
+        if (de) de[i] = 2.f * d;
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += sh[i];
+        if (loss_step) loss_step[0] = tot;
+        if (loss_accum) loss_accum[0] += (double)tot;
+    }
+}
+hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, float* loss_step, double* loss_accum,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, e, t, n, de, loss_step, loss_accum);
+    return hipGetLastError();
+}

@@ -1,0 +1,91 @@
+// Host-side launcher declarations for the HIP kernels (internal to libvpdhip).
+#pragma once
+#include "common.h"
+
+struct BnApplyParams {
+    const bf16_t* z;                    // dense [M][C]
+    const float* scale; const float* shift;
+    int res_kind;                       // 0 none, 1 padded activation, 2 dense z with rscale/rshift
+    const bf16_t* res; int rHp, rWp, rpad;
+    const float* rscale; const float* rshift;
+    bf16_t* out; int oHp, oWp, opad;    // padded output
+    int M, H, W, C, relu;
+};
+
+struct StemPoolParams {
+    const bf16_t* z; int Hz, Wz;        // dense conv output
+    const float* scale; const float* shift;
+    bf16_t* out; int opad;              // padded pooled output
+    unsigned char* idx;                 // dense argmax (train) or null
+    int N, Ho, Wo, C;
+};
+
+struct BnBwdParams {
+    const bf16_t* dy;                   // dense [M][C] gradient w.r.t. the BN(+ReLU) output
+    bf16_t* dy_rw;                      // same buffer, written with g when write_g
+    const bf16_t* z;                    // dense conv output saved by forward
+    const bf16_t* act; int aHp, aWp, apad;   // padded post-ReLU activation (mask) or null
+    const float* mean; const float* rstd;
+    float* coef;                        // [3][C] scratch
+    float* partials;                    // [T][2][C] scratch
+    bf16_t* dz; int dzHp, dzWp, dzpad;  // output (padded or dense)
+    int M, H, W, C, write_g, ppb;
+};
+
+struct StemPoolBwdParams {
+    const bf16_t* dpool;                // dense [N][Ho][Wo][C]
+    const unsigned char* idx;
+    const bf16_t* z;                    // dense [N][Hz][Wz][C]
+    const float* mean; const float* rstd; const float* scale; const float* shift;
+    bf16_t* g;                          // dense [M][C] out
+    float* partials;
+    int M, Hz, Wz, Ho, Wo, C, ppb;
+};
+
+struct PackDesc {                       // one convolution's weight tensors
+    long long src_off;                  // fp32 OIHW master / grad offset (elements) in the flat buffers
+    long long fwd_off;                  // bf16 [ntaps][Co][Kc] offset in the packed-weight arena
+    long long dgr_off;                  // bf16 [kh*kw][Ci][Co] offset (dgrad layout) or -1
+    long long wg_off;                   // fp32 [ntaps][Co][Kc] offset in the wgrad scratch
+    int Co, Ci, kh, kw, Kc, ntaps, stem;
+};
+
+hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
+extern "C" int vpd_conv_bm(int M, int Co);
+hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
+
+hipError_t vpd_launch_bn_finalize(const float* partials, int T, int C, float count, const float* gamma,
+                                  const float* beta, float* rm, float* rv, float momentum, float eps,
+                                  float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
+hipError_t vpd_launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                              float* scale, float* shift, int C, hipStream_t s);
+hipError_t vpd_launch_bn_apply(const BnApplyParams& p, hipStream_t s);
+hipError_t vpd_launch_stem_pool(const StemPoolParams& p, hipStream_t s);
+int vpd_bn_bwd_blocks(int M, int C, int* ppb_out);
+hipError_t vpd_launch_bn_bwd(const BnBwdParams& p, float count, const float* gamma, float* dgamma, float* dbeta,
+                             hipStream_t s);
+hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p, float count, const float* gamma, float* dgamma,
+                                    float* dbeta, float* coef, bf16_t* dz, hipStream_t s);
+
+// head.hip
+hipError_t vpd_launch_avgpool(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, float* pooled,
+                              hipStream_t s);
+hipError_t vpd_launch_avgpool_bwd(const float* dpooled, int H, int W, int C, int N, bf16_t* dact, hipStream_t s);
+// Y[M][N] (=|+=) op(A)[M][K] * op(B)[K][N] (+ bias[N]) (relu?)   fp32, row-major
+//   ta: A is stored [K][M];  tb: B is stored [N][K]
+hipError_t vpd_launch_sgemm(const float* A, const float* B, float* Y, const float* bias, int M, int N, int K, int ta,
+                            int tb, int relu, hipStream_t s);
+hipError_t vpd_launch_colsum(const float* A, int M, int N, float* out, hipStream_t s);
+hipError_t vpd_launch_relu_mask(float* d, const float* act, long n, hipStream_t s);
+hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, float* loss_step, double* loss_accum,
+                          hipStream_t s);
+
+// optim.hip
+hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
+                                 int Cp, hipStream_t s);
+hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
+                                   const float* master, bf16_t* arena, hipStream_t s);
+hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
+                                   const float* wg, float* grads, hipStream_t s);
+hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, float wd, int step, hipStream_t s);

@@ -1,0 +1,132 @@
+// Layout conversion at the reference boundary (fp32 NCHW / OIHW <-> internal
+// bf16 NHWC / packed-tap weights) and the fused AdamW step.
+#include "common.h"
+#include "kernels.h"
+
+// f32 [N][C][H][W] -> bf16 [N][Hp][Wp][Cp] interior (zero border is pre-set and never written)
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* x, int N, int C, int H, int W, bf16_t* out,
+                                                         int Hp, int Wp, int pad, int Cp) {
+    const long total = (long)N * H * W;
+    const long plane = (long)H * W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(it / plane);
+        const long r = it - (long)b * plane;
+        const int y = (int)(r / W);
+        const int xx = (int)(r - (long)y * W);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < C; ++c) v[c] = x[((size_t)b * C + c) * plane + r];
+        *reinterpret_cast<uint4*>(out + ((size_t)(b * Hp + y + pad) * Wp + xx + pad) * Cp) = pack8(v);
+    }
+}
+hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
+                                 int Cp, hipStream_t s) {
+    if (Cp != 8 || C > 8) return hipErrorInvalidValue;
+    long items = (long)N * H * W;
+    long g = (items + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+    return hipGetLastError();
+}
+
+#define PACK_CHUNK 4096
+
+// master fp32 OIHW -> bf16 forward layout [tap][Co][Kc] and dgrad layout [tap][Ci][Co]
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* descs, const int* blockmap,
+                                                           const float* master, bf16_t* arena) {
+    const PackDesc d = descs[blockmap[2 * blockIdx.x]];
+    const long e0 = (long)blockmap[2 * blockIdx.x + 1] * PACK_CHUNK;
+    const float* src = master + d.src_off;
+    const int khw = d.kh * d.kw;
+    const long nf = (long)d.ntaps * d.Co * d.Kc;
+    for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < nf; e += 256) {
+        const int kc = (int)(e % d.Kc);
+        const long q = e / d.Kc;
+        const int co = (int)(q % d.Co);
+        const int tap = (int)(q / d.Co);
+        float v = 0.f;
+        if (d.stem) {                   // tap = kernel row r; kc = t*8 + c
+            const int t = kc >> 3, c = kc & 7;
+            if (t < d.kw && c < d.Ci) v = src[((size_t)(co * d.Ci + c) * d.kh + tap) * d.kw + t];
+        } else {
+            v = src[((size_t)co * d.Ci + kc) * khw + tap];
+        }
+        arena[d.fwd_off + e] = (bf16_t)v;
+    }
+    if (d.dgr_off >= 0) {
+        const long nd = (long)khw * d.Ci * d.Co;
+        for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < nd; e += 256) {
+            const int co = (int)(e % d.Co);
+            const long q = e / d.Co;
+            const int ci = (int)(q % d.Ci);
+            const int tap = (int)(q / d.Ci);
+            arena[d.dgr_off + e] = (bf16_t)src[((size_t)co * d.Ci + ci) * khw + tap];
+        }
+    }
+}
+hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
+                                   const float* master, bf16_t* arena, hipStream_t s) {
+    (void)ndesc;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, master, arena);
+    return hipGetLastError();
+}
+
+// wgrad scratch fp32 [tap][Co][Kc] -> flat gradient buffer in the reference's OIHW order
+__global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* descs, const int* blockmap, const float* wg,
+                                                           float* grads) {
+    const PackDesc d = descs[blockmap[2 * blockIdx.x]];
+    const long e0 = (long)blockmap[2 * blockIdx.x + 1] * PACK_CHUNK;
+    const int khw = d.kh * d.kw;
+    const long ns = (long)d.Co * d.Ci * khw;
+    const float* src = wg + d.wg_off;
+    for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < ns; e += 256) {
+        const int tap = (int)(e % khw);
+        const long q = e / khw;
+        const int ci = (int)(q % d.Ci);
+        const int co = (int)(q / d.Ci);
+        float v;
+        if (d.stem) {
+            const int r = tap / d.kw, t = tap - r * d.kw;
+            v = src[((size_t)r * d.Co + co) * d.Kc + t * 8 + ci];
+        } else {
+            v = src[((size_t)tap * d.Co + co) * d.Kc + ci];
+        }
+        grads[d.src_off + e] = v;
+    }
+}
+hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
+                                   const float* wg, float* grads, hipStream_t s) {
+    (void)ndesc;
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, wg, grads);
+    return hipGetLastError();
+}
+
+// Fused AdamW over the whole flat parameter buffer (every tensor shares the
+// hyper-parameters: train_vpd_model.py:104 uses one param group, wd on all).
+__global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, float4* m, float4* v, long n4,
+                                                    float decay, float b1, float b2, float step_size, float inv_sqrt_bc2,
+                                                    float eps) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+#define ADAMW1(f)                                                         \
+        pp.f *= decay;                                                    \
+        mm.f += (gg.f - mm.f) * (1.f - b1);                               \
+        vv.f = vv.f * b2 + (1.f - b2) * gg.f * gg.f;                      \
+        pp.f -= step_size * (mm.f / (sqrtf(vv.f) * inv_sqrt_bc2 + eps));
+        ADAMW1(x) ADAMW1(y) ADAMW1(z) ADAMW1(w)
+#undef ADAMW1
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, float wd, int step, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const double bc1 = 1.0 - pow((double)b1, step);
+    const double bc2 = 1.0 - pow((double)b2, step);
+    const long n4 = n / 4;
+    long gsz = (n4 + 255) / 256;
+    if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(gsz < 1 ? 1 : (int)gsz), dim3(256), 0, s, (float4*)p, (const float4*)g,
+                       (float4*)m, (float4*)v, n4, (float)(1.0 - (double)lr * wd), b1, b2, (float)((double)lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), eps);
+    return hipGetLastError();
+}

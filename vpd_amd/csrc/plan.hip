@@ -1,0 +1,829 @@
+// Network plan: owns the static description of the student (ResNet-18/34
+// BasicBlock encoder + optional motion MLP), the workspace layout, and the
+// launch sequences for eval forward, train forward+loss, backward, and the
+// weight re-pack.  Exposes the C ABI of include/vpd_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/vpd_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+static int fail(const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return -1;
+}
+#define HCHECK(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return fail(#expr, _e);  \
+    } while (0)
+
+extern "C" const char* vpd_last_error(void) { return g_err.c_str(); }
+extern "C" int vpd_abi_version(void) { return 1; }
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+constexpr float kBnMomentum = 0.1f;
+
+struct BnInfo {
+    int C = 0;
+    long long w_off = 0, b_off = 0;      // gamma / beta in the flat param buffer
+    long long rm_off = 0, rv_off = 0;    // in the running-stat buffer
+    size_t fl_off = 0;                   // float scratch in ws: mean,rstd,scale,shift,coef[3],escale,eshift (9C)
+};
+struct ConvInfo {
+    int Ci = 0, Co = 0, k = 0, stride = 1, pad = 0;
+    int Hin = 0, Win = 0, Hout = 0, Wout = 0;
+    bool stem = false;
+    int Kc = 0, ntaps = 0;
+    long long w_off = 0;                 // OIHW offset in flat params/grads
+    long long fwd_off = 0, dgr_off = -1; // bf16 element offsets in the weight arena
+    long long wg_off = 0;                // fp32 element offset in the wgrad scratch
+    BnInfo bn;
+    size_t z_off = 0;                    // dense bf16 conv output (train)
+};
+struct BlockInfo {
+    ConvInfo c1, c2, cd;
+    bool ds = false;
+    int stage = 0;
+    size_t a1_off = 0, out_off = 0;      // padded bf16 activations
+};
+struct StageInfo {
+    int H = 0, W = 0, C = 0;
+    size_t dz2_off = 0, dz1_off = 0, dzd_off = 0, idn_off = 0;
+};
+struct TensorRow {
+    int kind, is_dec;
+    long long off, numel;
+    int ndim, dims[4];
+};
+struct LinInfo {
+    int in = 0, out = 0;
+    long long w_off = 0, b_off = 0;
+};
+
+}  // namespace
+
+struct vpd_plan {
+    int c_in, H, W, D, motion, max_batch, train;
+    std::vector<int> layers;
+    ConvInfo stem;
+    std::vector<BlockInfo> blocks;
+    StageInfo stages[4];
+    LinInfo fc, dec[3];
+    std::vector<TensorRow> tensors;
+    std::vector<BnInfo*> bns;
+    long long nparam = 0, nparam_padded = 0, nbn = 0;
+    long long arena_elems = 0, wg_elems = 0;
+    // gradient buckets (flat-buffer ranges) -- bucket 0 = layer4+fc+decoder ... bucket 3 = stem+layer1
+    long long bucket_off[4], bucket_numel[4];
+    // workspace offsets (bytes)
+    size_t ws_bytes = 0;
+    size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
+    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0};
+    size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
+    size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
+    size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
+    int xHp = 0, xWp = 0;
+    int H0 = 0, W0 = 0, H1 = 0, W1 = 0;   // stem conv output, pooled output
+    // descriptor tables (host copies, uploaded by init_workspace)
+    std::vector<PackDesc> descs;
+    std::vector<int> bmap_pack;
+    std::vector<int> bmap_unpack[4];
+    size_t partial_bytes = 0;
+    // captured eval graphs keyed by batch size
+    struct Graph { int n; hipGraph_t g; hipGraphExec_t e; };
+    std::vector<Graph> graphs;
+    void* bound_ws = nullptr;
+};
+
+namespace {
+
+struct Bump {
+    size_t cur = 0;
+    size_t take(size_t bytes) {
+        size_t o = cur;
+        cur += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+};
+
+inline size_t padded_elems(int n, int H, int W, int C, int pad) {
+    return (size_t)n * (H + 2 * pad) * (W + 2 * pad) * C;
+}
+
+void add_tensor(vpd_plan* p, int kind, int is_dec, long long numel, int ndim, int d0, int d1, int d2, int d3,
+                long long* off_out) {
+    TensorRow r;
+    r.kind = kind; r.is_dec = is_dec; r.off = p->nparam; r.numel = numel; r.ndim = ndim;
+    r.dims[0] = d0; r.dims[1] = d1; r.dims[2] = d2; r.dims[3] = d3;
+    p->tensors.push_back(r);
+    *off_out = p->nparam;
+    p->nparam += numel;
+}
+
+void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int pad, int Hin, int Win, bool stem) {
+    c.Ci = Ci; c.Co = Co; c.k = k; c.stride = stride; c.pad = pad; c.Hin = Hin; c.Win = Win; c.stem = stem;
+    c.Hout = (Hin + 2 * pad - k) / stride + 1;
+    c.Wout = (Win + 2 * pad - k) / stride + 1;
+    if (stem) { c.Kc = 64; c.ntaps = k; } else { c.Kc = Ci; c.ntaps = k * k; }
+    add_tensor(p, 0, 0, (long long)Co * Ci * k * k, 4, Co, Ci, k, k, &c.w_off);
+    c.bn.C = Co;
+    add_tensor(p, 1, 0, Co, 1, Co, 0, 0, 0, &c.bn.w_off);
+    add_tensor(p, 2, 0, Co, 1, Co, 0, 0, 0, &c.bn.b_off);
+    c.bn.rm_off = p->nbn; c.bn.rv_off = p->nbn + Co;
+    p->nbn += 2 * Co;
+    c.fwd_off = p->arena_elems;
+    p->arena_elems += (long long)c.ntaps * Co * c.Kc;
+    if (!stem) {
+        c.dgr_off = p->arena_elems;
+        p->arena_elems += (long long)k * k * Ci * Co;
+    }
+    c.wg_off = p->wg_elems;
+    p->wg_elems += (long long)c.ntaps * Co * c.Kc;
+}
+
+TapSet conv_taps_fwd(const ConvInfo& c) {
+    TapSet t;
+    if (c.stem) {
+        // one tap per kernel row; the 7 column taps x 8 channels are 56 (of 64) contiguous values
+        t.nr = c.k; t.nc = 1; t.dy0 = 0; t.dys = 1; t.dx0 = 0; t.dxs = 0; t.w0 = 0; t.wrs = 1; t.wcs = 0;
+    } else {
+        // input tensors carry a 1-pixel border: padded coord = y*stride + r - pad + 1
+        t.nr = c.k; t.nc = c.k; t.dy0 = 1 - c.pad; t.dys = 1; t.dx0 = 1 - c.pad; t.dxs = 1;
+        t.w0 = 0; t.wrs = c.k; t.wcs = 1;
+    }
+    return t;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
+                               int max_batch, int train, vpd_plan_t** out) {
+    if (!arch || !out) return fail("null argument");
+    std::vector<int> layers;
+    if (!strcmp(arch, "resnet18")) layers = {2, 2, 2, 2};
+    else if (!strcmp(arch, "resnet34")) layers = {3, 4, 6, 3};
+    else return fail("unsupported arch (resnet18 | resnet34)");
+    if (c_in < 1 || c_in > 8) return fail("c_in must be in 1..8");
+    if (img_h < 32 || img_w < 32 || (img_h % 2) || (img_w % 2)) return fail("img dims must be even and >= 32");
+    if (emb_dim < 1 || max_batch < 1) return fail("bad emb_dim / max_batch");
+
+    vpd_plan* p = new vpd_plan();
+    p->c_in = c_in; p->H = img_h; p->W = img_w; p->D = emb_dim; p->motion = motion ? 1 : 0;
+    p->max_batch = max_batch; p->train = train ? 1 : 0; p->layers = layers;
+
+    // ---- topology + flat tables (reference module order) ----
+    add_conv(p, p->stem, c_in, 64, 7, 2, 3, img_h, img_w, true);
+    p->bns.push_back(&p->stem.bn);
+    p->H0 = p->stem.Hout; p->W0 = p->stem.Wout;
+    p->H1 = (p->H0 + 2 - 3) / 2 + 1; p->W1 = (p->W0 + 2 - 3) / 2 + 1;
+    int inplanes = 64, h = p->H1, w = p->W1;
+    const int widths[4] = {64, 128, 256, 512};
+    long long stage_first_tensor_off[5];
+    int nblocks_total = 0;
+    for (int s = 0; s < 4; ++s) nblocks_total += layers[s];
+    p->blocks.resize(nblocks_total);
+    int bi = 0;
+    for (int s = 0; s < 4; ++s) {
+        stage_first_tensor_off[s] = p->nparam;
+        for (int b = 0; b < layers[s]; ++b, ++bi) {
+            BlockInfo& B = p->blocks[bi];
+            const int stride = (b == 0 && s > 0) ? 2 : 1;
+            B.stage = s;
+            add_conv(p, B.c1, inplanes, widths[s], 3, stride, 1, h, w, false);
+            add_conv(p, B.c2, widths[s], widths[s], 3, 1, 1, B.c1.Hout, B.c1.Wout, false);
+            B.ds = (stride != 1 || inplanes != widths[s]);
+            if (B.ds) add_conv(p, B.cd, inplanes, widths[s], 1, stride, 0, h, w, false);
+            h = B.c1.Hout; w = B.c1.Wout; inplanes = widths[s];
+        }
+        p->stages[s].H = h; p->stages[s].W = w; p->stages[s].C = widths[s];
+    }
+    for (auto& B : p->blocks) {     // BN module order: bn1, bn2, downsample.1
+        p->bns.push_back(&B.c1.bn);
+        p->bns.push_back(&B.c2.bn);
+        if (B.ds) p->bns.push_back(&B.cd.bn);
+    }
+    if (h < 1 || w < 1) { delete p; return fail("image too small for 5 stride-2 stages"); }
+    stage_first_tensor_off[4] = p->nparam;
+    p->fc.in = 512; p->fc.out = emb_dim;
+    add_tensor(p, 3, 0, (long long)emb_dim * 512, 2, emb_dim, 512, 0, 0, &p->fc.w_off);
+    add_tensor(p, 4, 0, emb_dim, 1, emb_dim, 0, 0, 0, &p->fc.b_off);
+    if (p->motion) {
+        const int dims[4] = {emb_dim, 128, 128, 2 * emb_dim};
+        for (int i = 0; i < 3; ++i) {
+            p->dec[i].in = dims[i]; p->dec[i].out = dims[i + 1];
+            add_tensor(p, 3, 1, (long long)dims[i + 1] * dims[i], 2, dims[i + 1], dims[i], 0, 0, &p->dec[i].w_off);
+            add_tensor(p, 4, 1, dims[i + 1], 1, dims[i + 1], 0, 0, 0, &p->dec[i].b_off);
+        }
+    }
+    p->nparam_padded = (p->nparam + 3) & ~3LL;
+    // buckets in completion order
+    p->bucket_off[0] = stage_first_tensor_off[3]; p->bucket_numel[0] = p->nparam - stage_first_tensor_off[3];
+    p->bucket_off[1] = stage_first_tensor_off[2]; p->bucket_numel[1] = stage_first_tensor_off[3] - stage_first_tensor_off[2];
+    p->bucket_off[2] = stage_first_tensor_off[1]; p->bucket_numel[2] = stage_first_tensor_off[2] - stage_first_tensor_off[1];
+    p->bucket_off[3] = 0; p->bucket_numel[3] = stage_first_tensor_off[1];
+
+    // ---- pack descriptors + block maps ----
+    auto push_desc = [&](const ConvInfo& c, int bucket) {
+        PackDesc d;
+        d.src_off = c.w_off; d.fwd_off = c.fwd_off; d.dgr_off = c.dgr_off; d.wg_off = c.wg_off;
+        d.Co = c.Co; d.Ci = c.Ci; d.kh = c.k; d.kw = c.k; d.Kc = c.Kc; d.ntaps = c.ntaps; d.stem = c.stem ? 1 : 0;
+        const int id = (int)p->descs.size();
+        p->descs.push_back(d);
+        const long long nf = (long long)c.ntaps * c.Co * c.Kc;
+        const long long ns = (long long)c.Co * c.Ci * c.k * c.k;
+        const long long npk = nf > ns ? nf : ns;
+        for (long long ch = 0; ch * 4096 < npk; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
+        for (long long ch = 0; ch * 4096 < ns; ++ch) {
+            p->bmap_unpack[bucket].push_back(id);
+            p->bmap_unpack[bucket].push_back((int)ch);
+        }
+    };
+    push_desc(p->stem, 3);
+    for (auto& B : p->blocks) {
+        const int bucket = 3 - B.stage;
+        push_desc(B.c1, bucket);
+        push_desc(B.c2, bucket);
+        if (B.ds) push_desc(B.cd, bucket);
+    }
+
+    // ---- workspace layout ----
+    Bump bp;
+    const int NB = max_batch;
+    p->xHp = img_h + 6; p->xWp = img_w + 8;
+    p->xin_off = bp.take(((size_t)NB * p->xHp * p->xWp * 8 + 256) * 2);
+    p->arena_off = bp.take((size_t)p->arena_elems * 2);
+    p->wg_off = bp.take((size_t)p->wg_elems * 4);
+    for (BnInfo* b : p->bns) b->fl_off = bp.take((size_t)9 * b->C * 4);
+    p->desc_off = bp.take(p->descs.size() * sizeof(PackDesc));
+    p->bmap_pack_off = bp.take(p->bmap_pack.size() * sizeof(int));
+    for (int i = 0; i < 4; ++i) p->bmap_unpack_off[i] = bp.take(p->bmap_unpack[i].size() * sizeof(int) + 16);
+    // statistics partials: max over layers of T*2*C floats
+    {
+        size_t mx = 0;
+        auto upd = [&](const ConvInfo& c) {
+            const long long M = (long long)NB * c.Hout * c.Wout;
+            const int bm = vpd_conv_bm((int)M, c.Co);
+            size_t t1 = (size_t)((M + bm - 1) / bm) * 2 * c.Co * 4;
+            int ppb;
+            size_t t2 = (size_t)vpd_bn_bwd_blocks((int)M, c.Co, &ppb) * 2 * c.Co * 4;
+            // small batches use smaller BM choices: be generous
+            size_t t3 = (size_t)((M + 63) / 64) * 2 * c.Co * 4;
+            mx = t1 > mx ? t1 : mx; mx = t2 > mx ? t2 : mx; mx = t3 > mx ? t3 : mx;
+        };
+        upd(p->stem);
+        for (auto& B : p->blocks) { upd(B.c1); upd(B.c2); if (B.ds) upd(B.cd); }
+        p->partial_bytes = mx;
+        p->partial_off = bp.take(mx);
+    }
+    p->z0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
+    p->p0_off = bp.take(padded_elems(NB, p->H1, p->W1, 64, 1) * 2);
+    for (auto& B : p->blocks) {
+        B.a1_off = bp.take(padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1) * 2);
+        B.out_off = bp.take(padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1) * 2);
+    }
+    for (int s = 0; s < 4; ++s) {
+        StageInfo& S = p->stages[s];
+        S.idn_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+    }
+    p->pooled_off = bp.take((size_t)NB * 512 * 4);
+    p->emb_off = bp.take((size_t)NB * emb_dim * 4);
+    p->h1_off = bp.take((size_t)NB * 128 * 4);
+    p->h2_off = bp.take((size_t)NB * 128 * 4);
+    p->pred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
+    if (p->train) {
+        p->idx_off = bp.take((size_t)NB * p->H1 * p->W1 * 64);
+        size_t maxact = (size_t)NB * p->H1 * p->W1 * 64;
+        for (auto& B : p->blocks) {
+            B.c1.z_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co * 2);
+            B.c2.z_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co * 2);
+            if (B.ds) B.cd.z_off = bp.take((size_t)NB * B.cd.Hout * B.cd.Wout * B.cd.Co * 2);
+            size_t e = (size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co;
+            maxact = e > maxact ? e : maxact;
+        }
+        for (int s = 0; s < 4; ++s) {
+            StageInfo& S = p->stages[s];
+            S.dz2_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+            S.dz1_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+            S.dzd_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+        }
+        for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
+        p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
+        p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
+        p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
+        p->dh2_off = bp.take((size_t)NB * 128 * 4);
+        p->dh1_off = bp.take((size_t)NB * 128 * 4);
+        p->demb_off = bp.take((size_t)NB * emb_dim * 4);
+        p->dpooled_off = bp.take((size_t)NB * 512 * 4);
+    }
+    p->ws_bytes = bp.cur;
+    *out = p;
+    return 0;
+}
+
+extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
+    if (!p) return;
+    for (auto& g : p->graphs) {
+        (void)hipGraphExecDestroy(g.e);
+        (void)hipGraphDestroy(g.g);
+    }
+    delete p;
+}
+
+extern "C" int vpd_plan_num_tensors(const vpd_plan_t* p) { return (int)p->tensors.size(); }
+extern "C" int vpd_plan_tensor_info(const vpd_plan_t* p, int i, int* kind, int* is_decoder, long long* offset,
+                                    long long* numel, int* ndim, int dims[4]) {
+    if (i < 0 || i >= (int)p->tensors.size()) return fail("tensor index out of range");
+    const TensorRow& r = p->tensors[i];
+    *kind = r.kind; *is_decoder = r.is_dec; *offset = r.off; *numel = r.numel; *ndim = r.ndim;
+    for (int k = 0; k < 4; ++k) dims[k] = r.dims[k];
+    return 0;
+}
+extern "C" long long vpd_plan_param_numel(const vpd_plan_t* p) { return p->nparam_padded; }
+extern "C" int vpd_plan_num_bn(const vpd_plan_t* p) { return (int)p->bns.size(); }
+extern "C" int vpd_plan_bn_info(const vpd_plan_t* p, int i, int* channels, long long* rm_off, long long* rv_off) {
+    if (i < 0 || i >= (int)p->bns.size()) return fail("bn index out of range");
+    *channels = p->bns[i]->C; *rm_off = p->bns[i]->rm_off; *rv_off = p->bns[i]->rv_off;
+    return 0;
+}
+extern "C" long long vpd_plan_bn_numel(const vpd_plan_t* p) { return p->nbn; }
+extern "C" int vpd_plan_num_buckets(const vpd_plan_t*) { return 4; }
+extern "C" int vpd_plan_bucket_range(const vpd_plan_t* p, int b, long long* offset, long long* numel) {
+    if (b < 0 || b >= 4) return fail("bucket index out of range");
+    *offset = p->bucket_off[b]; *numel = p->bucket_numel[b];
+    return 0;
+}
+extern "C" size_t vpd_plan_workspace_bytes(const vpd_plan_t* p) { return p->ws_bytes; }
+
+extern "C" int vpd_plan_init_workspace(vpd_plan_t* p, void* ws, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    char* w = (char*)ws;
+    HCHECK(hipMemsetAsync(ws, 0, p->ws_bytes, s));
+    HCHECK(hipMemcpyAsync(w + p->desc_off, p->descs.data(), p->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s));
+    HCHECK(hipMemcpyAsync(w + p->bmap_pack_off, p->bmap_pack.data(), p->bmap_pack.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < 4; ++i)
+        if (!p->bmap_unpack[i].empty())
+            HCHECK(hipMemcpyAsync(w + p->bmap_unpack_off[i], p->bmap_unpack[i].data(),
+                                  p->bmap_unpack[i].size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HCHECK(hipStreamSynchronize(s));   // host vectors may be re-read only now; one-time setup
+    p->bound_ws = ws;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Ctx {
+    vpd_plan* p;
+    char* ws;
+    hipStream_t s;
+    const float* params;
+    int n;
+    bf16_t* b16(size_t off) const { return reinterpret_cast<bf16_t*>(ws + off); }
+    float* f32(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    float* bn_mean(const BnInfo& b) const { return f32(b.fl_off); }
+    float* bn_rstd(const BnInfo& b) const { return f32(b.fl_off) + b.C; }
+    float* bn_scale(const BnInfo& b) const { return f32(b.fl_off) + 2 * b.C; }
+    float* bn_shift(const BnInfo& b) const { return f32(b.fl_off) + 3 * b.C; }
+    float* bn_coef(const BnInfo& b) const { return f32(b.fl_off) + 4 * b.C; }
+    float* bn_escale(const BnInfo& b) const { return f32(b.fl_off) + 7 * b.C; }
+    float* bn_eshift(const BnInfo& b) const { return f32(b.fl_off) + 8 * b.C; }
+};
+
+// forward convolution launch; input padded activation `x` (border 1; stem: xin), output `y`
+hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
+                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu) {
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = x;
+    if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
+    else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
+    q.w = c.b16(c.p->arena_off) + cv.fwd_off;
+    q.y = y; q.yHp = cv.Hout + 2 * ypad; q.yWp = cv.Wout + 2 * ypad; q.yC = cv.Co; q.ypad = ypad;
+    q.stats = stats ? c.f32(c.p->partial_off) : nullptr;
+    q.ep_scale = ep_scale; q.ep_shift = ep_shift; q.res = res; q.ep_relu = ep_relu;
+    q.rHp = cv.Hout + 2; q.rWp = cv.Wout + 2; q.rC = cv.Co; q.rpad = 1;
+    q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
+    q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
+    q.taps = conv_taps_fwd(cv);
+    return vpd_launch_conv(q, c.s);
+}
+
+hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) {
+    const int M = c.n * cv.Hout * cv.Wout;
+    const int bm = vpd_conv_bm(M, cv.Co);
+    const int T = (M + bm - 1) / bm;
+    return vpd_launch_bn_finalize(c.f32(c.p->partial_off), T, cv.Co, (float)M, c.params + cv.bn.w_off,
+                                  c.params + cv.bn.b_off, bn_running ? bn_running + cv.bn.rm_off : nullptr,
+                                  bn_running ? bn_running + cv.bn.rv_off : nullptr, kBnMomentum, kBnEps,
+                                  c.bn_mean(cv.bn), c.bn_rstd(cv.bn), c.bn_scale(cv.bn), c.bn_shift(cv.bn), c.s);
+}
+
+// data-gradient of a conv: dz (padded, border 1) -> dx (dense [n][Hin][Win][Ci])
+hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
+    q.w = c.b16(c.p->arena_off) + cv.dgr_off;
+    q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
+    q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
+    hipError_t e = hipSuccess;
+    if (cv.stride == 1) {
+        // dx[y][x] = sum_{r,t} dz[y + pad - r][x + pad - t] W[r][t]; padded coord adds 1
+        q.Hs = cv.Hin; q.Ws = cv.Win; q.osub = 1; q.oph = 0; q.opw = 0;
+        q.M = c.n * q.Hs * q.Ws;
+        q.taps.nr = cv.k; q.taps.nc = cv.k;
+        q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
+        q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
+        return vpd_launch_conv(q, c.s);
+    }
+    // stride 2: one launch per input-pixel parity class; only taps r with (ph + pad - r) even
+    // contribute: r = rf, rf+2, ... with dz row  y + (ph + pad - r)/2  (+1 for the border)
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            q.Hs = (cv.Hin - ph + 1) / 2; q.Ws = (cv.Win - pw + 1) / 2;
+            if (q.Hs <= 0 || q.Ws <= 0) continue;
+            q.osub = 2; q.oph = ph; q.opw = pw;
+            q.M = c.n * q.Hs * q.Ws;
+            const int rf = (ph + cv.pad) % 2, tf = (pw + cv.pad) % 2;
+            q.taps.nr = rf < cv.k ? (cv.k - rf + 1) / 2 : 0;
+            q.taps.nc = tf < cv.k ? (cv.k - tf + 1) / 2 : 0;
+            if (q.taps.nr == 0 || q.taps.nc == 0) continue;   // caller zero-fills / overwrites those pixels
+            q.taps.dy0 = (ph + cv.pad - rf) / 2 + 1; q.taps.dys = -1;
+            q.taps.dx0 = (pw + cv.pad - tf) / 2 + 1; q.taps.dxs = -1;
+            q.taps.w0 = rf * cv.k + tf; q.taps.wrs = 2 * cv.k; q.taps.wcs = 2;
+            e = vpd_launch_conv(q, c.s);
+            if (e != hipSuccess) return e;
+        }
+    return e;
+}
+
+hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) {
+    WgradParams q;
+    memset(&q, 0, sizeof q);
+    q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
+    q.x = x;
+    if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
+    else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
+    q.dw = c.f32(c.p->wg_off) + cv.wg_off;
+    q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
+    q.M = c.n * cv.Hout * cv.Wout;
+    q.taps = conv_taps_fwd(cv);
+    return vpd_launch_wgrad(q, c.s);
+}
+
+hipError_t run_bn_apply(const Ctx& c, const ConvInfo& cv, int res_kind, const bf16_t* res, const ConvInfo* rcv,
+                        bf16_t* out, int relu) {
+    BnApplyParams a;
+    memset(&a, 0, sizeof a);
+    a.z = c.b16(cv.z_off); a.scale = c.bn_scale(cv.bn); a.shift = c.bn_shift(cv.bn);
+    a.res_kind = res_kind; a.res = res; a.rHp = cv.Hout + 2; a.rWp = cv.Wout + 2; a.rpad = 1;
+    if (rcv) { a.rscale = c.bn_scale(rcv->bn); a.rshift = c.bn_shift(rcv->bn); }
+    a.out = out; a.oHp = cv.Hout + 2; a.oWp = cv.Wout + 2; a.opad = 1;
+    a.M = c.n * cv.Hout * cv.Wout; a.H = cv.Hout; a.W = cv.Wout; a.C = cv.Co; a.relu = relu;
+    return vpd_launch_bn_apply(a, c.s);
+}
+
+hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
+                      int write_g, float* grads) {
+    BnBwdParams b;
+    memset(&b, 0, sizeof b);
+    b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
+    b.act = act; b.aHp = cv.Hout + 2; b.aWp = cv.Wout + 2; b.apad = 1;
+    b.mean = c.bn_mean(cv.bn); b.rstd = c.bn_rstd(cv.bn); b.coef = c.bn_coef(cv.bn);
+    b.partials = c.f32(c.p->partial_off);
+    b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
+    b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
+    return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s);
+}
+
+#define LCHECK(expr)                                   \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return fail(#expr, _e);  \
+    } while (0)
+
+int check_call(const vpd_plan* p, const void* ws, int n) {
+    if (!p || !ws) return fail("null plan / workspace");
+    if (p->bound_ws != ws) return fail("workspace not initialised with vpd_plan_init_workspace");
+    if (n < 1 || n > p->max_batch) return fail("batch size outside 1..max_batch");
+    return 0;
+}
+
+// encoder head shared by eval / train: avgpool + fc (+ motion MLP) (+ loss)
+int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* target, bool need_grad,
+             float* loss_step, double* loss_accum) {
+    vpd_plan* p = c.p;
+    const StageInfo& S = p->stages[3];
+    LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, 512, c.n, c.f32(p->pooled_off), c.s));
+    float* emb = c.f32(p->emb_off);
+    LCHECK(vpd_launch_sgemm(c.f32(p->pooled_off), c.params + p->fc.w_off, emb, c.params + p->fc.b_off, c.n, p->D, 512,
+                            0, 1, 0, c.s));
+    if (emb_out) LCHECK(hipMemcpyAsync(emb_out, emb, (size_t)c.n * p->D * 4, hipMemcpyDeviceToDevice, c.s));
+    if (!target) return 0;
+    const float* pred = emb;
+    int pd = p->D;
+    if (p->motion) {
+        LCHECK(vpd_launch_sgemm(emb, c.params + p->dec[0].w_off, c.f32(p->h1_off), c.params + p->dec[0].b_off, c.n, 128,
+                                p->D, 0, 1, 1, c.s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->h1_off), c.params + p->dec[1].w_off, c.f32(p->h2_off),
+                                c.params + p->dec[1].b_off, c.n, 128, 128, 0, 1, 1, c.s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->h2_off), c.params + p->dec[2].w_off, c.f32(p->pred_off),
+                                c.params + p->dec[2].b_off, c.n, 2 * p->D, 128, 0, 1, 0, c.s));
+        pred = c.f32(p->pred_off);
+        pd = 2 * p->D;
+    }
+    LCHECK(vpd_launch_mse(pred, target, (long)c.n * pd, need_grad ? c.f32(p->dpred_off) : nullptr, loss_step,
+                          loss_accum, c.s));
+    return 0;
+}
+
+int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, float* emb_out, const float* target,
+                     float* loss_step, double* loss_accum, char* ws, hipStream_t s) {
+    Ctx c{p, ws, s, params, n};
+    LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
+    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, false, nullptr, nullptr, nullptr, 0));
+    {
+        StemPoolParams sp;
+        memset(&sp, 0, sizeof sp);
+        sp.z = c.b16(p->z0_off); sp.Hz = p->H0; sp.Wz = p->W0;
+        sp.scale = c.bn_escale(p->stem.bn); sp.shift = c.bn_eshift(p->stem.bn);
+        sp.out = c.b16(p->p0_off); sp.opad = 1; sp.idx = nullptr; sp.N = n; sp.Ho = p->H1; sp.Wo = p->W1; sp.C = 64;
+        LCHECK(vpd_launch_stem_pool(sp, s));
+    }
+    const bf16_t* cur = c.b16(p->p0_off);
+    for (auto& B : p->blocks) {
+        bf16_t* a1 = c.b16(B.a1_off);
+        bf16_t* outp = c.b16(B.out_off);
+        LCHECK(run_conv_fwd(c, B.c1, cur, a1, 1, false, c.bn_escale(B.c1.bn), c.bn_eshift(B.c1.bn), nullptr, 1));
+        const bf16_t* idn = cur;
+        if (B.ds) {
+            bf16_t* idb = c.b16(p->stages[B.stage].idn_off);
+            LCHECK(run_conv_fwd(c, B.cd, cur, idb, 1, false, c.bn_escale(B.cd.bn), c.bn_eshift(B.cd.bn), nullptr, 0));
+            idn = idb;
+        }
+        LCHECK(run_conv_fwd(c, B.c2, a1, outp, 1, false, c.bn_escale(B.c2.bn), c.bn_eshift(B.c2.bn), idn, 1));
+        cur = outp;
+    }
+    return run_head(c, cur, emb_out, target, false, loss_step, loss_accum);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" int vpd_pack_weights(vpd_plan_t* p, const float* params, const float* bn_running, void* workspace,
+                                void* stream) {
+    if (!p || !workspace || !params) return fail("null argument");
+    if (p->bound_ws != workspace) return fail("workspace not initialised with vpd_plan_init_workspace");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    Ctx c{p, ws, s, params, 1};
+    LCHECK(vpd_launch_pack_weights(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
+                                   reinterpret_cast<const int*>(ws + p->bmap_pack_off), (int)p->bmap_pack.size() / 2,
+                                   params, c.b16(p->arena_off), s));
+    if (bn_running)
+        for (BnInfo* b : p->bns)
+            LCHECK(vpd_launch_bn_fold(params + b->w_off, params + b->b_off, bn_running + b->rm_off,
+                                      bn_running + b->rv_off, kBnEps, c.bn_escale(*b), c.bn_eshift(*b), b->C, s));
+    return 0;
+}
+
+extern "C" int vpd_forward_eval(vpd_plan_t* p, const float* params, const float* x, int n, float* emb_out,
+                                const float* target, float* loss_step, double* loss_accum, void* workspace,
+                                void* stream) {
+    if (check_call(p, workspace, n)) return -1;
+    return run_eval_forward(p, params, x, n, emb_out, target, loss_step, loss_accum, (char*)workspace,
+                            (hipStream_t)stream);
+}
+
+extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_running, const float* x,
+                                 const float* target, int n, float* emb_out, float* loss_step, double* loss_accum,
+                                 void* workspace, void* stream) {
+    if (check_call(p, workspace, n)) return -1;
+    if (!p->train) return fail("plan was created with train=0");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    Ctx c{p, ws, s, params, n};
+    LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
+    // stem: conv -> batch stats -> BN+ReLU+maxpool
+    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0));
+    LCHECK(run_bn_finalize(c, p->stem, bn_running));
+    {
+        StemPoolParams sp;
+        memset(&sp, 0, sizeof sp);
+        sp.z = c.b16(p->z0_off); sp.Hz = p->H0; sp.Wz = p->W0;
+        sp.scale = c.bn_scale(p->stem.bn); sp.shift = c.bn_shift(p->stem.bn);
+        sp.out = c.b16(p->p0_off); sp.opad = 1; sp.idx = reinterpret_cast<unsigned char*>(ws + p->idx_off);
+        sp.N = n; sp.Ho = p->H1; sp.Wo = p->W1; sp.C = 64;
+        LCHECK(vpd_launch_stem_pool(sp, s));
+    }
+    const bf16_t* cur = c.b16(p->p0_off);
+    for (auto& B : p->blocks) {
+        bf16_t* a1 = c.b16(B.a1_off);
+        bf16_t* outp = c.b16(B.out_off);
+        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+        LCHECK(run_bn_finalize(c, B.c1, bn_running));
+        LCHECK(run_bn_apply(c, B.c1, 0, nullptr, nullptr, a1, 1));
+        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+        LCHECK(run_bn_finalize(c, B.c2, bn_running));
+        if (B.ds) {
+            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+            LCHECK(run_bn_finalize(c, B.cd, bn_running));
+            LCHECK(run_bn_apply(c, B.c2, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+        } else {
+            LCHECK(run_bn_apply(c, B.c2, 1, cur, nullptr, outp, 1));
+        }
+        cur = outp;
+    }
+    return run_head(c, cur, emb_out, target, true, loss_step, loss_accum);
+}
+
+extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, int n, void** bucket_events,
+                            void* workspace, void* stream) {
+    if (check_call(p, workspace, n)) return -1;
+    if (!p->train) return fail("plan was created with train=0");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    Ctx c{p, ws, s, params, n};
+    LCHECK(hipMemsetAsync(ws + p->wg_off, 0, (size_t)p->wg_elems * 4, s));
+
+    // ---- head ----
+    const float* demb = c.f32(p->dpred_off);
+    if (p->motion) {
+        const LinInfo* L = p->dec;
+        // layer 5: pred = h2 W2^T + b
+        LCHECK(vpd_launch_sgemm(c.f32(p->dpred_off), c.f32(p->h2_off), grads + L[2].w_off, nullptr, L[2].out, L[2].in, n, 1, 0, 0, s));
+        LCHECK(vpd_launch_colsum(c.f32(p->dpred_off), n, L[2].out, grads + L[2].b_off, s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->dpred_off), params + L[2].w_off, c.f32(p->dh2_off), nullptr, n, L[2].in, L[2].out, 0, 0, 0, s));
+        LCHECK(vpd_launch_relu_mask(c.f32(p->dh2_off), c.f32(p->h2_off), (long)n * 128, s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->dh2_off), c.f32(p->h1_off), grads + L[1].w_off, nullptr, L[1].out, L[1].in, n, 1, 0, 0, s));
+        LCHECK(vpd_launch_colsum(c.f32(p->dh2_off), n, L[1].out, grads + L[1].b_off, s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->dh2_off), params + L[1].w_off, c.f32(p->dh1_off), nullptr, n, L[1].in, L[1].out, 0, 0, 0, s));
+        LCHECK(vpd_launch_relu_mask(c.f32(p->dh1_off), c.f32(p->h1_off), (long)n * 128, s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->dh1_off), c.f32(p->emb_off), grads + L[0].w_off, nullptr, L[0].out, L[0].in, n, 1, 0, 0, s));
+        LCHECK(vpd_launch_colsum(c.f32(p->dh1_off), n, L[0].out, grads + L[0].b_off, s));
+        LCHECK(vpd_launch_sgemm(c.f32(p->dh1_off), params + L[0].w_off, c.f32(p->demb_off), nullptr, n, L[0].in, L[0].out, 0, 0, 0, s));
+        demb = c.f32(p->demb_off);
+    }
+    LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, 512, n, 1, 0, 0, s));
+    LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
+    LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, 512, p->D, 0, 0, 0, s));
+
+    int gi = 0;      // index of the G buffer holding d(out) of the current block
+    bf16_t* G[3] = {c.b16(p->G_off[0]), c.b16(p->G_off[1]), c.b16(p->G_off[2])};
+    {
+        const StageInfo& S = p->stages[3];
+        LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, 512, n, G[gi], s));
+    }
+    auto unpack_bucket = [&](int b) -> int {
+        const int nb = (int)p->bmap_unpack[b].size() / 2;
+        if (nb > 0)
+            LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
+                                           reinterpret_cast<const int*>(ws + p->bmap_unpack_off[b]), nb,
+                                           c.f32(p->wg_off), grads, s));
+        if (bucket_events && bucket_events[b]) LCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
+        return 0;
+    };
+
+    for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
+        BlockInfo& B = p->blocks[bi];
+        const StageInfo& S = p->stages[B.stage];
+        const bf16_t* xin = bi == 0 ? c.b16(p->p0_off) : c.b16(p->blocks[bi - 1].out_off);
+        bf16_t* dout = G[gi];
+        bf16_t* da1 = G[(gi + 1) % 3];
+        bf16_t* dnew = G[(gi + 2) % 3];
+        bf16_t* dz2 = c.b16(S.dz2_off);
+        bf16_t* dz1 = c.b16(S.dz1_off);
+        // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
+        LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
+        LCHECK(run_conv_wgrad(c, B.c2, dz2, 1, c.b16(B.a1_off)));
+        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
+        LCHECK(run_bn_bwd(c, B.c1, da1, c.b16(B.a1_off), dz1, 1, 0, grads));
+        LCHECK(run_conv_wgrad(c, B.c1, dz1, 1, xin));
+        if (B.ds) {
+            bf16_t* dzd = c.b16(S.dzd_off);
+            LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
+            LCHECK(run_conv_wgrad(c, B.cd, dzd, 1, xin));
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
+            LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
+            gi = (gi + 2) % 3;
+        } else {
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
+        }
+        if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
+            if (unpack_bucket(3 - B.stage)) return -1;
+        }
+    }
+    // ---- stem ----
+    {
+        StemPoolBwdParams sb;
+        memset(&sb, 0, sizeof sb);
+        sb.dpool = G[gi]; sb.idx = reinterpret_cast<const unsigned char*>(ws + p->idx_off); sb.z = c.b16(p->z0_off);
+        sb.mean = c.bn_mean(p->stem.bn); sb.rstd = c.bn_rstd(p->stem.bn);
+        sb.scale = c.bn_scale(p->stem.bn); sb.shift = c.bn_shift(p->stem.bn);
+        sb.g = c.b16(p->g0_off); sb.partials = c.f32(p->partial_off);
+        sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
+        LCHECK(vpd_launch_stem_pool_bwd(sb, (float)sb.M, params + p->stem.bn.w_off, grads + p->stem.bn.w_off,
+                                        grads + p->stem.bn.b_off, c.bn_coef(p->stem.bn), c.b16(p->dz0_off), s));
+        LCHECK(run_conv_wgrad(c, p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
+    }
+    return unpack_bucket(3);
+}
+
+extern "C" int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              void* stream) {
+    if (!params || !grads || !adam_m || !adam_v) return fail("null argument");
+    if (numel % 4) return fail("numel must be a multiple of 4 (use vpd_plan_param_numel)");
+    if (step < 1) return fail("step is 1-based");
+    LCHECK(vpd_launch_adamw(params, grads, adam_m, adam_v, (long)numel, lr, beta1, beta2, eps, weight_decay, step,
+                            (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_graph_capture_eval(vpd_plan_t* p, const float* params, const float* x, int n, float* emb_out,
+                                      void* workspace, void* stream) {
+    if (check_call(p, workspace, n)) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t i = 0; i < p->graphs.size(); ++i)
+        if (p->graphs[i].n == n) {
+            (void)hipGraphExecDestroy(p->graphs[i].e);
+            (void)hipGraphDestroy(p->graphs[i].g);
+            p->graphs.erase(p->graphs.begin() + i);
+            break;
+        }
+    HCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run_eval_forward(p, params, x, n, emb_out, nullptr, nullptr, nullptr, (char*)workspace, s);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+    if (e != hipSuccess) return fail("hipStreamEndCapture", e);
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return fail("hipGraphInstantiate", e); }
+    p->graphs.push_back({n, g, ge});
+    return 0;
+}
+
+extern "C" int vpd_graph_launch_eval(vpd_plan_t* p, int n, void* stream) {
+    for (auto& g : p->graphs)
+        if (g.n == n) {
+            HCHECK(hipGraphLaunch(g.e, (hipStream_t)stream));
+            return 0;
+        }
+    return fail("no captured eval graph for this batch size");
+}
+
+// ---------------------------------------------------------------------------
+// single-operator entry points for the parity tests
+// ---------------------------------------------------------------------------
+extern "C" int vpd_op_conv_bm(int M, int Co) { return vpd_conv_bm(M, Co); }
+
+static TapSet tapset_from(const int* t) {
+    TapSet ts;
+    ts.nr = t[0]; ts.nc = t[1]; ts.dy0 = t[2]; ts.dys = t[3]; ts.dx0 = t[4]; ts.dxs = t[5];
+    ts.w0 = t[6]; ts.wrs = t[7]; ts.wcs = t[8];
+    return ts;
+}
+
+extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, float* stats, int n, int xHp, int xWp, int xC,
+                             int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
+                             int Kc, int Co, const int* tapset9, int accumulate, void* stream) {
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.w = (const bf16_t*)w;
+    q.y = (bf16_t*)y; q.yHp = yHp; q.yWp = yWp; q.yC = yC; q.ypad = ypad; q.stats = stats;
+    q.N = n; q.Hs = Hs; q.Ws = Ws; q.osub = osub; q.oph = oph; q.opw = opw; q.istr = istr;
+    q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws; q.accumulate = accumulate;
+    q.taps = tapset_from(tapset9);
+    if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
+    LCHECK(vpd_launch_conv(q, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int dzHp, int dzWp, int dzC, int dzpad,
+                            int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
+                            void* stream) {
+    WgradParams q;
+    memset(&q, 0, sizeof q);
+    q.dz = (const bf16_t*)dz; q.dzHp = dzHp; q.dzWp = dzWp; q.dzC = dzC; q.dzpad = dzpad;
+    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.dw = dw;
+    q.N = n; q.Hs = Hs; q.Ws = Ws; q.istr = istr; q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws;
+    q.taps = tapset_from(tapset9);
+    if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
+    LCHECK(vpd_launch_wgrad(q, (hipStream_t)stream));
+    return 0;
+}

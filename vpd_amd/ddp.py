@@ -1,0 +1,69 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed SUM all-reduce
+of the flat gradient buffer with RCCL (torch.distributed backend "nccl"),
+issued on a side stream as soon as a bucket is final so it overlaps the rest
+of backward.  The reference is single-device; the semantics
+are defined so that world_size 1 is the reference: the loss is a SUM over
+crops (train_vpd_model.py:87), so gradients are SUMMED, not averaged.
+
+The pure functions at the top have no GPU dependency and are what the gloo /
+world_size-2 CPU tests exercise.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_sizes(n, world):
+    """Contiguous split of n crops over `world` ranks (ragged last batch: some ranks may get 0)."""
+    base, rem = divmod(n, world)
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def shard_slice(n, rank, world):
+    sizes = shard_sizes(n, world)
+    start = sum(sizes[:rank])
+    return slice(start, start + sizes[rank])
+
+
+def all_reduce_buckets(flat, ranges, group=None, async_op=False):
+    """SUM all-reduce of flat[off:off+numel] for every bucket, in the given order."""
+    works = []
+    for off, numel in ranges:
+        if numel == 0:
+            continue
+        w = dist.all_reduce(flat[off:off + numel], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+class GradBucketReducer:
+    """Overlaps the bucket all-reduces with backward: libvpdhip records one HIP
+    event per bucket on the compute stream; the comm stream waits on it and
+    launches that bucket's all-reduce; the compute stream re-joins before AdamW."""
+
+    def __init__(self, engine, group=None):
+        self.engine = engine
+        self.group = group
+        self.comm_stream = torch.cuda.Stream(device=engine.device)
+        self.events = [torch.cuda.Event() for _ in range(4)]
+        for e in self.events:           # materialise the hipEvent_t handles
+            e.record(torch.cuda.current_stream(engine.device))
+
+    def event_handles(self):
+        return [e.cuda_event for e in self.events]
+
+    def reduce(self, plan):
+        cur = torch.cuda.current_stream(self.engine.device)
+        works = []
+        with torch.cuda.stream(self.comm_stream):
+            for ev, (off, numel) in zip(self.events, plan.buckets):
+                self.comm_stream.wait_event(ev)
+                works += all_reduce_buckets(self.engine.grads, [(off, numel)], self.group, async_op=True)
+            for w in works:
+                w.wait()                 # comm stream waits for RCCL
+        cur.wait_stream(self.comm_stream)
+
+    def all_reduce_scalars(self, loss_sum, count):
+        t = torch.tensor([loss_sum, float(count)], dtype=torch.float64, device=self.engine.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t[0].item()), int(round(t[1].item()))

@@ -1,0 +1,245 @@
+"""StudentEngine: device buffers + one libvpdhip plan for a student network.
+
+PyTorch is used for device memory, streams and (in ddp.py) torch.distributed
+only; every arithmetic step of the hot path is a hand-written HIP kernel behind
+the C ABI (include/vpd_hip.h).  There is no fallback path.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from ._lib import check, lib
+
+# reference: models/module.py:17-21 (BasicBlock archs; Bottleneck archs are out of scope)
+ENCODER_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+_STAGE_WIDTH = (64, 128, 256, 512)
+
+
+def encoder_param_names(arch):
+    """Trainable tensors / BN buffers of the encoder in reference state_dict order."""
+    if arch not in ENCODER_LAYERS:
+        raise KeyError("unsupported encoder_arch %r (resnet18 | resnet34)" % (arch,))
+    train, bns = ["resnet.conv1.weight", "resnet.bn1.weight", "resnet.bn1.bias"], ["resnet.bn1"]
+    inpl = 64
+    for li, (nblk, planes) in enumerate(zip(ENCODER_LAYERS[arch], _STAGE_WIDTH), start=1):
+        for bi in range(nblk):
+            p = "resnet.layer%d.%d" % (li, bi)
+            stride = 2 if (bi == 0 and li > 1) else 1
+            train += [p + ".conv1.weight", p + ".bn1.weight", p + ".bn1.bias",
+                      p + ".conv2.weight", p + ".bn2.weight", p + ".bn2.bias"]
+            bns += [p + ".bn1", p + ".bn2"]
+            if stride != 1 or inpl != planes:
+                train += [p + ".downsample.0.weight", p + ".downsample.1.weight", p + ".downsample.1.bias"]
+                bns.append(p + ".downsample.1")
+            inpl = planes
+    train += ["resnet.fc.weight", "resnet.fc.bias"]
+    return train, bns
+
+
+DECODER_PARAM_NAMES = ["layers.0.weight", "layers.0.bias", "layers.2.weight", "layers.2.bias",
+                       "layers.5.weight", "layers.5.bias"]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _Plan:
+    """One vpd_plan_t + its workspace for a fixed (H, W, max_batch, train, motion)."""
+
+    def __init__(self, eng, h, w, max_batch, train, motion):
+        L = lib()
+        self.h, self.w, self.max_batch, self.train, self.motion = h, w, max_batch, train, motion
+        handle = C.c_void_p()
+        check(L.vpd_plan_create(eng.arch.encode(), eng.c_in, h, w, eng.emb_dim, int(motion), max_batch, int(train),
+                                C.byref(handle)), "vpd_plan_create")
+        self.handle = handle
+        # the C side is the source of truth for the flat layout: verify ours
+        n = L.vpd_plan_num_tensors(handle)
+        rows = []
+        kind, dec, off, numel, ndim = C.c_int(), C.c_int(), C.c_longlong(), C.c_longlong(), C.c_int()
+        dims = (C.c_int * 4)()
+        for i in range(n):
+            check(L.vpd_plan_tensor_info(handle, i, C.byref(kind), C.byref(dec), C.byref(off), C.byref(numel),
+                                         C.byref(ndim), dims), "vpd_plan_tensor_info")
+            rows.append((kind.value, dec.value, off.value, numel.value, tuple(dims[k] for k in range(ndim.value))))
+        self.rows = rows
+        self.param_numel = L.vpd_plan_param_numel(handle)
+        self.ws_bytes = L.vpd_plan_workspace_bytes(handle)
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=eng.device)
+        check(L.vpd_plan_init_workspace(handle, _ptr(self.workspace), eng._stream()), "vpd_plan_init_workspace")
+        self.buckets = []
+        o, m = C.c_longlong(), C.c_longlong()
+        for b in range(L.vpd_plan_num_buckets(handle)):
+            check(L.vpd_plan_bucket_range(handle, b, C.byref(o), C.byref(m)), "vpd_plan_bucket_range")
+            self.buckets.append((o.value, m.value))
+        self.packed_version = None
+        self.graph_sizes = set()
+
+    def bn_table(self):
+        L = lib()
+        out = []
+        ch, rm, rv = C.c_int(), C.c_longlong(), C.c_longlong()
+        for i in range(L.vpd_plan_num_bn(self.handle)):
+            check(L.vpd_plan_bn_info(self.handle, i, C.byref(ch), C.byref(rm), C.byref(rv)), "vpd_plan_bn_info")
+            out.append((ch.value, rm.value, rv.value))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().vpd_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StudentEngine:
+    """Flat fp32 parameter / gradient / optimizer-state buffers in the
+    reference's state_dict order and layout, plus lazily created plans."""
+
+    def __init__(self, arch, c_in, emb_dim, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("vpd_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False; "
+                               "there is no CPU fallback for the student path")
+        lib()   # fail loudly right here if the HIP library is missing
+        self.arch, self.c_in, self.emb_dim = arch, int(c_in), int(emb_dim)
+        self.device = torch.device(device)
+        self.enc_names, self.bn_names = encoder_param_names(arch)
+        # a throw-away 1-crop plan tells us the flat layout (shapes/offsets) without duplicating it here
+        probe = _Plan(self, 64, 64, 1, False, True)
+        assert len(probe.rows) == len(self.enc_names) + len(DECODER_PARAM_NAMES)
+        self.layout = OrderedDict()
+        for name, row in zip(self.enc_names + ["decoder." + k for k in DECODER_PARAM_NAMES], probe.rows):
+            self.layout[name] = row
+        self.param_numel = probe.param_numel
+        self.bn_layout = OrderedDict(zip(self.bn_names, probe.bn_table()))
+        self.bn_numel = sum(2 * c for c, _, _ in self.bn_layout.values())
+        probe.close()
+
+        z = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(self.param_numel, **z)
+        self.grads = torch.zeros(self.param_numel, **z)
+        self.bn_running = torch.zeros(max(self.bn_numel, 1), **z)
+        self.num_batches_tracked = torch.zeros(len(self.bn_names), dtype=torch.int64, device=self.device)
+        self.adam_m = None
+        self.adam_v = None
+        self.adam_step = 0
+        self.loss_step = torch.zeros(1, **z)
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._plans = {}
+        self._hip_version = 0          # bumped when a HIP kernel (AdamW) rewrites params behind torch's back
+        self._last = None              # (plan, n) of the last train forward, consumed by backward
+        self.bucket_events = None
+
+    # -- helpers -------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def view(self, name, buf=None):
+        kind, dec, off, numel, shape = self.layout[name]
+        return (self.params if buf is None else buf)[off:off + numel].view(shape)
+
+    def bn_views(self, name):
+        c, rm, rv = self.bn_layout[name]
+        return self.bn_running[rm:rm + c], self.bn_running[rv:rv + c]
+
+    def weights_version(self):
+        return (self.params._version, self.bn_running._version, self._hip_version)
+
+    def plan(self, h, w, n, train, motion):
+        key = (h, w, bool(train), bool(motion))
+        pl = self._plans.get(key)
+        if pl is None or pl.max_batch < n:
+            if pl is not None:
+                pl.close()
+            pl = _Plan(self, h, w, max(n, pl.max_batch if pl else 0), train, motion)
+            assert pl.param_numel == self.param_numel
+            self._plans[key] = pl
+        return pl
+
+    def _ensure_packed(self, pl):
+        v = self.weights_version()
+        if pl.packed_version != v:
+            check(lib().vpd_pack_weights(pl.handle, _ptr(self.params), _ptr(self.bn_running), _ptr(pl.workspace),
+                                         self._stream()), "vpd_pack_weights")
+            pl.packed_version = v
+
+    @staticmethod
+    def _check_input(x, c_in):
+        assert x.dim() == 4 and x.shape[1] == c_in, "expected f32 [N,%d,H,W], got %s" % (c_in, tuple(x.shape))
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
+
+    # -- forward / backward / step ---------------------------------------------
+    def forward_eval(self, x, target=None, motion=False, out=None, accumulate_loss=True):
+        self._check_input(x, self.c_in)
+        n, _, h, w = x.shape
+        pl = self.plan(h, w, n, False, motion)
+        self._ensure_packed(pl)
+        emb = out if out is not None else torch.empty((n, self.emb_dim), dtype=torch.float32, device=self.device)
+        check(lib().vpd_forward_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(emb), _ptr(target),
+                                     _ptr(self.loss_step) if target is not None else None,
+                                     _ptr(self.loss_accum) if (target is not None and accumulate_loss) else None,
+                                     _ptr(pl.workspace), self._stream()), "vpd_forward_eval")
+        return emb
+
+    def forward_train(self, x, target=None, motion=False, accumulate_loss=True):
+        self._check_input(x, self.c_in)
+        n, _, h, w = x.shape
+        pl = self.plan(h, w, n, True, motion)
+        self._ensure_packed(pl)
+        emb = torch.empty((n, self.emb_dim), dtype=torch.float32, device=self.device)
+        if target is not None:
+            want = (n, self.emb_dim * (2 if motion else 1))
+            assert tuple(target.shape) == want and target.dtype == torch.float32 and target.is_contiguous(), \
+                "target must be f32 %s" % (want,)
+        check(lib().vpd_forward_train(pl.handle, _ptr(self.params), _ptr(self.bn_running), _ptr(x), _ptr(target), n,
+                                      _ptr(emb), _ptr(self.loss_step),
+                                      _ptr(self.loss_accum) if accumulate_loss else None,
+                                      _ptr(pl.workspace), self._stream()), "vpd_forward_train")
+        # BN running stats were rewritten by HIP kernels: packed eval scale/shift are stale
+        self._hip_version += 1
+        pl.packed_version = (self.params._version, self.bn_running._version, self._hip_version)
+        self.num_batches_tracked += 1
+        self._last = (pl, n) if target is not None else None
+        return emb
+
+    def backward(self, events=None):
+        if self._last is None:
+            raise RuntimeError("backward() without a preceding train-mode forward with a target")
+        pl, n = self._last
+        self._last = None
+        ev = None
+        if events is not None:
+            ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
+        check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self.grads), n, ev, _ptr(pl.workspace),
+                                 self._stream()), "vpd_backward")
+        return pl
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        self.adam_step += 1
+        check(lib().vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                   self.param_numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
+                                   self._stream()), "vpd_adamw_step")
+        self._hip_version += 1
+
+    def capture_eval_graph(self, x, out):
+        self._check_input(x, self.c_in)
+        n, _, h, w = x.shape
+        pl = self.plan(h, w, n, False, False)
+        self._ensure_packed(pl)
+        check(lib().vpd_graph_capture_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(out), _ptr(pl.workspace),
+                                           self._stream()), "vpd_graph_capture_eval")
+        pl.graph_sizes.add(n)
+        return pl
+
+    def launch_eval_graph(self, pl, n):
+        self._ensure_packed(pl)
+        check(lib().vpd_graph_launch_eval(pl.handle, n, self._stream()), "vpd_graph_launch_eval")

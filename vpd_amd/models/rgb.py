@@ -1,0 +1,110 @@
+"""RGBF_EmbeddingModel: the reference's student wrapper (models/rgb.py:46-86)
+over the HIP engine.  Same constructor arguments, attributes, state_dict keys,
+embed() contract and assertion behaviour; the arithmetic is libvpdhip."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..engine import StudentEngine
+from .module import ENCODER_ARCH, attach_views
+
+
+class RGBF_EmbeddingModel(nn.Module):
+    """Basic embedding model with single frame features (HIP / MI355X)."""
+
+    def __init__(self, model_arch, emb_dim, use_flow, device, pretrained=False):
+        super().__init__()
+        if "effnet" in model_arch:
+            raise NotImplementedError("EfficientNet students are out of scope (SURVEY.md 2.1 #3)")
+        if model_arch not in ENCODER_ARCH:
+            raise KeyError(model_arch)
+        if pretrained:
+            raise NotImplementedError("ImageNet weights need network access; load a state_dict instead")
+        self.device = device
+        self.use_flow = use_flow
+        self.emb_dim = emb_dim
+        self.model_arch = model_arch
+        c_in = 5 if use_flow else 3
+        eng = StudentEngine(model_arch, c_in, emb_dim, device="cuda" if str(device) == "cuda" else device)
+        self._engine_ref = [eng]
+        attach_views(self, eng.enc_names, eng.view)
+        for k in eng.enc_names:
+            self.get_parameter(k).grad = eng.view(k, eng.grads)
+        # BN buffers in reference order: running_mean, running_var, num_batches_tracked right after weight/bias
+        for i, bn in enumerate(eng.bn_names):
+            rm, rv = eng.bn_views(bn)
+            mod = self.get_submodule(bn)
+            mod.register_buffer("running_mean", rm)
+            mod.register_buffer("running_var", rv)
+            mod.register_buffer("num_batches_tracked", eng.num_batches_tracked[i])
+        self.reset_parameters()
+
+    @property
+    def engine(self):
+        return self._engine_ref[0]
+
+    def reset_parameters(self, seed=None):
+        """Reference init: kaiming-normal fan_out convs, BN gamma=1/beta=0 (models/module.py:71-76);
+        5-ch stem = channel mean of a 3-ch kernel (models/rgb.py:19-23); nn.Linear default fc."""
+        eng = self.engine
+        g = None
+        if seed is not None:
+            g = torch.Generator(device=eng.device).manual_seed(seed)
+        with torch.no_grad():
+            for name in eng.enc_names:
+                p = self.get_parameter(name)
+                kind = eng.layout[name][0]
+                if kind == 0:
+                    co, ci, kh, kw = p.shape
+                    std = math.sqrt(2.0 / (co * kh * kw))
+                    if name == "resnet.conv1.weight" and self.use_flow:
+                        w3 = torch.randn((co, 3, kh, kw), device=eng.device, generator=g) * std
+                        p.copy_(w3.mean(dim=1, keepdim=True).expand_as(p))
+                    else:
+                        p.copy_(torch.randn(p.shape, device=eng.device, generator=g) * std)
+                elif kind == 1:
+                    p.fill_(1.0)
+                elif kind == 2:
+                    p.zero_()
+                else:
+                    bound = 1.0 / math.sqrt(512)
+                    p.copy_((torch.rand(p.shape, device=eng.device, generator=g) * 2 - 1) * bound)
+            for bn in eng.bn_names:
+                rm, rv = eng.bn_views(bn)
+                rm.zero_()
+                rv.fill_(1.0)
+            eng.num_batches_tracked.zero_()
+
+    def _check_storage(self):
+        p = self.get_parameter("resnet.conv1.weight")
+        if p.data_ptr() != self.engine.params.data_ptr():
+            raise RuntimeError("model parameters were moved off the engine's flat buffer (.cpu()/.to(other)); "
+                               "the HIP student must stay on its GPU")
+
+    def forward(self, x):
+        """f32 [N,C,H,W] on the GPU -> f32 [N,emb_dim].  Train mode uses batch statistics and
+        updates the running ones (nn.BatchNorm2d semantics); gradients flow only through
+        ModelTrainer.epoch's fused step, not through torch autograd."""
+        self._check_storage()
+        x = x.to(self.engine.device, dtype=torch.float32).contiguous()
+        if self.training:
+            return self.engine.forward_train(x, None, motion=False)
+        return self.engine.forward_eval(x)
+
+    def embed(self, x):
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
+        x = x.to(self.engine.device)
+        if len(x.shape) == 3:
+            x = x.unsqueeze(0)
+
+        if self.use_flow:
+            assert x.shape[1] == 5, 'Wrong number of channels for RGB + flow'
+        else:
+            assert x.shape[1] == 3, 'Wrong number of channels for RGB'
+
+        self.eval()
+        with torch.no_grad():
+            return self(x).cpu().numpy()

@@ -1,0 +1,112 @@
+"""ModelTrainer: the reference's training driver (train_vpd_model.py:53-112)
+on the HIP engine.  Same methods, same epoch() return value (sum of per-batch
+sum-MSE / number of crops), same checkpoint files."""
+import os
+
+import torch
+
+from .ddp import GradBucketReducer
+from .models.module import FCNet
+from .models.util import step
+
+
+class _Loss:
+    """What `F.mse_loss(...)` returns in the reference loop, for the fused path:
+    supports .backward() (models/util.py:52) and .item() (train_vpd_model.py:93)."""
+
+    def __init__(self, trainer):
+        self._t = trainer
+
+    def backward(self):
+        self._t._backward()
+
+    def item(self):
+        return float(self._t.encoder.engine.loss_step.item())   # host sync, as in the reference
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(params, lr) with torch defaults (train_vpd_model.py:104) as ONE
+    HIP kernel over the engine's flat fp32 buffers (weight decay on every tensor)."""
+
+    def __init__(self, params, engine, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._engine = engine
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        self._engine.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"])
+
+    def zero_grad(self, set_to_none=False):
+        # gradients live in the engine's flat buffer and are overwritten (not accumulated)
+        # by the next backward, which is what zero_grad-after-every-step amounts to
+        return None
+
+
+class ModelTrainer:
+    """Class for training the encoder. Discarded after training"""
+
+    def __init__(self, encoder, motion, process_group=None):
+        device = encoder.device
+        self.encoder = encoder.to(device)
+        self.motion = bool(motion)
+        if motion:
+            self.fcn_time = FCNet(encoder.engine, encoder.emb_dim, [128, 128], 2 * encoder.emb_dim, dropout=0)
+        self._reducer = None
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                         and torch.distributed.get_world_size() > 1):
+            self._reducer = GradBucketReducer(encoder.engine, process_group)
+
+    # -- pieces of the reference loop body (train_vpd_model.py:79-91) -------------------
+    def _forward_loss(self, img, gt_emb, train):
+        eng = self.encoder.engine
+        img = img.to(eng.device, dtype=torch.float32, non_blocking=True).contiguous()
+        gt = gt_emb.to(eng.device, dtype=torch.float32, non_blocking=True).contiguous()
+        if train:
+            eng.forward_train(img, gt, motion=self.motion)
+        else:
+            eng.forward_eval(img, gt, motion=self.motion)
+        return _Loss(self)
+
+    def _backward(self):
+        eng = self.encoder.engine
+        if self._reducer is not None:
+            pl = eng.backward(self._reducer.event_handles())
+            self._reducer.reduce(pl)
+        else:
+            eng.backward()
+
+    def epoch(self, data_loader, optimizer=None, scaler=None, progress_cb=None):
+        eng = self.encoder.engine
+        self.encoder.eval() if optimizer is None else self.encoder.train()
+        if hasattr(self, 'fcn_time'):
+            self.fcn_time.eval() if optimizer is None else self.fcn_time.train()
+
+        eng.loss_accum.zero_()          # the epoch accumulator of train_vpd_model.py:73,93 lives on device
+        epoch_emb_n = 0
+        for batch in data_loader:
+            n = batch['img'].shape[0]
+            loss = self._forward_loss(batch['img'], batch['emb'], train=optimizer is not None)
+            if optimizer is not None:
+                step(optimizer, scaler, loss)
+            epoch_emb_n += n
+            if progress_cb is not None:
+                progress_cb(n)
+        epoch_emb_loss = float(eng.loss_accum.item())   # ONE host sync per epoch
+        if self._reducer is not None:
+            epoch_emb_loss, epoch_emb_n = self._reducer.all_reduce_scalars(epoch_emb_loss, epoch_emb_n)
+        return epoch_emb_loss / epoch_emb_n
+
+    def get_optimizer(self, learning_rate):
+        params = list(self.encoder.parameters())
+        if hasattr(self, 'fcn_time'):
+            params.extend(self.fcn_time.parameters())
+        # scaler is None: bf16 operands with fp32 accumulation need no GradScaler
+        return FusedAdamW(params, self.encoder.engine, lr=learning_rate), None
+
+    def save_model(self, save_dir, name):
+        torch.save(self.encoder.state_dict(),
+                   os.path.join(save_dir, '{}.encoder.pt'.format(name)))
+        if hasattr(self, 'fcn_time'):
+            torch.save(self.fcn_time.state_dict(),
+                       os.path.join(save_dir, '{}.decoder.pt'.format(name)))
