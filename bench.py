@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""VPD student train-step benchmark on MI355X (BASELINE.json metric: frame-crops/sec).
+
+One "step" = one pass of the hot path over one resident synthetic batch:
+  pack weights -> forward (train-mode BN) -> sum-MSE -> backward -> [RCCL SUM all-reduce] -> AdamW.
+Workload (BASELINE.json configs[1]): ResNet-34 student, 5-channel 128x128 crops (RGB+flow),
+emb_dim 128, batch 256 per GPU, bf16 operands / fp32 accumulation, weak scaling over GPUs.
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+ARCH, C_IN, EMB_DIM, HW, BATCH_PER_GPU = "resnet34", 5, 128, 128, 256
+# algorithmic work per crop: fwd + dgrad (no stem dgrad) + wgrad
+TRAIN_FLOP_PER_CROP = {("resnet34", 5): 7203061760, ("resnet34", 3): 7100301312, ("resnet18", 5): 3579183104}
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md
+DIVING48_MEAN_STD = ((0.3411329922282787, 0.46349889258964044, 0.5162481674015696),
+                     (0.16302619019820488, 0.17092395707914718, 0.19266662199338647))
+
+
+def synthetic_batch(n, device, seed):
+    """Diving48-shaped crops in the reference's value ranges (vpd_dataset/common.py:52-69):
+    RGB ~ U{0..255}/255 normalised with the diving48 mean/std; flow = clip(round(124+12 N(0,1)))/255 - 0.5."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rgb = torch.randint(0, 256, (n, 3, HW, HW), generator=g, device=device).float() / 255.0
+    mean = torch.tensor(DIVING48_MEAN_STD[0], device=device).view(1, 3, 1, 1)
+    std = torch.tensor(DIVING48_MEAN_STD[1], device=device).view(1, 3, 1, 1)
+    flow = (124 + 12 * torch.randn((n, 2, HW, HW), generator=g, device=device)).round().clamp(0, 255) / 255.0 - 0.5
+    img = torch.cat([(rgb - mean) / std, flow], dim=1).contiguous()
+    emb = torch.randn((n, EMB_DIM), generator=g, device=device)
+    return img, emb
+
+
+def cpu_baseline(sample_batch=16, steps=3):
+    """The CPU oracle (fp32 torch-CPU restatement of the reference loop, kind "port") on the
+    host cores: same network/loss/optimizer on a bounded sample of the same workload."""
+    from oracle import vpd_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    enc = O.reference_init_state_dict(ARCH, C_IN, EMB_DIM, 0)
+    orc = O.StudentOracle(ARCH, C_IN, EMB_DIM, False, enc)
+    orc.get_optimizer(5e-4)
+    img = O.synthetic_crops(sample_batch, C_IN, HW, 1)
+    tgt = O.synthetic_targets(sample_batch, EMB_DIM, False, 2)
+    orc.train_step(img, tgt)                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.train_step(img, tgt)
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch * steps / dt, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d train steps of %d crops (ResNet-34, 5x128x128, fp32, torch-CPU oracle)" % (steps, sample_batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="crops per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+
+    torch.manual_seed(0)
+    enc = RGBF_EmbeddingModel(ARCH, EMB_DIM, True, device)
+    enc.reset_parameters(seed=0)                 # reference init semantics, same weights on every rank
+    trainer = ModelTrainer(enc, motion=False)
+    optimizer, scaler = trainer.get_optimizer(5e-4)
+    img, emb = synthetic_batch(args.batch, device, seed=1 + rank)
+    eng = enc.engine
+    enc.train()
+
+    def one_step():
+        loss = trainer._forward_loss(img, emb, train=True)
+        loss.backward()          # includes the bucketed RCCL all-reduce when world > 1
+        optimizer.step()
+        optimizer.zero_grad()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_now = float(eng.loss_step.item())
+
+    out = None
+    if rank == 0:
+        crops = args.batch * world * args.steps
+        value = crops / dt
+        flop = TRAIN_FLOP_PER_CROP[(ARCH, C_IN)]
+        # ---- roofline of the dominant kernel class: HIP events around each conv launch, on its stream ----
+        pl = eng.plan(HW, HW, args.batch, True, False)
+        eng.set_timing(pl, True)
+        for _ in range(args.profile_steps):
+            one_step()
+        torch.cuda.synchronize(device)
+        cls = eng.read_timing(pl)
+        eng.set_timing(pl, False)
+        kernels = {}
+        for k, v in cls.items():
+            if v["launches"] > 0:
+                kernels[k] = {"launches_per_step": v["launches"] / args.profile_steps,
+                              "ms_per_step": v["ms"] / args.profile_steps,
+                              "avg_launch_us": 1e3 * v["ms"] / v["launches"],
+                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"],
+                    "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": kernels[dom]["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                    "whole_step_frac": value / world * flop / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12),
+                    "kernels": kernels,
+                    "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region; "
+                            "a stride-2 dgrad's parity-class launches are one timed unit" % args.profile_steps}
+        out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "configs[1]: Diving48-shaped synthetic crops 128x128, ResNet-34 student (5-ch RGB+flow), "
+                                      "emb_dim 128, sum-MSE + AdamW, batch=%d per GPU" % args.batch,
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "flop_per_crop": flop, "loss_last_step": loss_now},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

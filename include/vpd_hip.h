@@ -97,7 +97,7 @@ int vpd_backward(vpd_plan_t* plan, const float* params, float* grads, int n, voi
 /* optimizer.step() of models/util.py:53 for torch.optim.AdamW(lr) with torch defaults
  * (train_vpd_model.py:104): decoupled weight decay on every tensor. `step` is 1-based. */
 int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
-                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
 /* hipGraph-captured eval forward for a fixed batch size (apply_vpd_model.py:152-168 inner
  * loop at BATCH_SIZE crops per call).  Capture binds the pointers given here. */
@@ -105,11 +105,19 @@ int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x
                            void* workspace, void* stream);
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 
+/* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
+ * bracketed by HIP events on its own stream.  Classes: 0 conv_igemm<128,64>, 1 conv_igemm<128,128>,
+ * 2 conv_igemm<64,64> (forward + data-gradient convs), 3 conv_wgrad.  vpd_plan_read_timing waits for
+ * the events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
+int vpd_plan_set_timing(vpd_plan_t* plan, int enable);
+int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
+
 /* ---- single-operator entry points (used by the parity tests; same kernels) ---- */
 /* One implicit-GEMM conv launch on padded-NHWC bf16 tensors (forward conv or data-gradient conv).
  * tapset9 = {nr, nc, dy0, dys, dx0, dxs, w0, wrs, wcs}: tap (ir,ic) gathers input pixel
  * (y*istr + dy0 + ir*dys, x*istr + dx0 + ic*dxs) in padded coordinates and uses weight slice
- * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional): [ceil(M/vpd_op_conv_bm)][2][Co]. */
+ * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional, pre-zeroed): [64][2][Co] accumulator
+ * rows (block b adds its per-channel sum / sum of squares into row b % 64). */
 int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, float* stats, int n, int xHp, int xWp,
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);

@@ -73,7 +73,7 @@ def run_conv(xp, wp, n, xHp, xWp, xC, yH, yW, ypad, Hs, Ws, osub, oph, opw, istr
     stats = None
     if want_stats:
         bm = L.vpd_op_conv_bm(n * Hs * Ws, Co)
-        T = (n * Hs * Ws + bm - 1) // bm
+        T = min((n * Hs * Ws + bm - 1) // bm, 64)      # VPD_STAT_ROWS accumulator rows
         stats = torch.zeros(T, 2, Co, dtype=torch.float32, device="cuda")
     _check(L.vpd_op_conv2d(ptr(xp), ptr(wp), ptr(y), ptr(stats) if stats is not None else None, n, xHp, xWp, xC,
                            yHp, yWp, yC, ypad, Hs, Ws, osub, oph, opw, istr, Kc, Co, taps, accumulate, stream()))

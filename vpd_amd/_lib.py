@@ -35,10 +35,12 @@ SIGNATURES = {
     "vpd_forward_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "vpd_forward_train": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp]),
     "vpd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(vp), vp, vp]),
-    "vpd_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float,
-                                 C.c_float, C.c_int, vp]),
+    "vpd_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_double, C.c_int, vp]),
     "vpd_graph_capture_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "vpd_graph_launch_eval": (C.c_int, [vp, C.c_int, vp]),
+    "vpd_plan_set_timing": (C.c_int, [vp, C.c_int]),
+    "vpd_plan_read_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
     "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),
     "vpd_op_conv_bm": (C.c_int, [C.c_int, C.c_int]),
     "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp]),

@@ -10,7 +10,7 @@
 // shift; running-stat update (momentum, unbiased var) as nn.BatchNorm2d.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partials, int T, int C, float count,
+    float* partials, int T, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, float momentum, float eps,
     float* mean, float* rstd, float* scale, float* shift) {
@@ -20,8 +20,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
         for (int t = g; t < T; t += 4) {
-            s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
-            s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+            float* q = partials + ((size_t)t * 2) * C + c;
+            s1 += (double)q[0];
+            s2 += (double)q[C];
+            q[0] = 0.f; q[C] = 0.f;          // leave the accumulator rows zeroed for the next producer
         }
     sh[0][g][cl] = s1; sh[1][g][cl] = s2;
     __syncthreads();
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     }
 }
 
-hipError_t vpd_launch_bn_finalize(const float* partials, int T, int C, float count, const float* gamma,
+hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, partials, T, C, count, gamma,
@@ -244,13 +246,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
         const int q8 = ch >> 3, j = ch & 7;
         float tot = 0.f;
         for (int g = 0; g < ppi; ++g) tot += sh[g * cv + q8][which * 8 + j];
-        p.partials[((size_t)blockIdx.x * 2 + which) * p.C + ch] = tot;
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
     }
 }
 
 // pass 1b: partials -> dgamma, dbeta (fp32 grads) and the apply coefficients
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
-    const float* __restrict__ partials, int T, int C, float count, const float* __restrict__ gamma,
+    float* partials, int T, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ rstd, float* dgamma, float* dbeta, float* coef) {
     __shared__ double sh[2][4][64];
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -258,8 +260,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
         for (int t = g; t < T; t += 4) {
-            s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
-            s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+            float* q = partials + ((size_t)t * 2) * C + c;
+            s1 += (double)q[0];
+            s2 += (double)q[C];
+            q[0] = 0.f; q[C] = 0.f;
         }
     sh[0][g][cl] = s1; sh[1][g][cl] = s2;
     __syncthreads();
@@ -325,7 +329,8 @@ hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* ga
     if (p.C % 8 || p.C > 2048 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, T, p.C, count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
+                       T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, p.coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
     return hipGetLastError();
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
         const int q8 = ch >> 3, j = ch & 7;
         float tot = 0.f;
         for (int gI = 0; gI < ppi; ++gI) tot += sh[gI * cv + q8][which * 8 + j];
-        p.partials[((size_t)blockIdx.x * 2 + which) * p.C + ch] = tot;
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
     }
 }
 
@@ -415,7 +420,8 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
     if (p.C % 8 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials, T, p.C, count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
+                       T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, coef);
     BnBwdParams q = {};
     q.dy = p.g; q.dy_rw = nullptr; q.z = p.z; q.act = nullptr; q.mean = p.mean; q.rstd = p.rstd; q.coef = coef;

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
-            p.stats[((size_t)mtile * 2 + which) * p.Co + n0 + c] = t;
+            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
+            atomicAdd(&p.stats[((size_t)(mtile & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
         }
     }
 }

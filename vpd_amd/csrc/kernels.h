@@ -54,7 +54,7 @@ hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
 
-hipError_t vpd_launch_bn_finalize(const float* partials, int T, int C, float count, const float* gamma,
+hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
 hipError_t vpd_launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -87,5 +87,5 @@ hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int
                                    const float* master, bf16_t* arena, hipStream_t s);
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* wg, float* grads, hipStream_t s);
-hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                            float eps, float wd, int step, hipStream_t s);
+hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                            double eps, double wd, int step, hipStream_t s);

@@ -103,30 +103,30 @@ hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int
 // Fused AdamW over the whole flat parameter buffer (every tensor shares the
 // hyper-parameters: train_vpd_model.py:104 uses one param group, wd on all).
 __global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, float4* m, float4* v, long n4,
-                                                    float decay, float b1, float b2, float step_size, float inv_sqrt_bc2,
-                                                    float eps) {
+                                                    float decay, float omb1, float b2, float omb2, float step_size,
+                                                    float inv_sqrt_bc2, float eps) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
 #define ADAMW1(f)                                                         \
         pp.f *= decay;                                                    \
-        mm.f += (gg.f - mm.f) * (1.f - b1);                               \
-        vv.f = vv.f * b2 + (1.f - b2) * gg.f * gg.f;                      \
+        mm.f += (gg.f - mm.f) * omb1;                                     \
+        vv.f = vv.f * b2 + omb2 * gg.f * gg.f;                            \
         pp.f -= step_size * (mm.f / (sqrtf(vv.f) * inv_sqrt_bc2 + eps));
         ADAMW1(x) ADAMW1(y) ADAMW1(z) ADAMW1(w)
 #undef ADAMW1
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
-hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                            float eps, float wd, int step, hipStream_t s) {
+hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                            double eps, double wd, int step, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
-    const double bc1 = 1.0 - pow((double)b1, step);
-    const double bc2 = 1.0 - pow((double)b2, step);
+    const double bc1 = 1.0 - pow(b1, step);
+    const double bc2 = 1.0 - pow(b2, step);
     const long n4 = n / 4;
     long gsz = (n4 + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3(gsz < 1 ? 1 : (int)gsz), dim3(256), 0, s, (float4*)p, (const float4*)g,
-                       (float4*)m, (float4*)v, n4, (float)(1.0 - (double)lr * wd), b1, b2, (float)((double)lr / bc1),
-                       (float)(1.0 / sqrt(bc2)), eps);
+                       (float4*)m, (float4*)v, n4, (float)(1.0 - lr * wd), (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
     return hipGetLastError();
 }

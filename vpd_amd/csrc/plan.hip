@@ -106,6 +106,11 @@ struct vpd_plan {
     struct Graph { int n; hipGraph_t g; hipGraphExec_t e; };
     std::vector<Graph> graphs;
     void* bound_ws = nullptr;
+    // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
+    bool timing = false;
+    struct TimedLaunch { int cls; double flops; hipEvent_t a, b; };
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace {
@@ -286,8 +291,9 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         };
         upd(p->stem);
         for (auto& B : p->blocks) { upd(B.c1); upd(B.c2); if (B.ds) upd(B.cd); }
-        p->partial_bytes = mx;
-        p->partial_off = bp.take(mx);
+        (void)mx;   // producers accumulate atomically into VPD_STAT_ROWS rows of [2][C]
+        p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * 512 * 4;
+        p->partial_off = bp.take(p->partial_bytes);
     }
     p->z0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
     p->p0_off = bp.take(padded_elems(NB, p->H1, p->W1, 64, 1) * 2);
@@ -340,6 +346,8 @@ extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
         (void)hipGraphExecDestroy(g.e);
         (void)hipGraphDestroy(g.g);
     }
+    for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -403,6 +411,32 @@ struct Ctx {
     float* bn_eshift(const BnInfo& b) const { return f32(b.fl_off) + 8 * b.C; }
 };
 
+// timing classes: 0 igemm<128,64> 1 igemm<128,128> 2 igemm<64,64> 3 wgrad
+struct TimeScope {
+    vpd_plan* p; hipStream_t s; int idx = -1;
+    TimeScope(vpd_plan* p_, hipStream_t s_, int cls, double flops) : p(p_), s(s_) {
+        if (!p->timing) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!p->ev_pool.empty()) { e = p->ev_pool.back(); p->ev_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        vpd_plan::TimedLaunch t{cls, flops, get(), get()};
+        (void)hipEventRecord(t.a, s);
+        p->timed.push_back(t);
+        idx = (int)p->timed.size() - 1;
+    }
+    ~TimeScope() { if (idx >= 0) (void)hipEventRecord(p->timed[idx].b, s); }
+};
+inline int igemm_class(int M, int Co) {
+    if (Co % 128 != 0) return 0;
+    return vpd_conv_bm(M, Co) == 128 ? 1 : 2;
+}
+inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real taps and channels
+    return 2.0 * n * cv.Hout * cv.Wout * cv.Co * (double)cv.Ci * cv.k * cv.k;
+}
+
 // forward convolution launch; input padded activation `x` (border 1; stem: xin), output `y`
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
                         const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu) {
@@ -419,13 +453,15 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
+    TimeScope ts(c.p, c.s, igemm_class(q.M, q.Co), conv_flops(cv, c.n));
     return vpd_launch_conv(q, c.s);
 }
 
 hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) {
     const int M = c.n * cv.Hout * cv.Wout;
     const int bm = vpd_conv_bm(M, cv.Co);
-    const int T = (M + bm - 1) / bm;
+    int T = (M + bm - 1) / bm;
+    T = T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS;
     return vpd_launch_bn_finalize(c.f32(c.p->partial_off), T, cv.Co, (float)M, c.params + cv.bn.w_off,
                                   c.params + cv.bn.b_off, bn_running ? bn_running + cv.bn.rm_off : nullptr,
                                   bn_running ? bn_running + cv.bn.rv_off : nullptr, kBnMomentum, kBnEps,
@@ -441,6 +477,9 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
     q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
     hipError_t e = hipSuccess;
+    // one timing scope for all parity-class launches of this dgrad (classified by the first launch's shape)
+    TimeScope ts(c.p, c.s, igemm_class(c.n * (cv.stride == 1 ? cv.Hin * cv.Win : ((cv.Hin + 1) / 2) * ((cv.Win + 1) / 2)), cv.Ci),
+                 conv_flops(cv, c.n));
     if (cv.stride == 1) {
         // dx[y][x] = sum_{r,t} dz[y + pad - r][x + pad - t] W[r][t]; padded coord adds 1
         q.Hs = cv.Hin; q.Ws = cv.Win; q.osub = 1; q.oph = 0; q.opw = 0;
@@ -482,6 +521,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
+    TimeScope ts(c.p, c.s, 3, conv_flops(cv, c.n));
     return vpd_launch_wgrad(q, c.s);
 }
 
@@ -617,6 +657,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
+    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes, s));
     LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     // stem: conv -> batch stats -> BN+ReLU+maxpool
     LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0));
@@ -659,6 +700,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
     LCHECK(hipMemsetAsync(ws + p->wg_off, 0, (size_t)p->wg_elems * 4, s));
+    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes, s));
 
     // ---- head ----
     const float* demb = c.f32(p->dpred_off);
@@ -744,13 +786,34 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
 }
 
 extern "C" int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
-                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                               void* stream) {
     if (!params || !grads || !adam_m || !adam_v) return fail("null argument");
     if (numel % 4) return fail("numel must be a multiple of 4 (use vpd_plan_param_numel)");
     if (step < 1) return fail("step is 1-based");
     LCHECK(vpd_launch_adamw(params, grads, adam_m, adam_v, (long)numel, lr, beta1, beta2, eps, weight_decay, step,
                             (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_plan_set_timing(vpd_plan_t* p, int enable) {
+    if (!p) return fail("null plan");
+    p->timing = enable != 0;
+    return 0;
+}
+
+// Sums (and clears) the recorded launches: out[4*cls + {0,1,2}] = {launches, milliseconds, flops}
+extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
+    if (!p || !out || nclasses < 4) return fail("bad argument");
+    for (int i = 0; i < 3 * nclasses; ++i) out[i] = 0.0;
+    for (auto& t : p->timed) {
+        HCHECK(hipEventSynchronize(t.b));
+        float ms = 0.f;
+        HCHECK(hipEventElapsedTime(&ms, t.a, t.b));
+        out[3 * t.cls + 0] += 1.0; out[3 * t.cls + 1] += ms; out[3 * t.cls + 2] += t.flops;
+        p->ev_pool.push_back(t.a); p->ev_pool.push_back(t.b);
+    }
+    p->timed.clear();
     return 0;
 }
 

@@ -158,15 +158,16 @@ class StudentEngine:
             if pl is not None:
                 pl.close()
             pl = _Plan(self, h, w, max(n, pl.max_batch if pl else 0), train, motion)
-            assert pl.param_numel == self.param_numel
+            assert pl.param_numel <= self.param_numel      # plans without the motion head omit its tensors
             self._plans[key] = pl
         return pl
 
     def _ensure_packed(self, pl):
         v = self.weights_version()
         if pl.packed_version != v:
-            check(lib().vpd_pack_weights(pl.handle, _ptr(self.params), _ptr(self.bn_running), _ptr(pl.workspace),
-                                         self._stream()), "vpd_pack_weights")
+            # the eval-mode BN fold is only needed by eval plans
+            check(lib().vpd_pack_weights(pl.handle, _ptr(self.params), None if pl.train else _ptr(self.bn_running),
+                                         _ptr(pl.workspace), self._stream()), "vpd_pack_weights")
             pl.packed_version = v
 
     @staticmethod
@@ -231,14 +232,28 @@ class StudentEngine:
         self._hip_version += 1
 
     def capture_eval_graph(self, x, out):
+        """hipGraph of the eval forward for this batch size, bound to x / out (capture needs a
+        non-default stream; the graph itself is launched on the current stream)."""
         self._check_input(x, self.c_in)
         n, _, h, w = x.shape
         pl = self.plan(h, w, n, False, False)
         self._ensure_packed(pl)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
         check(lib().vpd_graph_capture_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(out), _ptr(pl.workspace),
-                                           self._stream()), "vpd_graph_capture_eval")
+                                           C.c_void_p(side.cuda_stream)), "vpd_graph_capture_eval")
+        torch.cuda.current_stream(self.device).wait_stream(side)
         pl.graph_sizes.add(n)
         return pl
+
+    def set_timing(self, pl, enable):
+        check(lib().vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
+
+    def read_timing(self, pl):
+        out = (C.c_double * 12)()
+        check(lib().vpd_plan_read_timing(pl.handle, out, 4), "vpd_plan_read_timing")
+        names = ["conv_igemm<128,64>", "conv_igemm<128,128>", "conv_igemm<64,64>", "conv_wgrad"]
+        return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(4)}
 
     def launch_eval_graph(self, pl, n):
         self._ensure_packed(pl)
