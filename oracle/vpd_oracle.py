@@ -173,27 +173,56 @@ def _bn(sd, prefix, x, train, taps=None):
                         False, BN_MOMENTUM, BN_EPS)
 
 
+class _RoundBf16(torch.autograd.Function):
+    """Value AND gradient rounded to bf16 (round-to-nearest-even): models a tensor that the
+    HIP path stores in bf16 in both directions (activation forward, its gradient backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _rb(x, on):
+    return _RoundBf16.apply(x) if on else x
+
+
+def _wq(w, on):
+    """bf16 weight shadow: rounded value, straight-through gradient (fp32 master gets the fp32 wgrad)."""
+    return w + (w.detach().bfloat16().float() - w.detach()) if on else w
+
+
 def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, arch: str,
-                    train: bool, taps: Optional[dict] = None) -> torch.Tensor:
+                    train: bool, taps: Optional[dict] = None, emulate_bf16: bool = False) -> torch.Tensor:
     """f32[N,C,H,W] -> f32[N,D].  models/module.py:112-127 order; train-mode BN
-    mutates running stats in ``sd`` exactly like nn.BatchNorm2d."""
-    h = F.conv2d(x, sd["resnet.conv1.weight"], None, stride=2, padding=3)
-    h = F.relu(_bn(sd, "resnet.bn1", h, train, taps))
+    mutates running stats in ``sd`` exactly like nn.BatchNorm2d.
+
+    emulate_bf16=True restates the PRECISION of the HIP path on top of the same
+    algorithm (bf16 conv operands and stored activations / activation gradients,
+    fp32 accumulation, statistics, BN arithmetic, head and loss), so that tests
+    can separate rounding noise from kernel errors."""
+    q = emulate_bf16
+    x = _rb(x, q)
+    h = _rb(F.conv2d(x, _wq(sd["resnet.conv1.weight"], q), None, stride=2, padding=3), q)
+    h = _rb(F.relu(_bn(sd, "resnet.bn1", h, train, taps)), q)
     h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
     for li, nblk in enumerate(ARCH_LAYERS[arch], start=1):
         for bi in range(nblk):
             p = "resnet.layer%d.%d" % (li, bi)
             stride = 2 if (bi == 0 and li > 1) else 1
-            o = F.conv2d(h, sd[p + ".conv1.weight"], None, stride=stride, padding=1)
-            o = F.relu(_bn(sd, p + ".bn1", o, train, taps))
-            o = F.conv2d(o, sd[p + ".conv2.weight"], None, stride=1, padding=1)
+            o = _rb(F.conv2d(h, _wq(sd[p + ".conv1.weight"], q), None, stride=stride, padding=1), q)
+            o = _rb(F.relu(_bn(sd, p + ".bn1", o, train, taps)), q)
+            o = _rb(F.conv2d(o, _wq(sd[p + ".conv2.weight"], q), None, stride=1, padding=1), q)
             o = _bn(sd, p + ".bn2", o, train, taps)
             if (p + ".downsample.0.weight") in sd:
-                idn = F.conv2d(h, sd[p + ".downsample.0.weight"], None, stride=stride)
+                idn = _rb(F.conv2d(h, _wq(sd[p + ".downsample.0.weight"], q), None, stride=stride), q)
                 idn = _bn(sd, p + ".downsample.1", idn, train, taps)
             else:
                 idn = h
-            h = F.relu(o + idn)
+            h = _rb(F.relu(o + idn), q)
     h = h.mean(dim=(2, 3))                     # AdaptiveAvgPool2d((1,1)) + flatten
     return F.linear(h, sd["resnet.fc.weight"], sd["resnet.fc.bias"])
 
@@ -282,7 +311,7 @@ class StudentOracle:
 
     # -- forward / loss / backward ------------------------------------------
     def forward_loss(self, img: torch.Tensor, target: torch.Tensor, train: bool,
-                     need_grad: bool, taps: Optional[dict] = None):
+                     need_grad: bool, taps: Optional[dict] = None, emulate_bf16: bool = False):
         ps = self.params()
         if need_grad:
             for p in ps.values():
@@ -290,7 +319,7 @@ class StudentOracle:
                 p.grad = None
         ctx = torch.enable_grad() if need_grad else torch.no_grad()
         with ctx:
-            emb = encoder_forward(self.enc, img, self.arch, train, taps)
+            emb = encoder_forward(self.enc, img, self.arch, train, taps, emulate_bf16)
             out = decoder_forward(self.dec, emb) if self.motion else emb
             loss = sum_mse(out, target)
         grads = None

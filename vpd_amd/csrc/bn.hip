@@ -330,7 +330,7 @@ hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* ga
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
-                       T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS, p.C, count,
+                       VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, p.coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
     return hipGetLastError();
@@ -421,7 +421,7 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
-                       T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS, p.C, count,
+                       VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, coef);
     BnBwdParams q = {};
     q.dy = p.g; q.dy_rw = nullptr; q.z = p.z; q.act = nullptr; q.mean = p.mean; q.rstd = p.rstd; q.coef = coef;

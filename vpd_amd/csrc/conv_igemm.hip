@@ -14,6 +14,118 @@
 // chunk index XOR-ed by (row & 7): conflict-free for ds_read_b128 fragments.
 #include "common.h"
 
+// Shared epilogue: acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr].
+// Stores bf16 NHWC (8 B per lane), optional eval epilogue (scale/shift/residual/ReLU), optional
+// read-modify-write accumulate, optional per-channel sum / sum-of-squares of the stored values.
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                     int mtile, int n0, unsigned char* smem) {
+    constexpr int WTM = BM / WM;
+    constexpr int WTN = BN / WN;
+    constexpr int MI = WTM / 16;
+    constexpr int NI = WTN / 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    const int m0 = mtile * BM;
+    const int HW = p.Hs * p.Ws;
+    // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
+    float s1[NI][4], s2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
+
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = m0 + wm * WTM + b * 16 + fr;
+        const bool valid = m < p.M;
+        const int mc = valid ? m : p.M - 1;
+        const int bi = mc / HW;
+        const int r = mc - bi * HW;
+        const int yy = r / p.Ws;
+        const int xx = r - yy * p.Ws;
+        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + p.oph + p.ypad) * p.yWp +
+                             (xx * p.osub + p.opw + p.ypad)) * p.yC;
+        size_t roff = 0;
+        if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (p.ep_scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
+                const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                if (p.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+                    v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
+                    v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
+                }
+                if (p.ep_relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                }
+            }
+            bf16_t* dst = p.y + yoff + n;
+            if (p.accumulate && valid) {
+                const uint2 ov = *reinterpret_cast<const uint2*>(dst);
+                v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
+                v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
+            }
+            uint2 ov;
+            ov.x = pack2bf(v[0], v[1]);
+            ov.y = pack2bf(v[2], v[3]);
+            if (valid) {
+                *reinterpret_cast<uint2*>(dst) = ov;
+                // statistics are taken over the bf16-rounded values actually stored
+                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
+                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
+                s1[a][0] += q0; s2[a][0] += q0 * q0;
+                s1[a][1] += q1; s2[a][1] += q1 * q1;
+                s1[a][2] += q2; s2[a][2] += q2 * q2;
+                s1[a][3] += q3; s2[a][3] += q3 * q3;
+            }
+        }
+    }
+
+    if (p.stats) {
+        // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
+        float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float u = s1[a][j], v = s2[a][j];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    u += __shfl_xor(u, o, 64);
+                    v += __shfl_xor(v, o, 64);
+                }
+                if (fr == 0) {
+                    const int c = wn * WTN + a * 16 + 4 * fq + j;
+                    red[(wm * 2 + 0) * BN + c] = u;
+                    red[(wm * 2 + 1) * BN + c] = v;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN;
+            const int c = tid - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
+            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
+            atomicAdd(&p.stats[((size_t)(mtile & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves");
@@ -127,99 +239,184 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         if (s + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
     }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+}
 
-    // ---------------- epilogue ----------------
-    // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
-    float s1[NI][4], s2[NI][4];
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 convolution with an LDS-resident NHWC halo tile.
+//
+// The output tile is BM consecutive pixels of whole image rows (BM % W == 0).  In the zero-bordered
+// NHWC layout the input pixels all nine taps need form ONE contiguous run of padded rows (also across
+// images, whose padded planes are adjacent), so the halo [NHP pixels][64 channels] is brought to LDS
+// once per 64-channel chunk by LDS-DMA (global_load_lds, 16 B per lane, swizzle applied on the source
+// address) and every tap reads its pixel fragments from it at a shifted row.  Only the per-tap weight
+// tile [BN][64] streams (double-buffered LDS-DMA, prefetched one tap ahead).  No register staging, one
+// barrier per 64-deep K-step.
+// ---------------------------------------------------------------------------
+struct HaloGeom {
+    int TR;        // output rows per tile (BM / W)
+    int multi;     // tile spans TR/H whole images (TR > H)
+    int HR;        // padded rows in the halo
+    int NHP;       // halo pixels = HR * (W + 2)
+    int total_pix; // N * (H+2) * (W+2): clamp for the last (ragged) tile
+};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <int BM, int BN, int HROWS, bool HALO2>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, const HaloGeom g) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int HB = HALO2 ? 2 : 1;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [HB][HROWS*64]
+    bf16_t* sW = sH + HB * HROWS * 64;                            // [2][BN*64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    const int mtile = blockIdx.x;
+    const int n0 = blockIdx.y * BN;
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int Ci = p.Kc;
+
+    // first padded pixel of the halo in the input tensor
+    const int gr0 = mtile * g.TR;                                 // global output row = b*H + y
+    int prow0;
+    if (g.multi) prow0 = (gr0 / H) * (H + 2);
+    else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+    const int gp0 = prow0 * Wp;
+
+    // per-lane halo row of each pixel fragment (tap offset added per step)
+    int hbase[MI];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = wm * WTM + b * 16 + fr;
+        const int lr = m / W;
+        const int xx = m - lr * W;
+        const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+        hbase[b] = hrow * Wp + xx;
+    }
+
+    const int piece = tid & 7;
+    const int srow = tid >> 3;                                    // 0..31: row within a 32-row pass
+    auto issue_halo = [&](int cc, int hb) __attribute__((always_inline)) {
+        bf16_t* dst = sH + hb * HROWS * 64;
+#pragma unroll
+        for (int ps = 0; ps < HROWS / 32; ++ps) {
+            const int hp = ps * 32 + srow;
+            int gp = gp0 + hp;
+            gp = gp < g.total_pix ? gp : g.total_pix - 1;
+            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ (hp & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (ps * 32 + wave * 8) * 64), 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int step, int wb) __attribute__((always_inline)) {
+        const int cc = step / 9;
+        const int tap = step - cc * 9;
+        const int ir = tap / 3, ic = tap - ir * 3;
+        const int wsl = p.taps.w0 + ir * p.taps.wrs + ic * p.taps.wcs;
+        bf16_t* dst = sW + wb * BN * 64;
+        const bf16_t* wbp = p.w + ((size_t)wsl * p.Co + n0) * Ci + cc * 64;
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int n = i * 32 + srow;
+            const bf16_t* src = wbp + (size_t)n * Ci + ((piece ^ (n & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (i * 32 + wave * 8) * 64), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[NI][MI];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
+        for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const int nchunks = Ci >> 6;
+    const int nsteps = nchunks * 9;
+    issue_halo(0, 0);
+    issue_w(0, 0);
+
+    int step = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bf16_t* cH = sH + (HALO2 ? (cc & 1) : 0) * HROWS * 64;
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            // everything issued so far (this step's weights, this chunk's halo) has landed; all waves
+            // are past the previous step's LDS reads
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (step + 1 < nsteps) issue_w(step + 1, (step + 1) & 1);
+            if (HALO2 && tap == 0 && cc + 1 < nchunks) issue_halo(cc + 1, (cc + 1) & 1);
+
+            const int ir = tap / 3, ic = tap - ir * 3;
+            const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
+            const bf16_t* cW = sW + (step & 1) * BN * 64;
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * WTM + b * 16 + fr;
-        const bool valid = m < p.M;
-        const int mc = valid ? m : p.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / p.Ws;
-        const int xx = r - yy * p.Ws;
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + p.oph + p.ypad) * p.yWp +
-                             (xx * p.osub + p.opw + p.ypad)) * p.yC;
-        size_t roff = 0;
-        if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfm[MI];
+                const int chunk = kk * 4 + fq;
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (p.ep_scale) {
-                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                if (p.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-                    v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
-                    v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
+                for (int a = 0; a < NI; ++a) {
+                    const int r = wn * WTN + a * 16 + fr;
+                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
                 }
-                if (p.ep_relu) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                for (int b = 0; b < MI; ++b) {
+                    const int r = hbase[b] + toff;
+                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
                 }
-            }
-            bf16_t* dst = p.y + yoff + n;
-            if (p.accumulate && valid) {
-                const uint2 ov = *reinterpret_cast<const uint2*>(dst);
-                v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
-                v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
-            }
-            uint2 ov;
-            ov.x = pack2bf(v[0], v[1]);
-            ov.y = pack2bf(v[2], v[3]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(dst) = ov;
-                // statistics are taken over the bf16-rounded values actually stored
-                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
-                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
-                s1[a][0] += q0; s2[a][0] += q0 * q0;
-                s1[a][1] += q1; s2[a][1] += q1 * q1;
-                s1[a][2] += q2; s2[a][2] += q2 * q2;
-                s1[a][3] += q3; s2[a][3] += q3 * q3;
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-    }
-
-    if (p.stats) {
-        // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
-        float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = s1[a][j], v = s2[a][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    u += __shfl_xor(u, o, 64);
-                    v += __shfl_xor(v, o, 64);
-                }
-                if (fr == 0) {
-                    const int c = wn * WTN + a * 16 + 4 * fq + j;
-                    red[(wm * 2 + 0) * BN + c] = u;
-                    red[(wm * 2 + 1) * BN + c] = v;
-                }
-            }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN;
-            const int c = tid - which * BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
-            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
-            atomicAdd(&p.stats[((size_t)(mtile & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
+        if (!HALO2 && cc + 1 < nchunks) {
+            __builtin_amdgcn_s_barrier();          // every wave is done reading this chunk's halo
+            issue_halo(cc + 1, 0);
         }
     }
+    __syncthreads();                               // LDS is reused by the statistics reduction
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+}
+
+template <int BM, int BN, int HROWS, bool HALO2>
+static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    size_t lds = ((size_t)(HALO2 ? 2 : 1) * HROWS + 2 * BN) * 64 * sizeof(bf16_t);
+    const size_t red = (size_t)2 * 2 * BN * sizeof(float);
+    if (lds < red) lds = red;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, p, g);
+    return hipGetLastError();
+}
+
+// Geometry of the halo tiling for a BM-pixel tile, or false when the shape does not fit it.
+static bool halo_geom(const ConvParams& p, int BM, int hrows_max, HaloGeom* g) {
+    const int W = p.Ws, H = p.Hs;
+    if (BM % W != 0) return false;
+    const int TR = BM / W;
+    if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
+    else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
+    g->TR = TR;
+    g->NHP = g->HR * (W + 2);
+    g->total_pix = p.N * (H + 2) * (W + 2);
+    return g->NHP <= hrows_max;
+}
+
+// 3x3, stride 1, border-1 input, dense sub-grid: eligible for the halo kernel
+static bool halo_eligible(const ConvParams& p) {
+    return p.taps.nr == 3 && p.taps.nc == 3 && p.istr == 1 && p.osub == 1 && p.oph == 0 && p.opw == 0 &&
+           p.xC == p.Kc && p.xHp == p.Hs + 2 && p.xWp == p.Ws + 2 && p.taps.dy0 + 2 * p.taps.dys >= 0 &&
+           p.taps.dy0 >= 0 && p.taps.dy0 <= 2 && p.taps.dx0 >= 0 && p.taps.dx0 <= 2 &&
+           p.taps.dy0 + 2 * p.taps.dys <= 2 && p.taps.dx0 + 2 * p.taps.dxs >= 0 && p.taps.dx0 + 2 * p.taps.dxs <= 2;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -243,6 +440,18 @@ extern "C" int vpd_conv_bm(int M, int Co) {
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream) {
     if (p.Kc % 64 != 0 || p.Co % 64 != 0 || p.M <= 0) return hipErrorInvalidValue;
     const int bm = vpd_conv_bm(p.M, p.Co);
+    if (halo_eligible(p)) {
+        // the statistics accumulator rows only depend on the block index, so the tile choice is free
+        HaloGeom g;
+        if (p.Co % 128 == 0) {
+            if (bm == 128 && halo_geom(p, 128, 224, &g))
+                return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)
+                                  : launch_halo<128, 128, 224, false>(p, g, stream);
+            if (halo_geom(p, 64, 160, &g)) return launch_halo<64, 128, 160, true>(p, g, stream);
+        } else if (halo_geom(p, 128, 224, &g)) {
+            return launch_halo<128, 64, 224, false>(p, g, stream);
+        }
+    }
     if (p.Co % 128 == 0) {
         if (bm == 128) return launch_cfg<128, 128, 2, 2>(p, stream);
         return launch_cfg<64, 64, 2, 2>(p, stream);

@@ -460,8 +460,8 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
 hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) {
     const int M = c.n * cv.Hout * cv.Wout;
     const int bm = vpd_conv_bm(M, cv.Co);
-    int T = (M + bm - 1) / bm;
-    T = T < VPD_STAT_ROWS ? T : VPD_STAT_ROWS;
+    (void)bm;
+    const int T = VPD_STAT_ROWS;     // unused accumulator rows are zero; the producer's tile size is its own business
     return vpd_launch_bn_finalize(c.f32(c.p->partial_off), T, cv.Co, (float)M, c.params + cv.bn.w_off,
                                   c.params + cv.bn.b_off, bn_running ? bn_running + cv.bn.rm_off : nullptr,
                                   bn_running ? bn_running + cv.bn.rv_off : nullptr, kBnMomentum, kBnEps,
