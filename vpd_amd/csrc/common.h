@@ -80,6 +80,7 @@ struct ConvParams {
     int Kc, Co;
     int M;                                      // N*Hs*Ws
     int accumulate;                             // y += result
+    int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
 };
 

@@ -12,6 +12,8 @@
 // before the MFMAs of step s, written to the other LDS buffer after them; one
 // barrier per step.  LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B
 // chunk index XOR-ed by (row & 7): conflict-free for ds_read_b128 fragments.
+#include <stdlib.h>
+
 #include "common.h"
 
 // Shared epilogue: acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr].
@@ -352,8 +354,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
             // are past the previous step's LDS reads
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (step + 1 < nsteps) issue_w(step + 1, (step + 1) & 1);
-            if (HALO2 && tap == 0 && cc + 1 < nchunks) issue_halo(cc + 1, (cc + 1) & 1);
+            if (step + 1 < nsteps && !(p.ablate & 1)) issue_w(step + 1, (step + 1) & 1);
+            if (HALO2 && tap == 0 && cc + 1 < nchunks && !(p.ablate & 4)) issue_halo(cc + 1, (cc + 1) & 1);
+            if (p.ablate & 2) continue;
 
             const int ir = tap / 3, ic = tap - ir * 3;
             const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
@@ -437,8 +440,11 @@ extern "C" int vpd_conv_bm(int M, int Co) {
     return 128;
 }
 
-hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream) {
-    if (p.Kc % 64 != 0 || p.Co % 64 != 0 || p.M <= 0) return hipErrorInvalidValue;
+hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
+    if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+    p.ablate = ablate;
     const int bm = vpd_conv_bm(p.M, p.Co);
     if (halo_eligible(p)) {
         // the statistics accumulator rows only depend on the block index, so the tile choice is free
