@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Drop-in for reference apply_vpd_model.py (same flags and output files)."""
+import argparse
+import os
+
+import torch
+from torch.utils.data import DataLoader
+
+from vpd_amd import paths as dataset_paths
+from vpd_amd.apply import apply_batch_size, embed_dataset, write_embeddings
+from vpd_amd.data import FrameDataset, list_crop_dir
+from vpd_amd.io import load_json
+from vpd_amd.models.rgb import RGBF_EmbeddingModel
+
+
+def get_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('model_dir', type=str)
+    parser.add_argument('-d', '--dataset', type=str, required=True, choices=['tennis', 'fs', 'fx', 'diving48'])
+    parser.add_argument('-o', '--out_dir', type=str)
+    parser.add_argument('-m', '--model_epoch', type=int, help='Specify an epooh. Otherwise use the best one.')
+    parser.add_argument('--jitter', type=int, help='Create additional jittered features.')
+    parser.add_argument('--no_flip', action='store_true', help='Do not embed horizontal flips')
+    parser.add_argument('--flow_img', type=str)
+    return parser.parse_args()
+
+
+def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
+    device = 'cuda'
+    model_params = load_json(os.path.join(model_dir, 'config.json'))
+    emb_dim = model_params['emb_dim']
+    encoder_arch = model_params['encoder_arch']
+    img_dim = model_params['img_dim']
+    use_flow = model_params['use_flow']
+    if use_flow:
+        assert flow_img is not None, 'No flow image name specified'
+    embed_time = model_params.get('embed_time', model_params.get('motion'))   # Appendix B.1
+    rgb_mean_std = model_params['rgb_mean_std']
+    print('Embedding dim:', emb_dim)
+    print('Encoder architecture:', encoder_arch)
+    print('Image dim:', img_dim)
+    print('Use flow:', use_flow, '(name = {})'.format(flow_img))
+    print('Embed time:', embed_time)
+    print('Flip:', not no_flip)
+    print('RGB mean & std:', rgb_mean_std)
+
+    if dataset == 'tennis':
+        raise NotImplementedError('tennis uses per-player crop naming (apply_vpd_model.py:36-66): not yet mirrored')
+    videos, tasks = list_crop_dir(dataset_paths.CROPS[dataset])
+    ds = FrameDataset(tasks, img_dim, rgb_mean_std, augment_jitter=jitter or 0, augment_flip=not no_flip,
+                      flow_img_name=flow_img)
+
+    model_name = 'best_epoch' if model_epoch is None else 'epoch{:04d}'.format(model_epoch)
+    print('Model name:', model_name)
+    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, use_flow, device)
+    encoder.load_state_dict(torch.load(os.path.join(model_dir, '{}.encoder.pt'.format(model_name)),
+                                       map_location=device))
+    encoder.to(device)
+
+    loader = DataLoader(ds, batch_size=apply_batch_size(jitter, no_flip), shuffle=False,
+                        num_workers=max(os.cpu_count() // 2, 1), pin_memory=True)
+    all_embs = embed_dataset(encoder, loader, len(videos))
+    if out_dir is not None:
+        write_embeddings(out_dir, videos, all_embs)
+    print('Done!')
+
+
+if __name__ == '__main__':
+    main(**vars(get_args()))

@@ -44,24 +44,33 @@ def synthetic_batch(n, device, seed):
     return img, emb
 
 
-def cpu_baseline(sample_batch=16, steps=3):
+def cpu_baseline(sample_batch=32, budget_s=20.0, max_steps=40):
     """The CPU oracle (fp32 torch-CPU restatement of the reference loop, kind "port") on the
-    host cores: same network/loss/optimizer on a bounded sample of the same workload."""
+    host cores this process may run on: same network/loss/optimizer on a bounded sample of the
+    same workload (about `budget_s` seconds of CPU work)."""
     from oracle import vpd_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 32))              # more threads than that only adds contention at this size
+    torch.set_num_threads(threads)
     enc = O.reference_init_state_dict(ARCH, C_IN, EMB_DIM, 0)
     orc = O.StudentOracle(ARCH, C_IN, EMB_DIM, False, enc)
     orc.get_optimizer(5e-4)
     img = O.synthetic_crops(sample_batch, C_IN, HW, 1)
     tgt = O.synthetic_targets(sample_batch, EMB_DIM, False, 2)
-    orc.train_step(img, tgt)                     # warm-up
     t0 = time.perf_counter()
-    for _ in range(steps):
+    orc.train_step(img[:4], tgt[:4])              # warm-up (allocator, thread pool)
+    warm = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
         orc.train_step(img, tgt)
+        steps += 1
     dt = time.perf_counter() - t0
-    return {"value": sample_batch * steps / dt, "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d train steps of %d crops (ResNet-34, 5x128x128, fp32, torch-CPU oracle)" % (steps, sample_batch)}
+    return {"value": sample_batch * steps / dt, "unit": "crops/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps of %d crops in %.1f s (ResNet-34, 5x128x128, fp32, torch-CPU oracle; "
+                      "%d schedulable cores, warm-up %.1f s)" % (steps, sample_batch, dt, cores, warm)}
 
 
 def main():

@@ -106,9 +106,10 @@ int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 
 /* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
- * bracketed by HIP events on its own stream.  Classes: 0 conv_igemm<128,64>, 1 conv_igemm<128,128>,
- * 2 conv_igemm<64,64> (forward + data-gradient convs), 3 conv_wgrad.  vpd_plan_read_timing waits for
- * the events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
+ * bracketed by HIP events on its own stream.  Classes (forward + data-gradient convs): 0 conv3x3_halo<128,64>,
+ * 1 conv3x3_halo<128,128>, 2 conv3x3_halo<64,128>, 3 conv_igemm (gather kernel; the parity-class launches of a
+ * stride-2 dgrad count as one launch); 4 conv_wgrad.  vpd_plan_read_timing (nclasses >= 5) waits for the
+ * events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
 int vpd_plan_set_timing(vpd_plan_t* plan, int enable);
 int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
 

@@ -1,0 +1,68 @@
+"""apply path on the GPU: hipGraph-captured eval forward -> per-video pickles in the reference's
+format, checked against the golden produced by the reference's own loop body and writer."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vpd_oracle as O
+from tests.test_host_cpu import group_by_frame
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_apply_loop_pickles_match_reference_golden(tmp_path):
+    from vpd_amd.apply import embed_dataset, write_embeddings
+    from vpd_amd.io import load_pickle
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    g = np.load(os.path.join(REPO, "tests", "golden", "format_case.npz"))
+    arch, D, c_in = "resnet18", 32, 5
+    enc = RGBF_EmbeddingModel(arch, D, True, "cuda")
+    enc.load_state_dict(O.procedural_state_dict(O.encoder_schema(arch, c_in, D), 5))
+    videos = ["vidA", "vidB", "vidC"]
+    tasks = g["tasks"]
+    for k, tag in ((2, "k2"), (1, "k1")):
+        imgs = O.synthetic_crops(len(tasks) * k, c_in, 64, 21).reshape(len(tasks), k, c_in, 64, 64)
+        batches = [{"video": torch.tensor(tasks[s:s + 5, 0]), "frame": torch.tensor(tasks[s:s + 5, 1]),
+                    "img": imgs[s:s + 5]} for s in range(0, len(tasks), 5)]       # 5 + 5 + 2: tail batch
+        all_embs = embed_dataset(enc, batches, len(videos))
+        out = tmp_path / tag
+        write_embeddings(str(out), videos, all_embs)
+        for v in videos:
+            embs = load_pickle(str(out / ("%s.emb.pkl" % v)))
+            assert [t[0] for t in embs] == sorted(t[0] for t in embs)
+            assert all(isinstance(t[0], int) and t[1].dtype == np.float32 and t[2] == {} for t in embs)
+            assert embs[0][1].shape == ((2, D) if k == 2 else (D,))
+            dense, mask = group_by_frame(embs)
+            ref = g["dense/%s/%s" % (tag, v)]
+            assert np.array_equal(mask, g["mask/%s/%s" % (tag, v)])
+            rel = np.linalg.norm(dense - ref) / np.linalg.norm(ref)
+            assert rel <= 2e-2, rel            # bf16 student vs the fp32 reference
+
+
+def test_train_cli_synthetic_writes_reference_files(tmp_path):
+    save = tmp_path / "run"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "train_vpd_model.py"), "diving48", "--save_dir", str(save),
+                        "--num_epochs", "2", "--batch_size", "16", "--flow_img", "flow", "--motion",
+                        "--encoder_arch", "resnet18", "--img_dim", "64", "--synthetic", "48", "--synthetic_emb_dim", "16",
+                        "--checkpoint_frequency", "1"], cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    cfg = json.load(open(save / "config.json"))
+    assert cfg["motion"] is True and cfg["embed_time"] is True and cfg["emb_dim"] == 16 and cfg["use_flow"] is True
+    loss = json.load(open(save / "loss.json"))
+    assert len(loss) == 2 and set(loss[0]) == {"epoch", "train", "val", "dataset_train", "dataset_val"}
+    assert loss[1]["train"] < loss[0]["train"]
+    for name in ("best_epoch", "epoch0001", "epoch0002"):
+        sd = torch.load(save / ("%s.encoder.pt" % name), map_location="cpu")
+        assert list(sd.keys()) == list(O.encoder_schema("resnet18", 5, 16).keys())
+        dd = torch.load(save / ("%s.decoder.pt" % name), map_location="cpu")
+        assert list(dd.keys()) == list(O.decoder_schema(16).keys())
+    # an existing save_dir is an error, as in the reference
+    r = subprocess.run([sys.executable, os.path.join(REPO, "train_vpd_model.py"), "diving48", "--save_dir", str(save),
+                        "--synthetic", "8", "--num_epochs", "1"], cwd=REPO, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "FileExistsError" in r.stderr

@@ -1,0 +1,123 @@
+"""Host-side logic that needs no GPU: dataset contracts, file formats, CLI flag surface."""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(REPO, "tests", "golden", "format")
+
+
+def group_by_frame(embs):
+    """Test-side restatement of the downstream reader (reference action_dataset/load.py:16-43)."""
+    num_frames = max(x[0] for x in embs) + 1
+    shp = embs[0][1].shape
+    dense = np.zeros((num_frames, *shp)) if len(shp) == 2 else np.zeros((num_frames, shp[-1]))
+    counts = np.zeros(num_frames)
+    for i, e, _ in embs:
+        dense[i] += e
+        counts[i] += 1
+    frames = sorted({x[0] for x in embs})
+    prev = frames[0]
+    for fr in frames[1:]:
+        gap = fr - prev
+        for i in range(1, gap):
+            a = i / gap
+            dense[prev + i] = a * dense[prev] + (1. - a) * dense[fr]
+        prev = fr
+    return dense, counts > 0
+
+
+def test_reference_written_pickles_match_our_reader_restatement():
+    g = np.load(os.path.join(REPO, "tests", "golden", "format_case.npz"))
+    from vpd_amd.io import load_pickle
+    for tag in ("k1", "k2"):
+        for vid in ("vidA", "vidB", "vidC"):
+            embs = load_pickle(os.path.join(GOLDEN, "%s.%s.emb.pkl" % (vid, tag)))
+            assert isinstance(embs, list) and all(isinstance(t, tuple) and len(t) == 3 for t in embs)
+            assert [t[0] for t in embs] == sorted(t[0] for t in embs)
+            assert all(isinstance(t[0], int) and t[1].dtype == np.float32 and t[2] == {} for t in embs)
+            assert embs[0][1].shape == ((2, 32) if tag == "k2" else (32,))
+            dense, mask = group_by_frame(embs)
+            assert np.allclose(dense, g["dense/%s/%s" % (tag, vid)]) and np.array_equal(mask, g["mask/%s/%s" % (tag, vid)])
+
+
+def test_config_and_loss_json_schema():
+    cfg = json.load(open(os.path.join(GOLDEN, "config.json")))
+    assert set(cfg) == {"num_epochs", "batch_size", "learning_rate", "img_dim", "use_flow", "motion", "emb_dim",
+                        "encoder_arch", "rgb_mean_std"}
+    loss = json.load(open(os.path.join(GOLDEN, "loss.json")))
+    assert set(loss[0]) == {"epoch", "train", "val", "dataset_train", "dataset_val"}
+
+
+def test_apply_batch_size_rule():
+    from vpd_amd.apply import apply_batch_size
+    assert apply_batch_size(None, False) == 500       # 500 frames x 2 views
+    assert apply_batch_size(None, True) == 1000
+    assert apply_batch_size(4, False) == 100
+
+
+def test_cli_flag_surface_matches_reference():
+    sys.path.insert(0, REPO)
+    import apply_vpd_model
+    import train_vpd_model
+    old = sys.argv
+    try:
+        sys.argv = ["x", "diving48", "--save_dir", "d", "--motion", "--flow_img", "flow", "--encoder_arch", "resnet34",
+                    "--checkpoint_frequency", "5", "--model_select_window", "3", "--min_pose_score", "0.4",
+                    "--emb_dir", "e", "--batch_size", "256", "--learning_rate", "0.001", "--img_dim", "128",
+                    "--num_epochs", "2"]
+        a = train_vpd_model.get_args()
+        assert a.dataset == "diving48" and a.motion and a.flow_img == "flow" and a.batch_size == 256
+        sys.argv = ["x", "diving48", "--save_dir", "d"]
+        a = train_vpd_model.get_args()
+        assert (a.num_epochs, a.batch_size, a.learning_rate, a.img_dim, a.encoder_arch, a.model_select_window) == \
+            (1000, 100, 0.0005, 128, "resnet34", 5)
+        sys.argv = ["x", "diving48", "--save_dir", "d", "--emb_dir", "a", "--penn_dir", "b"]
+        with pytest.raises(SystemExit):
+            train_vpd_model.get_args()
+        sys.argv = ["x", "model", "-d", "fs", "-o", "out", "-m", "7", "--no_flip", "--flow_img", "flow"]
+        b = apply_vpd_model.get_args()
+        assert (b.model_dir, b.dataset, b.out_dir, b.model_epoch, b.no_flip, b.flow_img) == \
+            ("model", "fs", "out", 7, True, "flow")
+    finally:
+        sys.argv = old
+
+
+def test_teacher_dataset_contract(tmp_path):
+    """Teacher pickle ingestion: pose-score filter, embed_time pairing of consecutive frames,
+    batch items {'img': f32[5,H,W], 'emb': f32[2D]}, flip negates the x-flow channel."""
+    from PIL import Image
+    from vpd_amd.data import RGB_MEAN_STD, TeacherEmbDataset
+    emb_dir, img_dir = tmp_path / "embs", tmp_path / "crops"
+    (img_dir / "vid").mkdir(parents=True)
+    emb_dir.mkdir()
+    rs = np.random.RandomState(0)
+    embs = []
+    for fr in (3, 4, 5, 7, 8):
+        Image.fromarray(rs.randint(0, 255, (32, 32, 3)).astype(np.uint8)).save(img_dir / "vid" / ("%d.png" % fr))
+        Image.fromarray(rs.randint(0, 255, (32, 32, 3)).astype(np.uint8)).save(img_dir / "vid" / ("%d.flow.png" % fr))
+        embs.append((fr, rs.randn(2, 8).astype(np.float32), {"kp_score": 0.9 if fr != 8 else 0.1}))
+    with open(emb_dir / "vid.emb.pkl", "wb") as fp:
+        pickle.dump(embs, fp)
+    tr, va, D = TeacherEmbDataset.load_default(str(emb_dir), str(img_dir), 32, True, 50, RGB_MEAN_STD["diving48"],
+                                               flow_img_name="flow")
+    assert D == 8 and len(tr) == 50 and len(va) == 10
+    kept = sorted(x[1] for x in tr.data + va.data)
+    assert kept == [4, 5]          # 3: no predecessor; 7: gap; 8: low pose score
+    item = tr[0]
+    assert item["img"].shape == (5, 32, 32) and item["img"].dtype == torch.float32
+    assert item["emb"].shape == (16,) and item["emb"].dtype == torch.float32
+    assert float(item["img"][3:].abs().max()) <= 0.5
+
+
+def test_synthetic_dataset_is_seeded_and_in_range():
+    from vpd_amd.data import RGB_MEAN_STD, SyntheticCrops
+    ds = SyntheticCrops(10, 5, 64, 16, True, RGB_MEAN_STD["diving48"], seed=3)
+    a, b = ds[2], ds[2]
+    assert torch.equal(a["img"], b["img"]) and a["img"].shape == (5, 64, 64) and a["emb"].shape == (32,)
+    assert float(a["img"][3:].abs().max()) <= 0.5

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Drop-in for reference train_vpd_model.py (same flags, files and bookkeeping; the
+student's arithmetic runs on libvpdhip).  Extra, optional flags: --synthetic N (no
+dataset files needed) and torchrun for multi-GPU data parallelism."""
+import argparse
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from vpd_amd import paths as dataset_paths
+from vpd_amd.data import RGB_MEAN_STD, SyntheticCrops, TeacherEmbDataset
+from vpd_amd.io import store_json
+from vpd_amd.models.rgb import RGBF_EmbeddingModel
+from vpd_amd.trainer import ModelTrainer
+
+DATASETS = ['tennis', 'fs', 'fx', 'penn', 'diving48']
+
+
+def get_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('dataset', type=str, choices=DATASETS)
+    parser.add_argument('--save_dir', type=str, required=True)
+    parser.add_argument('--checkpoint_frequency', type=int)
+    parser.add_argument('--num_epochs', type=int, default=1000)
+    parser.add_argument('--batch_size', type=int, default=100)
+    parser.add_argument('--learning_rate', type=float, default=0.0005)
+    parser.add_argument('--img_dim', type=int, default=128)
+    parser.add_argument('--flow_img', type=str)
+    parser.add_argument('--motion', action='store_true')
+    parser.add_argument('--encoder_arch', type=str, default='resnet34')
+    parser.add_argument('--model_select_window', type=int, default=5)
+    parser.add_argument('--pretrained', action='store_true')
+    parser.add_argument('--no_test_video', action='store_true')
+    parser.add_argument('--min_pose_score', type=float)
+    dataset_group = parser.add_mutually_exclusive_group()
+    dataset_group.add_argument('--emb_dir', type=str)
+    dataset_group.add_argument('--penn_dir', type=str)
+    # extensions (not in the reference)
+    parser.add_argument('--synthetic', type=int, help='train on N seeded synthetic crops per epoch')
+    parser.add_argument('--synthetic_emb_dim', type=int, default=128)
+    return parser.parse_args()
+
+
+def get_moving_avg_loss(losses, n, key):
+    return np.mean([l[key] for l in losses[-n:]])
+
+
+def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
+    if dataset == 'penn':
+        raise NotImplementedError('PennDataset reads a hard-coded private path in the reference (out of scope)')
+    if no_test_video:
+        raise NotImplementedError('--no_test_video needs the reference action_dataset split lists (out of scope)')
+    if emb_dir is None:
+        emb_dir = os.path.join(dataset_paths.ROOT[dataset], 'embs')
+    return TeacherEmbDataset.load_default(emb_dir, dataset_paths.CROPS[dataset], **dataset_kwargs)
+
+
+def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, motion, encoder_arch, save_dir,
+         model_select_window, checkpoint_frequency, pretrained, emb_dir, penn_dir, no_test_video, min_pose_score,
+         synthetic=None, synthetic_emb_dim=128):
+    device = 'cuda'
+    rank, world = 0, 1
+    if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        torch.distributed.init_process_group('nccl')
+    rgb_mean_std = RGB_MEAN_STD['resnet' if pretrained else dataset]
+
+    if synthetic is not None:
+        use_flow = flow_img is not None
+        emb_dim = synthetic_emb_dim
+        mk = lambda n, seed: SyntheticCrops(n, 5 if use_flow else 3, img_dim, emb_dim, motion, rgb_mean_std, seed)
+        train_dataset, val_dataset = mk(synthetic, 1 + rank), mk(max(synthetic // 5, 1), 1001 + rank)
+    else:
+        dataset_kwargs = {'img_dim': img_dim, 'flow_img_name': flow_img, 'embed_time': motion,
+                          'rgb_mean_std': rgb_mean_std, 'target_len': 20000 // world}
+        if min_pose_score is not None:
+            dataset_kwargs['min_pose_score'] = min_pose_score
+        train_dataset, val_dataset, emb_dim = load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video)
+
+    if rank == 0:
+        print('Device:', device)
+        print('Num epochs:', num_epochs)
+        print('Batch size:', batch_size)
+        print('Image dim:', img_dim)
+        print('Use flow:', flow_img is not None)
+        print('Embed time:', motion)
+        print('Encoder arch:', encoder_arch)
+        print('Dataset:')
+        print('', 'Train images:', len(train_dataset))
+        print('', 'Val images:', len(val_dataset))
+        print('', 'Embedding dim:', emb_dim)
+        print('', 'Min pose score:', min_pose_score)
+
+    num_load_workers = min(os.cpu_count(), 8)
+    train_loader = DataLoader(train_dataset, batch_size, shuffle=True, num_workers=num_load_workers,
+                              persistent_workers=False, pin_memory=True)
+    val_loader = DataLoader(val_dataset, batch_size, num_workers=num_load_workers, persistent_workers=False,
+                            pin_memory=True)
+
+    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, flow_img is not None, device, pretrained=pretrained)
+    if world > 1:      # same initial weights on every rank
+        torch.distributed.broadcast(encoder.engine.params, 0)
+    trainer = ModelTrainer(encoder, motion)
+    optimizer, scaler = trainer.get_optimizer(learning_rate)
+
+    if rank == 0:
+        os.makedirs(save_dir)     # fails on an existing directory, as the reference (train_vpd_model.py:221)
+        store_json(os.path.join(save_dir, 'config.json'), {
+            'num_epochs': num_epochs, 'batch_size': batch_size, 'learning_rate': learning_rate, 'img_dim': img_dim,
+            'use_flow': flow_img is not None, 'motion': motion,
+            'embed_time': motion,      # apply_vpd_model.py:102 reads this key; the reference never writes it
+            'emb_dim': emb_dim, 'encoder_arch': encoder_arch, 'rgb_mean_std': rgb_mean_std})
+
+    loss_file = os.path.join(save_dir, 'loss.json')
+    losses = []
+    best_val_loss = float('inf')
+    for epoch in range(1, num_epochs + 1):
+        train_loss = trainer.epoch(train_loader, optimizer=optimizer, scaler=scaler)
+        val_loss = trainer.epoch(val_loader)
+        losses.append({'epoch': epoch, 'train': train_loss, 'val': val_loss,
+                       'dataset_train': [(dataset, train_loss)], 'dataset_val': [(dataset, val_loss)]})
+        moving_avg_val_loss = get_moving_avg_loss(losses, model_select_window, 'val')
+        if rank == 0:
+            print('Epoch {} - train loss: {:0.4f} [avg: {:0.4f}] val loss: {:0.4f} [avg: {:0.4f}]'.format(
+                epoch, train_loss, get_moving_avg_loss(losses, model_select_window, 'train'), val_loss,
+                moving_avg_val_loss))
+            store_json(loss_file, losses)
+            if moving_avg_val_loss < best_val_loss:
+                print('New best epoch!')
+                trainer.save_model(save_dir, 'best_epoch')
+            if checkpoint_frequency is not None and epoch % checkpoint_frequency == 0:
+                print('Saving checkpoint: {}'.format(epoch))
+                trainer.save_model(save_dir, 'epoch{:04d}'.format(epoch))
+        best_val_loss = min(moving_avg_val_loss, best_val_loss)
+    if rank == 0:
+        print('Saving last epoch: {}'.format(epoch))
+        trainer.save_model(save_dir, 'epoch{:04d}'.format(epoch))
+        print('Done!')
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main(**vars(get_args()))

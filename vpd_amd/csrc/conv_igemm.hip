@@ -440,24 +440,37 @@ extern "C" int vpd_conv_bm(int M, int Co) {
     return 128;
 }
 
+// Kernel selection.  Classes (also the timing classes of vpd_plan_read_timing):
+//   0 conv3x3_halo<128,64>  1 conv3x3_halo<128,128>  2 conv3x3_halo<64,128>  3 conv_igemm (gather; any tile)
+int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
+    const int bm = vpd_conv_bm(p.M, p.Co);
+    if (halo_eligible(p)) {
+        if (p.Co % 128 == 0) {
+            if (bm == 128 && halo_geom(p, 128, 224, g)) return 1;
+            if (halo_geom(p, 64, 160, g)) return 2;
+        } else if (halo_geom(p, 128, 224, g)) {
+            return 0;
+        }
+    }
+    return 3;
+}
+int vpd_conv_kernel_class(const ConvParams& p) { HaloGeom g; return vpd_conv_kernel_class(p, &g); }
+
 hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     ConvParams p = p0;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     p.ablate = ablate;
-    const int bm = vpd_conv_bm(p.M, p.Co);
-    if (halo_eligible(p)) {
-        // the statistics accumulator rows only depend on the block index, so the tile choice is free
-        HaloGeom g;
-        if (p.Co % 128 == 0) {
-            if (bm == 128 && halo_geom(p, 128, 224, &g))
-                return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)
+    HaloGeom g;
+    switch (vpd_conv_kernel_class(p, &g)) {
+        case 0: return launch_halo<128, 64, 224, false>(p, g, stream);
+        case 1: return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)
                                   : launch_halo<128, 128, 224, false>(p, g, stream);
-            if (halo_geom(p, 64, 160, &g)) return launch_halo<64, 128, 160, true>(p, g, stream);
-        } else if (halo_geom(p, 128, 224, &g)) {
-            return launch_halo<128, 64, 224, false>(p, g, stream);
-        }
+        case 2: return launch_halo<64, 128, 160, true>(p, g, stream);
+        default: break;
     }
+    // the statistics accumulator rows only depend on the block index, so the tile choice is free
+    const int bm = vpd_conv_bm(p.M, p.Co);
     if (p.Co % 128 == 0) {
         if (bm == 128) return launch_cfg<128, 128, 2, 2>(p, stream);
         return launch_cfg<64, 64, 2, 2>(p, stream);

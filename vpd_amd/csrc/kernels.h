@@ -51,6 +51,7 @@ struct PackDesc {                       // one convolution's weight tensors
 };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
+int vpd_conv_kernel_class(const ConvParams& p);      // 0..3, see conv_igemm.hip
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
 

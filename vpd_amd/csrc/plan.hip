@@ -411,7 +411,7 @@ struct Ctx {
     float* bn_eshift(const BnInfo& b) const { return f32(b.fl_off) + 8 * b.C; }
 };
 
-// timing classes: 0 igemm<128,64> 1 igemm<128,128> 2 igemm<64,64> 3 wgrad
+// timing classes: 0..3 = vpd_conv_kernel_class (halo<128,64>, halo<128,128>, halo<64,128>, gather igemm), 4 = wgrad
 struct TimeScope {
     vpd_plan* p; hipStream_t s; int idx = -1;
     TimeScope(vpd_plan* p_, hipStream_t s_, int cls, double flops) : p(p_), s(s_) {
@@ -429,10 +429,6 @@ struct TimeScope {
     }
     ~TimeScope() { if (idx >= 0) (void)hipEventRecord(p->timed[idx].b, s); }
 };
-inline int igemm_class(int M, int Co) {
-    if (Co % 128 != 0) return 0;
-    return vpd_conv_bm(M, Co) == 128 ? 1 : 2;
-}
 inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real taps and channels
     return 2.0 * n * cv.Hout * cv.Wout * cv.Co * (double)cv.Ci * cv.k * cv.k;
 }
@@ -453,7 +449,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
-    TimeScope ts(c.p, c.s, igemm_class(q.M, q.Co), conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
     return vpd_launch_conv(q, c.s);
 }
 
@@ -477,9 +473,6 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
     q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
     hipError_t e = hipSuccess;
-    // one timing scope for all parity-class launches of this dgrad (classified by the first launch's shape)
-    TimeScope ts(c.p, c.s, igemm_class(c.n * (cv.stride == 1 ? cv.Hin * cv.Win : ((cv.Hin + 1) / 2) * ((cv.Win + 1) / 2)), cv.Ci),
-                 conv_flops(cv, c.n));
     if (cv.stride == 1) {
         // dx[y][x] = sum_{r,t} dz[y + pad - r][x + pad - t] W[r][t]; padded coord adds 1
         q.Hs = cv.Hin; q.Ws = cv.Win; q.osub = 1; q.oph = 0; q.opw = 0;
@@ -487,8 +480,11 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         q.taps.nr = cv.k; q.taps.nc = cv.k;
         q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
         q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
+        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
+    // the parity-class launches of a stride-2 dgrad are one timed unit (gather kernel)
+    TimeScope ts(c.p, c.s, 3, conv_flops(cv, c.n));
     // stride 2: one launch per input-pixel parity class; only taps r with (ph + pad - r) even
     // contribute: r = rf, rf+2, ... with dz row  y + (ph + pad - r)/2  (+1 for the border)
     for (int ph = 0; ph < 2; ++ph)
@@ -521,7 +517,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
-    TimeScope ts(c.p, c.s, 3, conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
     return vpd_launch_wgrad(q, c.s);
 }
 
@@ -804,7 +800,7 @@ extern "C" int vpd_plan_set_timing(vpd_plan_t* p, int enable) {
 
 // Sums (and clears) the recorded launches: out[4*cls + {0,1,2}] = {launches, milliseconds, flops}
 extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
-    if (!p || !out || nclasses < 4) return fail("bad argument");
+    if (!p || !out || nclasses < 5) return fail("bad argument");
     for (int i = 0; i < 3 * nclasses; ++i) out[i] = 0.0;
     for (auto& t : p->timed) {
         HCHECK(hipEventSynchronize(t.b));

@@ -1,0 +1,197 @@
+"""Batch producers on either side of the hot path (the
+*contract* is in scope, the augmentation pipeline is a "next" row).
+
+* RGB_MEAN_STD, EMB_FILE_SUFFIX .... reference vpd_dataset/common.py:9-36
+* TeacherEmbDataset ................ GenericDataset (vpd_dataset/single_frame.py:166-273):
+      teacher .emb.pkl ingestion (pose-score filter :35-44/:236-242, embed_time pairing
+      :247-258), unseeded 80/20 split (:263), sampling WITH replacement for a constant
+      epoch length (common.py:104-108), h-flip with x-flow negation (:199-203).
+      NOT yet implemented (next row f1): ColorJitter, mask noise, RandomResizedCrop.
+* FrameDataset ..................... vpd_dataset/single_frame.py:361-403 (orig + h-flip views)
+* SyntheticCrops ................... seeded crops in the reference's value ranges
+
+PNG decoding uses PIL (cv2 is not in this image).
+"""
+import os
+import random
+import re
+
+import numpy as np
+import torch
+
+from .io import load_pickle
+
+EMB_FILE_SUFFIX = '.emb.pkl'
+DEFAULT_MIN_POSE_SCORE = 0.5
+
+RGB_MEAN_STD = {
+    'tennis': ((0.44157383614877077, 0.47029633580897046, 0.4534017568516162),
+               (0.13526736314774856, 0.1208027074415591, 0.1261687563723076)),
+    'fs': ((0.5747710337842444, 0.5644043210903272, 0.6334494151377134),
+           (0.21349823115367886, 0.21827191146692457, 0.20393919008463163)),
+    'fx': ((0.38402001736617936, 0.34764328219285123, 0.4099846773620623),
+           (0.19505844565544309, 0.18984186888162677, 0.1989230425908947)),
+    'diving48': ((0.3411329922282787, 0.46349889258964044, 0.5162481674015696),
+                 (0.16302619019820488, 0.17092395707914718, 0.19266662199338647)),
+    'penn': ((0.43258389316320306, 0.4293850246457961, 0.383481774195889),
+             (0.18936336742486998, 0.18502009571154798, 0.18244625387985822)),
+    'resnet': ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225)),
+}
+
+
+def _load_png(path, img_dim):
+    from PIL import Image
+    im = Image.open(path).convert('RGB')
+    if im.size != (img_dim, img_dim):
+        im = im.resize((img_dim, img_dim), Image.BILINEAR)
+    return np.asarray(im, dtype=np.float32)          # H, W, 3 (RGB)
+
+
+def load_rgb(path, img_dim, rgb_mean_std):
+    rgb = torch.from_numpy(_load_png(path, img_dim)).permute(2, 0, 1) / 255.
+    mean = torch.tensor(rgb_mean_std[0]).view(3, 1, 1)
+    std = torch.tensor(rgb_mean_std[1]).view(3, 1, 1)
+    return (rgb - mean) / std
+
+
+def load_flow(path, img_dim):
+    # raft/flow.py:80-84 stores (fx, fy, 128) as RGB-ordered PNG channels read back by cv2 as BGR;
+    # vpd_dataset/common.py:69 keeps cv2 channels 0 and 1
+    arr = _load_png(path, img_dim)[:, :, ::-1][:, :, :2].copy()
+    return torch.from_numpy(arr / 255. - 0.5).permute(2, 0, 1).float()
+
+
+def _pose_score(meta):
+    return meta.get('kp_score', 1.) if isinstance(meta, dict) else 1.
+
+
+class TeacherEmbDataset(torch.utils.data.Dataset):
+
+    def __init__(self, data, img_dir, img_dim, rgb_mean_std, target_len, flow_img_name=None, augment=True):
+        self.data, self.img_dir, self.img_dim = data, img_dir, img_dim
+        self.rgb_mean_std, self.target_len = rgb_mean_std, target_len
+        self.flow_img_name, self.augment = flow_img_name, augment
+
+    def __len__(self):
+        return self.target_len
+
+    def __getitem__(self, idx):
+        video_name, frame_num, emb, _ = random.choice(self.data)      # index ignored, as the reference
+        flip = False
+        if len(emb.shape) == 2:
+            flip = self.augment and random.getrandbits(1) > 0
+            emb = emb[int(flip), :]
+        img = load_rgb(os.path.join(self.img_dir, video_name, '{}.png'.format(frame_num)), self.img_dim,
+                       self.rgb_mean_std)
+        if self.flow_img_name is not None:
+            flow = load_flow(os.path.join(self.img_dir, video_name, '{}.{}.png'.format(frame_num, self.flow_img_name)),
+                             self.img_dim)
+            img = torch.cat((img, flow))
+        if flip:
+            img = torch.flip(img, (2,))
+            if self.flow_img_name is not None:
+                img[3, :, :] *= -1
+        return {'emb': torch.as_tensor(emb, dtype=torch.float32), 'img': img}
+
+    @staticmethod
+    def load_default(emb_dir, img_dir, img_dim, embed_time, target_len, rgb_mean_std, flow_img_name=None,
+                     min_pose_score=None, exclude_prefixes=None):
+        all_data, emb_dim = [], None
+        thresh = DEFAULT_MIN_POSE_SCORE if min_pose_score is None else min_pose_score
+        for emb_file in sorted(os.listdir(emb_dir)):
+            if not emb_file.endswith(EMB_FILE_SUFFIX):
+                continue
+            video_name = emb_file.split(EMB_FILE_SUFFIX)[0]
+            if exclude_prefixes is not None and video_name.startswith(tuple(exclude_prefixes)):
+                print('Excluded:', video_name)
+                continue
+            video_embs = load_pickle(os.path.join(emb_dir, emb_file))
+            for i, (frame_num, emb_target, emb_meta) in enumerate(video_embs):
+                if emb_dim is None:
+                    emb_dim = emb_target.shape[-1]
+                assert emb_target.shape[-1] == emb_dim, 'Inconsistent emb dims {} != {}'.format(
+                    emb_target.shape[-1], emb_dim)
+                if _pose_score(emb_meta) < thresh:
+                    continue
+                if embed_time:
+                    if i == 0 or video_embs[i - 1][0] != frame_num - 1:
+                        continue
+                    emb_prev = video_embs[i - 1][1]
+                    emb_target = np.concatenate([emb_target, emb_target - emb_prev],
+                                                axis=0 if len(emb_target.shape) == 1 else 1)
+                all_data.append((video_name, frame_num, emb_target, emb_meta))
+        print('Videos:', len({x[0] for x in all_data}))
+        random.shuffle(all_data)                     # unseeded 80/20 split, like train_test_split(test_size=0.2)
+        n_val = int(round(0.2 * len(all_data)))
+        val_data, train_data = sorted(all_data[:n_val], key=lambda x: x[:2]), sorted(all_data[n_val:], key=lambda x: x[:2])
+        mk = lambda d, n: TeacherEmbDataset(d, img_dir, img_dim, rgb_mean_std, n, flow_img_name=flow_img_name)
+        return mk(train_data, target_len), mk(val_data, int(target_len * 0.2)), emb_dim
+
+
+class FrameDataset(torch.utils.data.Dataset):
+    """Inference items {'video', 'frame', 'img': [k, C, H, W]} with k = 1 (+1 h-flip view)."""
+
+    def __init__(self, tasks, img_dim, rgb_mean_std, augment_jitter=0, augment_flip=False, flow_img_name=None):
+        if augment_jitter:
+            raise NotImplementedError('--jitter views need ColorJitter (next row f1)')
+        self.tasks, self.img_dim, self.rgb_mean_std = tasks, img_dim, rgb_mean_std
+        self.flip, self.flow_img_name = augment_flip, flow_img_name
+
+    def __len__(self):
+        return len(self.tasks)
+
+    def __getitem__(self, idx):
+        video, frame_num, prefix = self.tasks[idx]
+        img = load_rgb('{}.png'.format(prefix), self.img_dim, self.rgb_mean_std)
+        imgs = [img]
+        flips = [torch.flip(img, (2,))] if self.flip else []
+        if self.flow_img_name is not None:
+            flow = load_flow('{}.{}.png'.format(prefix, self.flow_img_name), self.img_dim)
+            imgs = [torch.cat((x, flow)) for x in imgs]
+            if flips:
+                ff = torch.flip(flow, (2,))
+                ff[0, :, :] *= -1
+                flips = [torch.cat((x, ff)) for x in flips]
+        return {'video': video, 'frame': frame_num, 'img': torch.stack(imgs + flips)}
+
+
+def list_crop_dir(crop_dir):
+    """apply_vpd_model.get_dataset (:69-89): every <crop_dir>/<video>/<frame>.png"""
+    img_re = re.compile(r'^\d+\.png$')
+    tasks, videos = [], []
+    for video_name in sorted(os.listdir(crop_dir)):
+        d = os.path.join(crop_dir, video_name)
+        if not os.path.isdir(d):
+            continue
+        vid = len(videos)
+        videos.append(video_name)
+        for f in os.listdir(d):
+            if img_re.match(f):
+                fr = int(os.path.splitext(f)[0])
+                tasks.append((vid, fr, os.path.join(d, str(fr))))
+    return videos, tasks
+
+
+class SyntheticCrops(torch.utils.data.Dataset):
+    """Seeded synthetic crops + teacher targets in the reference's value ranges (no files)."""
+
+    def __init__(self, length, c_in, img_dim, emb_dim, motion, rgb_mean_std, seed=0):
+        self.length, self.c_in, self.img_dim, self.emb_dim, self.motion = length, c_in, img_dim, emb_dim, motion
+        self.mean = torch.tensor(rgb_mean_std[0]).view(3, 1, 1)
+        self.std = torch.tensor(rgb_mean_std[1]).view(3, 1, 1)
+        self.seed = seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        rgb = torch.randint(0, 256, (3, self.img_dim, self.img_dim), generator=g).float() / 255.
+        img = (rgb - self.mean) / self.std
+        if self.c_in > 3:
+            fl = (124 + 12 * torch.randn((self.c_in - 3, self.img_dim, self.img_dim), generator=g)).round().clamp(0, 255)
+            img = torch.cat((img, fl / 255. - 0.5))
+        t = torch.randn(self.emb_dim, generator=g)
+        if self.motion:
+            t = torch.cat((t, t - torch.randn(self.emb_dim, generator=g)))
+        return {'emb': t, 'img': img}

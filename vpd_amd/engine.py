@@ -250,10 +250,11 @@ class StudentEngine:
         check(lib().vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
 
     def read_timing(self, pl):
-        out = (C.c_double * 12)()
-        check(lib().vpd_plan_read_timing(pl.handle, out, 4), "vpd_plan_read_timing")
-        names = ["conv_igemm<128,64>", "conv_igemm<128,128>", "conv_igemm<64,64>", "conv_wgrad"]
-        return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(4)}
+        out = (C.c_double * 15)()
+        check(lib().vpd_plan_read_timing(pl.handle, out, 5), "vpd_plan_read_timing")
+        names = ["conv3x3_halo_kernel<128,64>", "conv3x3_halo_kernel<128,128>", "conv3x3_halo_kernel<64,128>",
+                 "conv_igemm_kernel", "conv_wgrad_kernel"]
+        return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(5)}
 
     def launch_eval_graph(self, pl, n):
         self._ensure_packed(pl)
