@@ -106,9 +106,9 @@ int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 
 /* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
- * bracketed by HIP events on its own stream.  Classes (forward + data-gradient convs): 0 conv3x3_halo<128,64>,
- * 1 conv3x3_halo<128,128>, 2 conv3x3_halo<64,128>, 3 conv_igemm (gather kernel; the parity-class launches of a
- * stride-2 dgrad count as one launch); 4 conv_wgrad.  vpd_plan_read_timing (nclasses >= 5) waits for the
+ * bracketed by HIP events on its own stream.  Classes (forward + data-gradient convs): 0 conv3x3_ws<256,64>,
+ * 1 conv3x3_ws<256,128>, 2 conv3x3_ws<128,128>, 3 every other conv kernel (gather igemm; the parity-class launches
+ * of a stride-2 dgrad count as one launch); 4 weight-gradient kernels (+ their slab reduce).  vpd_plan_read_timing (nclasses >= 5) waits for the
  * events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
 int vpd_plan_set_timing(vpd_plan_t* plan, int enable);
 int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
@@ -123,10 +123,13 @@ int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, float* s
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);
 int vpd_op_conv_bm(int M, int Co);
-/* dw[slice][Co][Kc] (fp32) += sum over output pixels of dz[m][co] * x[gather(m, tap)][kc] */
+/* dw[slice][Co][Kc] (fp32) += sum over output pixels of dz[m][co] * x[gather(m, tap)][kc].
+ * slab: optional fp32 scratch of vpd_op_wgrad_slab_bytes() bytes; when given, eligible 3x3 stride-1 shapes use
+ * the halo kernel (split partials in the slab + reduce), otherwise the generic kernel (fp32 atomics). */
 int vpd_op_wgrad(const void* dz_bf16, const void* x_bf16, float* dw, int n, int dzHp, int dzWp, int dzC, int dzpad,
                  int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
-                 void* stream);
+                 float* slab, void* stream);
+size_t vpd_op_wgrad_slab_bytes(void);
 /* dumps the ds_read_b64_tr_b16 fragments of one [128][64] bf16 tile: out [4][4][64][8] bf16 */
 int vpd_op_tr_read_probe(const void* tile_bf16, void* out_bf16, void* stream);
 

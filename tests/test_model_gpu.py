@@ -171,8 +171,10 @@ def test_student_matches_reference_and_oracle(path):
     assert rec["grad_mean_excess_err"] <= 0.03 and rec["grad_mean_cos_deficit"] <= 0.03, rec
     assert rec["grad_flat_err"][0] <= 1.15 * rec["grad_flat_err"][1] + 0.01, rec["grad_flat_err"]
     assert abs(traj[0] - float(g["epoch_traj"][0])) <= LOSS_TOL * abs(traj[0])
-    # later steps depend on sign-like Adam updates: loose gate, trajectory must fall alike
-    assert np.allclose(traj, g["epoch_traj"], rtol=0.15), (traj, g["epoch_traj"].tolist())
+    # later steps depend on sign-like Adam updates: the trajectory must fall alike, within 5 % of
+    # the initial loss at every step
+    assert np.max(np.abs(np.asarray(traj) - g["epoch_traj"])) <= 0.05 * float(g["epoch_traj"][0]), \
+        (traj, g["epoch_traj"].tolist())
 
 
 def test_adamw_kernel_injected_grads():

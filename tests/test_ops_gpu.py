@@ -174,13 +174,15 @@ def test_conv_fwd_dgrad_wgrad(case):
 
     # ---- weight gradient ----
     L = _lib()
-    dw = torch.zeros(k * k, co, ci, dtype=torch.float32, device="cuda")
     taps = tapset(k, k, 1 - pad, 1, 1 - pad, 1, 0, k, 1)
-    _check(L.vpd_op_wgrad(ptr(dzp), ptr(xp), ptr(dw), n, ho + 2, wo + 2, co, 1, h + 2, w + 2, ci, ho, wo, stride,
-                          ci, co, taps, stream()))
-    torch.cuda.synchronize()
-    gotdw = dw.cpu().view(k, k, co, ci).permute(2, 3, 0, 1)
-    assert rel_l2(gotdw, wr.grad) < REL_TOL
+    slab = torch.empty(L.vpd_op_wgrad_slab_bytes() // 4, dtype=torch.float32, device="cuda")
+    for use_slab in (False, True):        # generic (atomics) kernel, then the halo + slab kernel where eligible
+        dw = torch.zeros(k * k, co, ci, dtype=torch.float32, device="cuda")
+        _check(L.vpd_op_wgrad(ptr(dzp), ptr(xp), ptr(dw), n, ho + 2, wo + 2, co, 1, h + 2, w + 2, ci, ho, wo, stride,
+                              ci, co, taps, ptr(slab) if use_slab else None, stream()))
+        torch.cuda.synchronize()
+        gotdw = dw.cpu().view(k, k, co, ci).permute(2, 3, 0, 1)
+        assert rel_l2(gotdw, wr.grad) < REL_TOL, use_slab
 
 
 def test_stem_conv_and_wgrad():
@@ -209,7 +211,7 @@ def test_stem_conv_and_wgrad():
     dzd = dz.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
     dw = torch.zeros(7, co, 64, dtype=torch.float32, device="cuda")
     _check(L.vpd_op_wgrad(ptr(dzd), ptr(xp), ptr(dw), n, ho, wo, co, 0, h + 6, w + 8, 8, ho, wo, 2, 64, co, taps,
-                          stream()))
+                          None, stream()))
     torch.cuda.synchronize()
     got = dw.cpu().view(7, co, 8, 8)[:, :, :7, :c].permute(1, 3, 0, 2)   # -> [co][c][r][t]
     assert rel_l2(got, wr.grad) < REL_TOL

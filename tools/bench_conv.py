@@ -40,6 +40,7 @@ for name, ci, co, hw in LAYERS:
     dzp = torch.randn(B * (hw + 2) * (hw + 2) * co, device="cuda").to(torch.bfloat16)
     stats = torch.zeros(64 * 2 * co, device="cuda")
     dw = torch.zeros(9 * co * ci, device="cuda")
+    slab = torch.empty(L.vpd_op_wgrad_slab_bytes() // 4, device="cuda")
     flops = 2.0 * B * hw * hw * co * ci * 9
     taps = tap(3, 3, 0, 1, 0, 1, 0, 3, 1)
 
@@ -49,7 +50,7 @@ for name, ci, co, hw in LAYERS:
 
     def wgrad():
         check(L.vpd_op_wgrad(ptr(dzp), ptr(x), ptr(dw), B, hw + 2, hw + 2, co, 1, hw + 2, hw + 2, ci, hw, hw, 1, ci, co,
-                             taps, st()), "wgrad")
+                             taps, ptr(slab), st()), "wgrad")
 
     t1 = timeit(fwd)
     t2 = timeit(wgrad)

@@ -43,7 +43,8 @@ SIGNATURES = {
     "vpd_plan_read_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
     "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),
     "vpd_op_conv_bm": (C.c_int, [C.c_int, C.c_int]),
-    "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp]),
+    "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp, vp]),
+    "vpd_op_wgrad_slab_bytes": (C.c_size_t, []),
     "vpd_op_tr_read_probe": (C.c_int, [vp, vp, vp]),
 }
 

@@ -204,11 +204,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
     const int pl = threadIdx.x / cv;
     const int c = c8 << 3;
     const int HW = p.H * p.W;
-    float mu[8], rs[8], a1[8], a2[8];
+    float mu[8], rs[8], a1[8], a2[8], msc[8], msh[8];
     *reinterpret_cast<float4*>(mu) = *reinterpret_cast<const float4*>(p.mean + c);
     *reinterpret_cast<float4*>(mu + 4) = *reinterpret_cast<const float4*>(p.mean + c + 4);
     *reinterpret_cast<float4*>(rs) = *reinterpret_cast<const float4*>(p.rstd + c);
     *reinterpret_cast<float4*>(rs + 4) = *reinterpret_cast<const float4*>(p.rstd + c + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { msc[j] = 0.f; msh[j] = 1.f; }
+    if (p.mscale) {
+        *reinterpret_cast<float4*>(msc) = *reinterpret_cast<const float4*>(p.mscale + c);
+        *reinterpret_cast<float4*>(msc + 4) = *reinterpret_cast<const float4*>(p.mscale + c + 4);
+        *reinterpret_cast<float4*>(msh) = *reinterpret_cast<const float4*>(p.mshift + c);
+        *reinterpret_cast<float4*>(msh + 4) = *reinterpret_cast<const float4*>(p.mshift + c + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
     const int mbeg = blockIdx.x * p.ppb;
@@ -229,6 +237,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
                             p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * p.C + c), a);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+            } else if (p.mscale) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -300,6 +311,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
             if (p.write_g) *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * p.C + c) = pack8(g);
+        } else if (p.mscale) {
+            float msc[8], msh[8];
+            *reinterpret_cast<float4*>(msc) = *reinterpret_cast<const float4*>(p.mscale + c);
+            *reinterpret_cast<float4*>(msc + 4) = *reinterpret_cast<const float4*>(p.mscale + c + 4);
+            *reinterpret_cast<float4*>(msh) = *reinterpret_cast<const float4*>(p.mshift + c);
+            *reinterpret_cast<float4*>(msh + 4) = *reinterpret_cast<const float4*>(p.mshift + c + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
         }
 #define LD8(dst, src) \
         *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \

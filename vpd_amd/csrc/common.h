@@ -89,6 +89,7 @@ struct WgradParams {
     const bf16_t* dz; int dzHp, dzWp, dzC, dzpad;
     const bf16_t* x; int xHp, xWp, xC;
     float* dw;                                  // [ntaps][Co][Kc] fp32 (atomically accumulated)
+    float* slab;                                // fp32 scratch for split partials (vpd_wgrad_slab_bytes()) or null
     int N, Hs, Ws, istr;
     int Kc, Co;
     int M;

@@ -15,118 +15,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-
-// Shared epilogue: acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr].
-// Stores bf16 NHWC (8 B per lane), optional eval epilogue (scale/shift/residual/ReLU), optional
-// read-modify-write accumulate, optional per-channel sum / sum-of-squares of the stored values.
-template <int BM, int BN, int WM, int WN>
-static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
-                                                     int mtile, int n0, unsigned char* smem) {
-    constexpr int WTM = BM / WM;
-    constexpr int WTN = BN / WN;
-    constexpr int MI = WTM / 16;
-    constexpr int NI = WTN / 16;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave % WM;
-    const int wn = wave / WM;
-    const int fr = lane & 15;
-    const int fq = lane >> 4;
-    const int m0 = mtile * BM;
-    const int HW = p.Hs * p.Ws;
-    // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
-    float s1[NI][4], s2[NI][4];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
-
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * WTM + b * 16 + fr;
-        const bool valid = m < p.M;
-        const int mc = valid ? m : p.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / p.Ws;
-        const int xx = r - yy * p.Ws;
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + p.oph + p.ypad) * p.yWp +
-                             (xx * p.osub + p.opw + p.ypad)) * p.yC;
-        size_t roff = 0;
-        if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (p.ep_scale) {
-                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                if (p.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
-                    v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
-                    v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
-                }
-                if (p.ep_relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-                }
-            }
-            bf16_t* dst = p.y + yoff + n;
-            if (p.accumulate && valid) {
-                const uint2 ov = *reinterpret_cast<const uint2*>(dst);
-                v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
-                v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
-            }
-            uint2 ov;
-            ov.x = pack2bf(v[0], v[1]);
-            ov.y = pack2bf(v[2], v[3]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(dst) = ov;
-                // statistics are taken over the bf16-rounded values actually stored
-                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
-                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
-                s1[a][0] += q0; s2[a][0] += q0 * q0;
-                s1[a][1] += q1; s2[a][1] += q1 * q1;
-                s1[a][2] += q2; s2[a][2] += q2 * q2;
-                s1[a][3] += q3; s2[a][3] += q3 * q3;
-            }
-        }
-    }
-
-    if (p.stats) {
-        // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
-        float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float u = s1[a][j], v = s2[a][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    u += __shfl_xor(u, o, 64);
-                    v += __shfl_xor(v, o, 64);
-                }
-                if (fr == 0) {
-                    const int c = wn * WTN + a * 16 + 4 * fq + j;
-                    red[(wm * 2 + 0) * BN + c] = u;
-                    red[(wm * 2 + 1) * BN + c] = v;
-                }
-            }
-        __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN;
-            const int c = tid - which * BN;
-            float t = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
-            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
-            atomicAdd(&p.stats[((size_t)(mtile & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
-        }
-    }
-}
+#include "conv_epilogue.h"
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
@@ -391,6 +280,164 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
     conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
 }
 
+// ---------------------------------------------------------------------------
+// Warp-specialised 3x3 stride-1 convolution (forward and data-gradient): 8 waves per block.
+//   waves 4..7 (loaders): all LDS-DMA.  Per K-step s they issue the weight tile of step s+2 into a
+//       3-stage ring and one eighth of the NEXT 64-channel chunk's halo into the other halo buffer, a
+//       fixed number of instructions per step so that one counted s_waitcnt vmcnt(PER_STEP) per step
+//       retires exactly "everything except the bundle issued one step ago".
+//   waves 0..3 (MFMA): only ds_read_b128 + MFMA; wave tile 64 channels x BM/WM pixels.
+// One barrier per step: READY_s = weights of step s (and at chunk boundaries the halo) have landed;
+// since the MFMA waves only arrive after finishing step s-1 it also frees ring stage (s+2)%3.
+// 256-pixel tiles halve the weight bytes streamed per FLOP with respect to the 128-pixel kernels.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int HROWS>
+__global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
+    constexpr int WN = BN / 64;
+    constexpr int WM = 4 / WN;
+    constexpr int WTM = BM / WM;
+    constexpr int MI = WTM / 16, NI = 4;
+    constexpr int NS = 3;
+    constexpr int WSTAGE = BN * 64;
+    constexpr int HBUF = HROWS * 64;
+    constexpr int W_PER = BN / 32;                   // weight-tile DMA instructions per loader wave per step
+    constexpr int HPASS = HROWS / 32;                // halo DMA instructions per loader wave per chunk
+    constexpr int H_PER = (HPASS + 7) / 8;           // ... spread over steps 0..7 of the previous chunk
+    constexpr int PER_STEP = W_PER + H_PER;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [2][HBUF]
+    bf16_t* sW = sH + 2 * HBUF;                                   // [NS][WSTAGE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtile = blockIdx.x;
+    const int n0 = blockIdx.y * BN;
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int Ci = p.Kc;
+    const int nchunks = Ci >> 6;
+    const int nsteps = nchunks * 9;
+
+    if (wave >= 4) {
+        // ------------------------------ loader waves ------------------------------
+        const int lw = wave - 4;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        const int gr0 = mtile * g.TR;
+        int prow0;
+        if (g.multi) prow0 = (gr0 / H) * (H + 2);
+        else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+        const int gp0 = prow0 * Wp;
+        auto halo_instr = [&](int cc, int k) __attribute__((always_inline)) {      // pass k of chunk cc
+            const int hp = (lw + 4 * k) * 8 + lrow;
+            int gp = gp0 + hp;
+            gp = gp < g.total_pix ? gp : g.total_pix - 1;
+            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ (hp & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (cc & 1) * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
+        };
+        auto issue_w = [&](int step, int stage) __attribute__((always_inline)) {
+            const int cc = step / 9;
+            const int tap = step - cc * 9;
+            const int ir = tap / 3, ic = tap - ir * 3;
+            const int wsl = p.taps.w0 + ir * p.taps.wrs + ic * p.taps.wcs;
+            const bf16_t* wbp = p.w + ((size_t)wsl * p.Co + n0) * Ci + cc * 64;
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i) {
+                const int n = (lw + 4 * i) * 8 + lrow;
+                const bf16_t* src = wbp + (size_t)n * Ci + ((piece ^ (n & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + stage * WSTAGE + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < HPASS; ++k) halo_instr(0, k);
+        issue_w(0, 0);
+        issue_w(nsteps > 1 ? 1 : 0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < nsteps; ++s) {
+            if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+            __builtin_amdgcn_s_barrier();                         // READY_s
+            const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;   // tail: harmless reload into a free stage
+            issue_w(sw, (s + 2) % NS);
+            const int cc = s / 9;
+            const int tap = s - cc * 9;
+            // next chunk's halo, slice `tap`; on the last chunk (and in slice 8) re-load identical bytes
+            const int hc = cc + 1 < nchunks ? cc + 1 : cc;
+#pragma unroll
+            for (int u = 0; u < H_PER; ++u) {
+                int k = tap * H_PER + u;
+                k = k < HPASS ? k : HPASS - 1;
+                halo_instr(hc, k);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
+        __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
+        if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_epilogue
+        return;
+    }
+
+    // ------------------------------ MFMA waves ------------------------------
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    int hbase[MI];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = wm * WTM + b * 16 + fr;
+        const int lr = m / W;
+        const int xx = m - lr * W;
+        const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+        hbase[b] = hrow * Wp + xx;
+    }
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int s = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const bf16_t* cH = sH + (cc & 1) * HBUF;
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            __builtin_amdgcn_s_barrier();                         // READY_s
+            const int ir = tap / 3, ic = tap - ir * 3;
+            const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
+            const bf16_t* cW = sW + (s % NS) * WSTAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfm[MI];
+                const int chunk = kk * 4 + fq;
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int r = wn * 64 + a * 16 + fr;
+                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int r = hbase[b] + toff;
+                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                                 // END
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+}
+
+template <int BM, int BN, int HROWS>
+static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    const size_t lds = ((size_t)2 * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS>), grid, dim3(512), lds, stream, p, g);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int HROWS, bool HALO2>
 static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
@@ -441,14 +488,16 @@ extern "C" int vpd_conv_bm(int M, int Co) {
 }
 
 // Kernel selection.  Classes (also the timing classes of vpd_plan_read_timing):
-//   0 conv3x3_halo<128,64>  1 conv3x3_halo<128,128>  2 conv3x3_halo<64,128>  3 conv_igemm (gather; any tile)
+//   0 conv3x3_ws<256,64>  1 conv3x3_ws<256,128>  2 conv3x3_ws<128,128>  3 every other conv kernel
+//   (conv3x3_halo<128,64> for shapes the ws tiles do not fit, conv_igemm gather kernel)
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
-    const int bm = vpd_conv_bm(p.M, p.Co);
-    if (halo_eligible(p)) {
+    static const int no_ws = getenv("VPD_NO_WS") ? atoi(getenv("VPD_NO_WS")) : 0;
+    if (halo_eligible(p) && !no_ws) {
         if (p.Co % 128 == 0) {
-            if (bm == 128 && halo_geom(p, 128, 224, g)) return 1;
-            if (halo_geom(p, 64, 160, g)) return 2;
-        } else if (halo_geom(p, 128, 224, g)) {
+            const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
+            if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
+            if (halo_geom(p, 128, 288, g)) return 2;
+        } else if (halo_geom(p, 256, 352, g)) {
             return 0;
         }
     }
@@ -463,14 +512,23 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
-        case 0: return launch_halo<128, 64, 224, false>(p, g, stream);
-        case 1: return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)
-                                  : launch_halo<128, 128, 224, false>(p, g, stream);
-        case 2: return launch_halo<64, 128, 160, true>(p, g, stream);
+        case 0: return launch_ws<256, 64, 352>(p, g, stream);
+        case 1: return launch_ws<256, 128, 352>(p, g, stream);
+        case 2: return launch_ws<128, 128, 288>(p, g, stream);
         default: break;
     }
     // the statistics accumulator rows only depend on the block index, so the tile choice is free
     const int bm = vpd_conv_bm(p.M, p.Co);
+    if (halo_eligible(p)) {
+        if (p.Co % 128 == 0) {
+            if (bm == 128 && halo_geom(p, 128, 224, &g))
+                return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)
+                                  : launch_halo<128, 128, 224, false>(p, g, stream);
+            if (halo_geom(p, 64, 160, &g)) return launch_halo<64, 128, 160, true>(p, g, stream);
+        } else if (halo_geom(p, 128, 224, &g)) {
+            return launch_halo<128, 64, 224, false>(p, g, stream);
+        }
+    }
     if (p.Co % 128 == 0) {
         if (bm == 128) return launch_cfg<128, 128, 2, 2>(p, stream);
         return launch_cfg<64, 64, 2, 2>(p, stream);

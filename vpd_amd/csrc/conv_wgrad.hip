@@ -13,6 +13,8 @@
 // 128-pixel chunks; the 4 waves split every chunk's pixels (32 each) and their
 // 64x64 partial tiles are summed through LDS before one fp32 atomic per
 // element.
+#include <stdlib.h>
+
 #include "common.h"
 
 static __device__ __forceinline__ int wg_swz(int r, int c16) {
@@ -157,9 +159,272 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
     }
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient, halo form (the bulk of the network).
+//
+// One block owns a 64(co) x 64(ci) tile for ALL NINE taps over a range of 64-pixel chunks (whole image
+// rows; two MFMA K-steps).  Per chunk the dz tile [64 px][64 co] and the x halo
+// [NHP px][64 ci] are brought to LDS by LDS-DMA (global_load_lds) issued by four dedicated LOADER waves
+// into a 3-stage ring, two chunks ahead (counted vmcnt), while the four MFMA waves (one per SIMD)
+// consume the current stage: wave w owns ci columns 16w..16w+15, keeps 9 taps x 4 co-tiles of
+// accumulators (144 VGPRs) and reads every operand with ds_read_b64_tr_b16 at 44 chunk-invariant,
+// precomputed swizzled offsets.  The x halo is loaded once and serves all nine taps (139 FLOP per
+// staged byte instead of 32).  One barrier per chunk: READY_c = "chunk c has landed" and, because the
+// MFMA waves only arrive after finishing chunk c-1, also "the stage of chunk c-1 is free".  Partial
+// tiles go to an fp32 slab with plain stores (slab[split][tap][Co][Ci]); wgrad_slab_reduce_kernel sums
+// the splits.
+// ---------------------------------------------------------------------------
+struct WgHaloGeom {
+    int TR, multi, HR, NHP, total_pix;   // halo tiling of a 128-pixel chunk (as HaloGeom in conv_igemm.hip)
+    int ksplit, cpb;                     // pixel-chunk splits and chunks per block
+};
+
+typedef const void __attribute__((address_space(1)))* wg_gptr_t;
+typedef void __attribute__((address_space(3)))* wg_lptr_t;
+
+static __device__ __forceinline__ int wg_f(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+
+// MFMA operand (K on LDS rows) from two explicit 4-row blocks: row ra (k = 8g+q) and row rb (k = 8g+4+q)
+static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, int rb, int ctile, int pp) {
+    const int col = ctile * 16 + 4 * pp;
+    const int o0 = ra * 64 + ((((col >> 4) ^ wg_f(ra)) << 4) | (col & 15));
+    const int o1 = rb * 64 + ((((col >> 4) ^ wg_f(rb)) << 4) | (col & 15));
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + o0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + o1));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define WG_CH 64           // pixels per chunk = two MFMA K-steps
+#define WG_NS 3            // ring stages
+
+// NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS)
+template <int NPASS>
+__global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
+    constexpr int HROWS = 32 * NPASS;
+    constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile then halo
+    constexpr int PER_CHUNK = 2 + NPASS;                          // LDS-DMA instructions per loader wave per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);               // [WG_NS][dz 64x64 | halo HROWSx64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..3 MFMA waves, 4..7 loader waves
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int kct = p.Kc >> 6;
+    const int co0 = (blockIdx.x / kct) * 64;
+    const int ci0 = (blockIdx.x % kct) * 64;
+    const int nchunks_total = (p.M + WG_CH - 1) / WG_CH;
+    const int chunk_begin = blockIdx.y * g.cpb;
+    int chunk_end = chunk_begin + g.cpb;
+    chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
+    const int nch = chunk_end - chunk_begin;                      // >= 1 by construction of ksplit
+
+    if (wave >= 4) {
+        // ------------------------- loader waves -------------------------
+        const int lw = wave - 4;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;                               // row within an 8-row wave instruction
+        auto issue = [&](int c) __attribute__((always_inline)) {
+            const int ch = chunk_begin + c;
+            bf16_t* st = ring + (c % WG_NS) * STAGE;
+            // dz tile: 8 wave-instructions of 8 pixel rows; two per loader wave
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lw + 4 * i) * 8 + lrow;
+                const int m = ch * WG_CH + row;
+                const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+                const bf16_t* src = p.dz + cpc * 8;               // zero border row of image 0: contributes nothing
+                if (m < p.M) {
+                    const int b = m / (H * W);
+                    const int r = m - b * H * W;
+                    const int yy = r / W;
+                    const int xx = r - yy * W;
+                    src = p.dz + ((size_t)(b * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cpc * 8;
+                }
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+            // x halo: 4*NPASS wave-instructions; NPASS per loader wave
+            const int gr0 = ch * g.TR;
+            int prow0;
+            if (g.multi) prow0 = (gr0 / H) * (H + 2);
+            else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+            const int gp0 = prow0 * Wp;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int hp = (lw + 4 * i) * 8 + lrow;
+                int gp = gp0 + hp;
+                gp = gp < g.total_pix ? gp : g.total_pix - 1;
+                const int cpc = (((piece >> 1) ^ wg_f(hp)) << 1) | (piece & 1);
+                const bf16_t* src = p.x + (size_t)gp * p.xC + ci0 + cpc * 8;
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + WG_CH * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nch > 1) issue(1);
+        for (int c = 0; c < nch; ++c) {
+            // chunk c has landed when at most the instructions of chunk c+1 are still outstanding
+            if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // READY_c (MFMA waves have finished chunk c-1)
+            if (c + 2 < nch) issue(c + 2);                        // into the stage chunk c-1 used
+        }
+        return;
+    }
+
+    // ------------------------- MFMA waves -------------------------
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    // chunk-invariant LDS element offsets (within a stage) of every transposed read of this lane.
+    // dz rows are 32*ks + 8*gq + 4*h + q: the swizzle only looks at row bits 1 and 3, so k-step 1 is +32 rows.
+    int offA[4][2], offB[2][9][2];
+    {
+        const int ra = 8 * gq + q;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = ra + 4 * h;
+                const int col = a * 16 + 4 * pp;
+                offA[a][h] = r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pk = 32 * ks + 8 * gq + 4 * h + q;      // pixel of the chunk this lane addresses
+                const int lr = pk / W;
+                const int xx = pk - lr * W;
+                const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+                const int hmv = hrow * Wp + xx;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = hmv + (p.taps.dy0 + (t / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (t % 3) * p.taps.dxs);
+                    const int col = wave * 16 + 4 * pp;
+                    offB[ks][t][h] = WG_CH * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+                }
+            }
+    }
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    auto frag = [&](const bf16_t* st, int o0, int o1) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o1));
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    for (int c = 0; c < nch; ++c) {
+        __builtin_amdgcn_s_barrier();                             // READY_c
+        const bf16_t* st = ring + (c % WG_NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 az[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) az[a] = frag(st + ks * 32 * 64, offA[a][0], offA[a][1]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const bf16x8 bx = frag(st, offB[ks][t][0], offB[ks][t][1]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx, acc[t][a], 0, 0, 0);
+            }
+        }
+    }
+
+    // acc[t][a][j] = partial dW[tap t][co0 + a*16 + 4*gq + j][ci0 + 16*wave + i16]
+    float* slab = p.slab + (size_t)blockIdx.y * 9 * p.Co * p.Kc;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
+        float* o = slab + ((size_t)wsl * p.Co + co0) * p.Kc + ci0 + 16 * wave + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
+    }
+}
+
+// dw[e] = sum over all splits of slab[split][e].  A block owns 64 float4 outputs; its `groups` thread
+// groups each sum every groups-th split (coalesced 1-KiB rows), then one LDS pass adds the groups.
+__global__ __launch_bounds__(1024) void wgrad_slab_reduce_kernel(const float4* slab, float4* dw, long n4, int ksplit,
+                                                                 int groups) {
+    __shared__ float4 sh[16][64];
+    const int o = threadIdx.x & 63, gi = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + o;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int s = gi; s < ksplit; s += groups) {
+            const float4 v = slab[(long)s * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    sh[gi][o] = a;
+    __syncthreads();
+    if (gi == 0 && i < n4) {
+        for (int k = 1; k < groups; ++k) {
+            const float4 v = sh[k][o];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        dw[i] = a;
+    }
+}
+
+static bool wg_halo_geom(const WgradParams& p, WgHaloGeom* g) {
+    const int W = p.Ws, H = p.Hs;
+    if (WG_CH % W != 0) return false;
+    const int TR = WG_CH / W;
+    if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
+    else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
+    g->TR = TR;
+    g->NHP = g->HR * (W + 2);
+    g->total_pix = p.N * (H + 2) * (W + 2);
+    return g->NHP <= 160;
+}
+
+// true when vpd_launch_wgrad will take the halo + slab path, which OVERWRITES dw (no pre-zeroing needed)
+bool vpd_wgrad_overwrites(const WgradParams& p) {
+    static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
+    WgHaloGeom g;
+    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && p.istr == 1 && p.xC == p.Kc && p.xHp == p.Hs + 2 &&
+           p.xWp == p.Ws + 2 && p.taps.dy0 >= 0 && p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
+           p.taps.dy0 + 2 * p.taps.dys <= 2 && p.taps.dx0 >= 0 && p.taps.dx0 + 2 * p.taps.dxs >= 0 && p.taps.dx0 <= 2 &&
+           p.taps.dx0 + 2 * p.taps.dxs <= 2 && wg_halo_geom(p, &g);
+}
+
+size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float); }   // ksplit * tiles <= 256
+
 hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     WgradParams p = p0;
+    WgHaloGeom g;
+    if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
+        const int tiles = (p.Co / 64) * (p.Kc / 64);
+        const int nchunks = (p.M + WG_CH - 1) / WG_CH;
+        int ksplit = 256 / tiles;
+        if (ksplit < 1) ksplit = 1;
+        if (ksplit > nchunks) ksplit = nchunks;
+        g.cpb = (nchunks + ksplit - 1) / ksplit;
+        g.ksplit = (nchunks + g.cpb - 1) / g.cpb;
+        const int npass = (g.NHP + 31) / 32;            // 3..5
+        const size_t lds = (size_t)WG_NS * (WG_CH + 32 * npass) * 64 * sizeof(bf16_t);
+        if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
+        else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
+        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
+        const long n4 = (long)9 * p.Co * p.Kc / 4;
+        const int groups = g.ksplit < 16 ? g.ksplit : 16;
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
+                           (const float4*)p.slab, (float4*)p.dw, n4, g.ksplit, groups);
+        return hipGetLastError();
+    }
     const int tiles = (p.Co / 64) * (p.Kc / 64) * p.taps.nr * p.taps.nc;
     const int nchunks = (p.M + 127) / 128;
     // aim for ~1024 blocks; at least 4 chunks per block to amortise the atomics

@@ -30,6 +30,7 @@ struct BnBwdParams {
     float* partials;                    // [T][2][C] scratch
     bf16_t* dz; int dzHp, dzWp, dzpad;  // output (padded or dense)
     int M, H, W, C, write_g, ppb;
+    const float* mscale; const float* mshift;   // when act == null and these are set: ReLU mask = (mscale*z + mshift > 0)
 };
 
 struct StemPoolBwdParams {
@@ -54,6 +55,8 @@ hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..3, see conv_igemm.hip
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
+size_t vpd_wgrad_slab_bytes();
+bool vpd_wgrad_overwrites(const WgradParams& p);
 
 hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,

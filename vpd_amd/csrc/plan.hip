@@ -91,7 +91,7 @@ struct vpd_plan {
     // workspace offsets (bytes)
     size_t ws_bytes = 0;
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
-    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0};
+    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, slab_off = 0;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
@@ -327,6 +327,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             S.dzd_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
+        p->slab_off = bp.take(vpd_wgrad_slab_bytes());
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
@@ -411,7 +412,7 @@ struct Ctx {
     float* bn_eshift(const BnInfo& b) const { return f32(b.fl_off) + 8 * b.C; }
 };
 
-// timing classes: 0..3 = vpd_conv_kernel_class (halo<128,64>, halo<128,128>, halo<64,128>, gather igemm), 4 = wgrad
+// timing classes: 0..3 = vpd_conv_kernel_class (ws<256,64>, ws<256,128>, ws<128,128>, other), 4 = wgrad
 struct TimeScope {
     vpd_plan* p; hipStream_t s; int idx = -1;
     TimeScope(vpd_plan* p_, hipStream_t s_, int cls, double flops) : p(p_), s(s_) {
@@ -514,9 +515,14 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.dw = c.f32(c.p->wg_off) + cv.wg_off;
+    q.slab = c.f32(c.p->slab_off);
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
+    if (!vpd_wgrad_overwrites(q)) {      // the generic kernel accumulates with atomics: zero its range first
+        hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, c.s);
+        if (e != hipSuccess) return e;
+    }
     TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
     return vpd_launch_wgrad(q, c.s);
 }
@@ -533,8 +539,10 @@ hipError_t run_bn_apply(const Ctx& c, const ConvInfo& cv, int res_kind, const bf
     return vpd_launch_bn_apply(a, c.s);
 }
 
+// act != null: ReLU mask from the stored activation (needed when a residual was added before the ReLU);
+// relu_from_z: mask recomputed as scale*z + shift > 0 (plain conv-BN-ReLU), which saves reading the activation
 hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
-                      int write_g, float* grads) {
+                      int write_g, float* grads, bool relu_from_z = false) {
     BnBwdParams b;
     memset(&b, 0, sizeof b);
     b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
@@ -543,6 +551,7 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     b.partials = c.f32(c.p->partial_off);
     b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
+    if (relu_from_z) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
     return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s);
 }
 
@@ -695,7 +704,6 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
-    LCHECK(hipMemsetAsync(ws + p->wg_off, 0, (size_t)p->wg_elems * 4, s));
     LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes, s));
 
     // ---- head ----
@@ -749,7 +757,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
         LCHECK(run_conv_wgrad(c, B.c2, dz2, 1, c.b16(B.a1_off)));
         LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
-        LCHECK(run_bn_bwd(c, B.c1, da1, c.b16(B.a1_off), dz1, 1, 0, grads));
+        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
         LCHECK(run_conv_wgrad(c, B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);
@@ -850,6 +858,7 @@ extern "C" int vpd_graph_launch_eval(vpd_plan_t* p, int n, void* stream) {
 // single-operator entry points for the parity tests
 // ---------------------------------------------------------------------------
 extern "C" int vpd_op_conv_bm(int M, int Co) { return vpd_conv_bm(M, Co); }
+extern "C" size_t vpd_op_wgrad_slab_bytes(void) { return vpd_wgrad_slab_bytes(); }
 
 static TapSet tapset_from(const int* t) {
     TapSet ts;
@@ -875,11 +884,11 @@ extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, float* stats
 
 extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int dzHp, int dzWp, int dzC, int dzpad,
                             int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
-                            void* stream) {
+                            float* slab, void* stream) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = (const bf16_t*)dz; q.dzHp = dzHp; q.dzWp = dzWp; q.dzC = dzC; q.dzpad = dzpad;
-    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.dw = dw;
+    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.dw = dw; q.slab = slab;
     q.N = n; q.Hs = Hs; q.Ws = Ws; q.istr = istr; q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws;
     q.taps = tapset_from(tapset9);
     if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
