@@ -106,7 +106,7 @@ int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 
 /* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
- * bracketed by HIP events on its own stream.  Classes (forward + data-gradient convs): 0 conv3x3_ws<256,64>,
+ * bracketed by HIP events on its own stream.  Classes (forward + data-gradient convs): 0 conv3x3_ws<128,64>,
  * 1 conv3x3_ws<256,128>, 2 conv3x3_ws<128,128>, 3 every other conv kernel (gather igemm; the parity-class launches
  * of a stride-2 dgrad count as one launch); 4 weight-gradient kernels (+ their slab reduce).  vpd_plan_read_timing (nclasses >= 5) waits for the
  * events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
@@ -117,8 +117,8 @@ int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
 /* One implicit-GEMM conv launch on padded-NHWC bf16 tensors (forward conv or data-gradient conv).
  * tapset9 = {nr, nc, dy0, dys, dx0, dxs, w0, wrs, wcs}: tap (ir,ic) gathers input pixel
  * (y*istr + dy0 + ir*dys, x*istr + dx0 + ic*dxs) in padded coordinates and uses weight slice
- * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional, pre-zeroed): [64][2][Co] accumulator
- * rows (block b adds its per-channel sum / sum of squares into row b % 64). */
+ * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional, pre-zeroed): [16][2][Co] accumulator
+ * rows (block b adds its per-channel sum / sum of squares into row b % 16). */
 int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, float* stats, int n, int xHp, int xWp,
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);

@@ -18,13 +18,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = g; t < T; t += 4) {
+    if (c < C) {
+        // T == VPD_STAT_ROWS == 16: four rows per thread group, all eight loads in flight at once
+        float v1[4], v2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = g + 4 * k;
             float* q = partials + ((size_t)t * 2) * C + c;
-            s1 += (double)q[0];
-            s2 += (double)q[C];
-            q[0] = 0.f; q[C] = 0.f;          // leave the accumulator rows zeroed for the next producer
+            v1[k] = t < T ? q[0] : 0.f;
+            v2[k] = t < T ? q[C] : 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = g + 4 * k;
+            if (t < T) {
+                float* q = partials + ((size_t)t * 2) * C + c;
+                q[0] = 0.f; q[C] = 0.f;      // leave the accumulator rows zeroed for the next producer
+            }
+            s1 += (double)v1[k];
+            s2 += (double)v2[k];
+        }
+    }
     sh[0][g][cl] = s1; sh[1][g][cl] = s2;
     __syncthreads();
     if (g == 0 && c < C) {
@@ -269,13 +283,27 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = g; t < T; t += 4) {
+    if (c < C) {
+        // T == VPD_STAT_ROWS == 16: four rows per thread group, all eight loads in flight at once
+        float v1[4], v2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = g + 4 * k;
             float* q = partials + ((size_t)t * 2) * C + c;
-            s1 += (double)q[0];
-            s2 += (double)q[C];
-            q[0] = 0.f; q[C] = 0.f;
+            v1[k] = t < T ? q[0] : 0.f;
+            v2[k] = t < T ? q[C] : 0.f;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = g + 4 * k;
+            if (t < T) {
+                float* q = partials + ((size_t)t * 2) * C + c;
+                q[0] = 0.f; q[C] = 0.f;
+            }
+            s1 += (double)v1[k];
+            s2 += (double)v2[k];
+        }
+    }
     sh[0][g][cl] = s1; sh[1][g][cl] = s2;
     __syncthreads();
     if (g == 0 && c < C) {

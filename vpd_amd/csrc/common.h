@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VPD_WAVE 64
 // per-channel statistics are accumulated into this many [2][C] fp32 rows (row = producer block % rows)
-#define VPD_STAT_ROWS 64
+#define VPD_STAT_ROWS 16
 
 static __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);

@@ -358,6 +358,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
             if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
             __builtin_amdgcn_s_barrier();                         // READY_s
             const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;   // tail: harmless reload into a free stage
+            if (p.ablate & 1) continue;
             issue_w(sw, (s + 2) % NS);
             const int cc = s / 9;
             const int tap = s - cc * 9;
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
         const bf16_t* cH = sH + (cc & 1) * HBUF;
         for (int tap = 0; tap < 9; ++tap, ++s) {
             __builtin_amdgcn_s_barrier();                         // READY_s
+            if (p.ablate & 2) continue;
             const int ir = tap / 3, ic = tap - ir * 3;
             const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
             const bf16_t* cW = sW + (s % NS) * WSTAGE;
@@ -488,17 +490,16 @@ extern "C" int vpd_conv_bm(int M, int Co) {
 }
 
 // Kernel selection.  Classes (also the timing classes of vpd_plan_read_timing):
-//   0 conv3x3_ws<256,64>  1 conv3x3_ws<256,128>  2 conv3x3_ws<128,128>  3 every other conv kernel
+//   0 conv3x3_ws<128,64>  1 conv3x3_ws<256,128>  2 conv3x3_ws<128,128>  3 every other conv kernel
 //   (conv3x3_halo<128,64> for shapes the ws tiles do not fit, conv_igemm gather kernel)
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
     static const int no_ws = getenv("VPD_NO_WS") ? atoi(getenv("VPD_NO_WS")) : 0;
     if (halo_eligible(p) && !no_ws) {
         if (p.Co % 128 == 0) {
             const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
+            const long t128 = (long)((p.M + 127) / 128) * (p.Co / 128);
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
-            if (halo_geom(p, 128, 288, g)) return 2;
-        } else if (halo_geom(p, 256, 352, g)) {
-            return 0;
+            if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 0;    // few pixel tiles: 64-channel tiles fill the chip
         }
     }
     return 3;
@@ -512,7 +513,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
-        case 0: return launch_ws<256, 64, 352>(p, g, stream);
+        case 0: return launch_ws<128, 64, 288>(p, g, stream);
         case 1: return launch_ws<256, 128, 352>(p, g, stream);
         case 2: return launch_ws<128, 128, 288>(p, g, stream);
         default: break;

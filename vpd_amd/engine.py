@@ -252,7 +252,7 @@ class StudentEngine:
     def read_timing(self, pl):
         out = (C.c_double * 15)()
         check(lib().vpd_plan_read_timing(pl.handle, out, 5), "vpd_plan_read_timing")
-        names = ["conv3x3_ws_kernel<256,64>", "conv3x3_ws_kernel<256,128>", "conv3x3_ws_kernel<128,128>",
+        names = ["conv3x3_ws_kernel<128,64>", "conv3x3_ws_kernel<256,128>", "conv3x3_ws_kernel<128,128>",
                  "conv_other (igemm gather / halo<128,64>)", "conv_wgrad_halo_kernel (+slab reduce; incl. generic wgrad)"]
         return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(5)}
 
