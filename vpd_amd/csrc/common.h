@@ -62,6 +62,18 @@ struct TapSet {
     int w0, wrs, wcs;
 };
 
+// Optional fused BatchNorm finalize: the LAST block of the producing kernel (ticket counter) turns the
+// statistics accumulator rows into mean / rstd / scale / shift and updates the running statistics,
+// instead of a separate dependent launch.  counter == null disables it.
+struct BnFin {
+    unsigned* counter;                          // zero between launches (the last block resets it)
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;    // may be null
+    float* mean; float* rstd; float* scale; float* shift;
+    float count, momentum, eps;
+    int nblocks;
+};
+
 // One implicit-GEMM convolution launch (forward conv, or data-gradient conv).
 // Output pixels are enumerated on a sub-grid (Hs x Ws per image); output pixel
 // (y, x) of the sub-grid lands at (y*osub+oph, x*osub+opw) of tensor Y and
@@ -82,7 +94,21 @@ struct ConvParams {
     int accumulate;                             // y += result
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
+    BnFin fin;                                  // fused finalize of `stats` (forward, train mode)
 };
+
+// Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the
+// bucket-level reduce so both agree on the number of slabs without a host->device hand-off.
+static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, int Kc, int* cpb_out) {
+    const int tiles = (Co / 64) * (Kc / 64);
+    const int nchunks = (M + 63) / 64;
+    int ksplit = 256 / tiles;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > nchunks) ksplit = nchunks;
+    const int cpb = (nchunks + ksplit - 1) / ksplit;
+    if (cpb_out) *cpb_out = cpb;
+    return (nchunks + cpb - 1) / cpb;
+}
 
 // One weight-gradient launch: dw[tap][co][kc] += sum_m dz[m][co] * x[gather(m,tap)][kc]
 struct WgradParams {
@@ -90,6 +116,7 @@ struct WgradParams {
     const bf16_t* x; int xHp, xWp, xC;
     float* dw;                                  // [ntaps][Co][Kc] fp32 (atomically accumulated)
     float* slab;                                // fp32 scratch for split partials (vpd_wgrad_slab_bytes()) or null
+    int defer_reduce;                           // leave the partials in the slab (a later bucket-level kernel sums them)
     int N, Hs, Ws, istr;
     int Kc, Co;
     int M;

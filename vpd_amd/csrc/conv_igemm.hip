@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         __syncthreads();
     }
     conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    conv_finalize_tail(p, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
     }
     __syncthreads();                               // LDS is reused by the statistics reduction
     conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    conv_finalize_tail(p, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
         __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
         if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_epilogue
+        conv_finalize_tail(p, smem);                              // barriers inside: all 8 waves take part
         return;
     }
 
@@ -430,13 +433,16 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
     }
     __builtin_amdgcn_s_barrier();                                 // END
     conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    conv_finalize_tail(p, smem);
 }
 
 template <int BM, int BN, int HROWS>
 static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
     const size_t lds = ((size_t)2 * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS>), grid, dim3(512), lds, stream, p, g);
+    ConvParams q = p;
+    q.fin.nblocks = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS>), grid, dim3(512), lds, stream, q, g);
     return hipGetLastError();
 }
 
@@ -446,7 +452,9 @@ static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_
     size_t lds = ((size_t)(HALO2 ? 2 : 1) * HROWS + 2 * BN) * 64 * sizeof(bf16_t);
     const size_t red = (size_t)2 * 2 * BN * sizeof(float);
     if (lds < red) lds = red;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, p, g);
+    ConvParams q = p;
+    q.fin.nblocks = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, q, g);
     return hipGetLastError();
 }
 
@@ -475,7 +483,9 @@ template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
     const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, stream, p);
+    ConvParams q = p;
+    q.fin.nblocks = (int)(grid.x * grid.y);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, stream, q);
     return hipGetLastError();
 }
 

@@ -198,7 +198,7 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
-#define WG_CH 64           // pixels per chunk = two MFMA K-steps
+#define WG_CH 64           // pixels per chunk = two MFMA K-steps (vpd_wgrad_split assumes 64)
 #define WG_NS 3            // ring stages
 
 // NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS)
@@ -390,6 +390,17 @@ static bool wg_halo_geom(const WgradParams& p, WgHaloGeom* g) {
     return g->NHP <= 160;
 }
 
+// shape test of the halo kernel for a 3x3 stride-1 conv with Hout x Wout outputs (independent of the batch size)
+bool vpd_wgrad_halo_shape_ok(int H, int W) {
+    static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
+    if (force_v1 || W <= 0 || WG_CH % W != 0) return false;
+    const int TR = WG_CH / W;
+    int HR;
+    if (TR <= H) { if (H % TR != 0) return false; HR = TR + 2; }
+    else { if (TR % H != 0) return false; HR = (TR / H) * (H + 2); }
+    return HR * (W + 2) <= 160;
+}
+
 // true when vpd_launch_wgrad will take the halo + slab path, which OVERWRITES dw (no pre-zeroing needed)
 bool vpd_wgrad_overwrites(const WgradParams& p) {
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
@@ -408,17 +419,13 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     WgHaloGeom g;
     if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
         const int tiles = (p.Co / 64) * (p.Kc / 64);
-        const int nchunks = (p.M + WG_CH - 1) / WG_CH;
-        int ksplit = 256 / tiles;
-        if (ksplit < 1) ksplit = 1;
-        if (ksplit > nchunks) ksplit = nchunks;
-        g.cpb = (nchunks + ksplit - 1) / ksplit;
-        g.ksplit = (nchunks + g.cpb - 1) / g.cpb;
+        g.ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, &g.cpb);
         const int npass = (g.NHP + 31) / 32;            // 3..5
         const size_t lds = (size_t)WG_NS * (WG_CH + 32 * npass) * 64 * sizeof(bf16_t);
         if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
         else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
         else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
+        if (p.defer_reduce) return hipGetLastError();
         const long n4 = (long)9 * p.Co * p.Kc / 4;
         const int groups = g.ksplit < 16 ? g.ksplit : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,

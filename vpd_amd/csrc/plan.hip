@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -50,6 +51,7 @@ struct ConvInfo {
     long long w_off = 0;                 // OIHW offset in flat params/grads
     long long fwd_off = 0, dgr_off = -1; // bf16 element offsets in the weight arena
     long long wg_off = 0;                // fp32 element offset in the wgrad scratch
+    long long slab_off = -1;             // fp32 element offset of this conv's split slabs (3x3 s1 convs) or -1
     BnInfo bn;
     size_t z_off = 0;                    // dense bf16 conv output (train)
 };
@@ -61,7 +63,7 @@ struct BlockInfo {
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
-    size_t dz2_off = 0, dz1_off = 0, dzd_off = 0, idn_off = 0;
+    size_t dz2_off[2] = {0, 0}, dz1_off[2] = {0, 0}, dzd_off = 0, idn_off = 0;   // dz buffers ping-pong by block parity
 };
 struct TensorRow {
     int kind, is_dec;
@@ -85,13 +87,15 @@ struct vpd_plan {
     std::vector<TensorRow> tensors;
     std::vector<BnInfo*> bns;
     long long nparam = 0, nparam_padded = 0, nbn = 0;
-    long long arena_elems = 0, wg_elems = 0;
+    long long arena_elems = 0, wg_elems = 0, slab_elems = 0;
     // gradient buckets (flat-buffer ranges) -- bucket 0 = layer4+fc+decoder ... bucket 3 = stem+layer1
     long long bucket_off[4], bucket_numel[4];
     // workspace offsets (bytes)
     size_t ws_bytes = 0;
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
-    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, slab_off = 0;
+    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, slab_off = 0, ticket_off = 0;
+    bool fused_fin = true;
+    bool defer_slab = false;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
@@ -106,6 +110,11 @@ struct vpd_plan {
     struct Graph { int n; hipGraph_t g; hipGraphExec_t e; };
     std::vector<Graph> graphs;
     void* bound_ws = nullptr;
+    // backward runs the weight-gradient kernels on a side stream (they are off the dgrad critical path)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_pool2;          // fork/join events, reused every step
+    size_t ev_next = 0;
+    bool two_streams = false;   // measured: no gain (conv kernels fill every CU's VGPR/LDS, nothing co-resides); VPD_TWO_STREAMS=1
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
     bool timing = false;
     struct TimedLaunch { int cls; double flops; hipEvent_t a, b; };
@@ -157,6 +166,15 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     }
     c.wg_off = p->wg_elems;
     p->wg_elems += (long long)c.ntaps * Co * c.Kc;
+    if (!stem && k == 3 && stride == 1 && p->train && vpd_wgrad_halo_shape_ok(c.Hout, c.Wout)) {
+        // halo wgrad conv.  Default: ONE shared slab, summed right after each wgrad launch while it is still in
+        // the Infinity Cache (measured 45.5k crops/s).  VPD_DEFER_SLAB=1: per-conv slabs kept until one
+        // bucket-level reduce (fewer launches, but 490 MB of slabs fall out of the cache: 43.2k crops/s).
+        static const bool defer = getenv("VPD_DEFER_SLAB") && atoi(getenv("VPD_DEFER_SLAB"));
+        p->defer_slab = defer;
+        c.slab_off = defer ? p->slab_elems : 0;
+        if (defer || p->slab_elems == 0) p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
+    }
 }
 
 TapSet conv_taps_fwd(const ConvInfo& c) {
@@ -246,13 +264,15 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         PackDesc d;
         d.src_off = c.w_off; d.fwd_off = c.fwd_off; d.dgr_off = c.dgr_off; d.wg_off = c.wg_off;
         d.Co = c.Co; d.Ci = c.Ci; d.kh = c.k; d.kw = c.k; d.Kc = c.Kc; d.ntaps = c.ntaps; d.stem = c.stem ? 1 : 0;
+        d.slab_off = p->defer_slab ? c.slab_off : -1; d.HWout = c.Hout * c.Wout;
         const int id = (int)p->descs.size();
         p->descs.push_back(d);
         const long long nf = (long long)c.ntaps * c.Co * c.Kc;
         const long long ns = (long long)c.Co * c.Ci * c.k * c.k;
         const long long npk = nf > ns ? nf : ns;
-        for (long long ch = 0; ch * 4096 < npk; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
-        for (long long ch = 0; ch * 4096 < ns; ++ch) {
+        for (long long ch = 0; ch * 1024 < npk; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
+        const long long uchunk = d.slab_off >= 0 ? 64 : 1024;     // SLAB_CHUNK / PACK_CHUNK of unpack_grads_kernel
+        for (long long ch = 0; ch * uchunk < ns; ++ch) {
             p->bmap_unpack[bucket].push_back(id);
             p->bmap_unpack[bucket].push_back((int)ch);
         }
@@ -294,6 +314,10 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         (void)mx;   // producers accumulate atomically into VPD_STAT_ROWS rows of [2][C]
         p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * 512 * 4;
         p->partial_off = bp.take(p->partial_bytes);
+        p->ticket_off = bp.take(256);
+        // measured: the per-block ticket round trip costs more than the 36 tiny finalize launches it saves
+        // (38.3k vs 44.7k crops/s), so the fused form is opt-in
+        p->fused_fin = getenv("VPD_FUSED_FIN") && atoi(getenv("VPD_FUSED_FIN"));
     }
     p->z0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
     p->p0_off = bp.take(padded_elems(NB, p->H1, p->W1, 64, 1) * 2);
@@ -322,12 +346,14 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         }
         for (int s = 0; s < 4; ++s) {
             StageInfo& S = p->stages[s];
-            S.dz2_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
-            S.dz1_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+            for (int k = 0; k < 2; ++k) {
+                S.dz2_off[k] = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+                S.dz1_off[k] = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
+            }
             S.dzd_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
-        p->slab_off = bp.take(vpd_wgrad_slab_bytes());
+        p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
@@ -347,6 +373,8 @@ extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
         (void)hipGraphExecDestroy(g.e);
         (void)hipGraphDestroy(g.g);
     }
+    for (auto e : p->ev_pool2) (void)hipEventDestroy(e);
+    if (p->side) (void)hipStreamDestroy(p->side);
     for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
@@ -436,7 +464,8 @@ inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real 
 
 // forward convolution launch; input padded activation `x` (border 1; stem: xin), output `y`
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
-                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu) {
+                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
+                        float* bn_running = nullptr, bool fuse_finalize = false) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -450,11 +479,21 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
+    if (stats && fuse_finalize) {
+        q.fin.counter = reinterpret_cast<unsigned*>(c.ws + c.p->ticket_off);
+        q.fin.gamma = c.params + cv.bn.w_off; q.fin.beta = c.params + cv.bn.b_off;
+        q.fin.running_mean = bn_running ? bn_running + cv.bn.rm_off : nullptr;
+        q.fin.running_var = bn_running ? bn_running + cv.bn.rv_off : nullptr;
+        q.fin.mean = c.bn_mean(cv.bn); q.fin.rstd = c.bn_rstd(cv.bn);
+        q.fin.scale = c.bn_scale(cv.bn); q.fin.shift = c.bn_shift(cv.bn);
+        q.fin.count = (float)q.M; q.fin.momentum = kBnMomentum; q.fin.eps = kBnEps;
+    }
     TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
     return vpd_launch_conv(q, c.s);
 }
 
 hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) {
+    if (c.p->fused_fin) return hipSuccess;      // done by the conv kernel's last block
     const int M = c.n * cv.Hout * cv.Wout;
     const int bm = vpd_conv_bm(M, cv.Co);
     (void)bm;
@@ -507,7 +546,8 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     return e;
 }
 
-hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) {
+hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
+                          hipStream_t st) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -515,16 +555,18 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.dw = c.f32(c.p->wg_off) + cv.wg_off;
-    q.slab = c.f32(c.p->slab_off);
+    q.slab = cv.slab_off >= 0 ? c.f32(c.p->slab_off) + cv.slab_off : nullptr;
+    q.defer_reduce = c.p->defer_slab ? 1 : 0;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
+    if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) return hipErrorInvalidValue;   // plan and launcher must agree
     if (!vpd_wgrad_overwrites(q)) {      // the generic kernel accumulates with atomics: zero its range first
-        hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, c.s);
+        hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, st);
         if (e != hipSuccess) return e;
     }
-    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
-    return vpd_launch_wgrad(q, c.s);
+    TimeScope ts(c.p, st, 4, conv_flops(cv, c.n));
+    return vpd_launch_wgrad(q, st);
 }
 
 hipError_t run_bn_apply(const Ctx& c, const ConvInfo& cv, int res_kind, const bf16_t* res, const ConvInfo* rcv,
@@ -662,10 +704,11 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
-    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes, s));
+    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes + 256, s));     // accumulator rows + ticket
     LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     // stem: conv -> batch stats -> BN+ReLU+maxpool
-    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0));
+    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0,
+                        bn_running, p->fused_fin));
     LCHECK(run_bn_finalize(c, p->stem, bn_running));
     {
         StemPoolParams sp;
@@ -680,13 +723,13 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     for (auto& B : p->blocks) {
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
-        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
         LCHECK(run_bn_finalize(c, B.c1, bn_running));
         LCHECK(run_bn_apply(c, B.c1, 0, nullptr, nullptr, a1, 1));
-        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
         LCHECK(run_bn_finalize(c, B.c2, bn_running));
         if (B.ds) {
-            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
+            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
             LCHECK(run_bn_finalize(c, B.cd, bn_running));
             LCHECK(run_bn_apply(c, B.c2, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
         } else {
@@ -734,12 +777,47 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         const StageInfo& S = p->stages[3];
         LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, 512, n, G[gi], s));
     }
+    // ---- side stream for the weight gradients ----
+    static const bool want_side = getenv("VPD_TWO_STREAMS") && atoi(getenv("VPD_TWO_STREAMS"));
+    const bool fork = p->two_streams || want_side;
+    if (fork && !p->side) LCHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    hipStream_t ws_stream = fork ? p->side : s;
+    p->ev_next = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (p->ev_next == p->ev_pool2.size()) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            p->ev_pool2.push_back(e);
+        }
+        return p->ev_pool2[p->ev_next++];
+    };
+    // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
+    auto fork_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
+        if (fork) {
+            hipEvent_t e = next_event();
+            hipError_t r = hipEventRecord(e, s);
+            if (r != hipSuccess) return r;
+            r = hipStreamWaitEvent(p->side, e, 0);
+            if (r != hipSuccess) return r;
+        }
+        return run_conv_wgrad(c, cv, dz, dzpad, x, ws_stream);
+    };
+    // main stream must not overwrite a dz buffer the side stream may still be reading
+    hipEvent_t dz_free[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    auto join_side = [&]() -> hipError_t {      // main waits for everything enqueued on the side stream so far
+        if (!fork) return hipSuccess;
+        hipEvent_t e = next_event();
+        hipError_t r = hipEventRecord(e, p->side);
+        if (r != hipSuccess) return r;
+        return hipStreamWaitEvent(s, e, 0);
+    };
     auto unpack_bucket = [&](int b) -> int {
+        LCHECK(join_side());
         const int nb = (int)p->bmap_unpack[b].size() / 2;
         if (nb > 0)
             LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
                                            reinterpret_cast<const int*>(ws + p->bmap_unpack_off[b]), nb,
-                                           c.f32(p->wg_off), grads, s));
+                                           c.f32(p->wg_off), c.f32(p->slab_off), n, grads, s));
         if (bucket_events && bucket_events[b]) LCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
         return 0;
     };
@@ -747,27 +825,35 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
         const StageInfo& S = p->stages[B.stage];
+        const int par = bi & 1;
         const bf16_t* xin = bi == 0 ? c.b16(p->p0_off) : c.b16(p->blocks[bi - 1].out_off);
         bf16_t* dout = G[gi];
         bf16_t* da1 = G[(gi + 1) % 3];
         bf16_t* dnew = G[(gi + 2) % 3];
-        bf16_t* dz2 = c.b16(S.dz2_off);
-        bf16_t* dz1 = c.b16(S.dz1_off);
+        bf16_t* dz2 = c.b16(S.dz2_off[par]);
+        bf16_t* dz1 = c.b16(S.dz1_off[par]);
+        // the side stream's readers of this parity's dz buffers (block bi+2 of the same stage) must be done
+        if (fork && dz_free[B.stage][par]) LCHECK(hipStreamWaitEvent(s, dz_free[B.stage][par], 0));
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
         LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
-        LCHECK(run_conv_wgrad(c, B.c2, dz2, 1, c.b16(B.a1_off)));
+        LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
         LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
-        LCHECK(run_conv_wgrad(c, B.c1, dz1, 1, xin));
+        LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
-            bf16_t* dzd = c.b16(S.dzd_off);
+            bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
             LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
-            LCHECK(run_conv_wgrad(c, B.cd, dzd, 1, xin));
+            LCHECK(fork_wgrad(B.cd, dzd, 1, xin));
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
             LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
             gi = (gi + 2) % 3;
         } else {
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
+        }
+        if (fork) {      // everything the side stream has been given so far covers this block's dz readers
+            hipEvent_t e = next_event();
+            LCHECK(hipEventRecord(e, p->side));
+            dz_free[B.stage][par] = e;
         }
         if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
             if (unpack_bucket(3 - B.stage)) return -1;
@@ -784,7 +870,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
         LCHECK(vpd_launch_stem_pool_bwd(sb, (float)sb.M, params + p->stem.bn.w_off, grads + p->stem.bn.w_off,
                                         grads + p->stem.bn.b_off, c.bn_coef(p->stem.bn), c.b16(p->dz0_off), s));
-        LCHECK(run_conv_wgrad(c, p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
+        LCHECK(fork_wgrad(p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
     }
     return unpack_bucket(3);
 }
