@@ -9,62 +9,55 @@
 // finalize of forward statistics: partials [T][2][C] -> mean, rstd, scale,
 // shift; running-stat update (momentum, unbiased var) as nn.BatchNorm2d.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+// One wave per 64 channels, one channel per lane: the 2*VPD_STAT_ROWS loads are independent and go out
+// back to back, so the kernel costs one memory round trip (it is latency, not bandwidth, bound).
+static __device__ __forceinline__ void stat_rows_take(float* partials, int C, int c, double* s1, double* s2) {
+    float v1[VPD_STAT_ROWS], v2[VPD_STAT_ROWS];
+#pragma unroll
+    for (int t = 0; t < VPD_STAT_ROWS; ++t) {
+        v1[t] = partials[((size_t)t * 2) * C + c];
+        v2[t] = partials[((size_t)t * 2 + 1) * C + c];
+    }
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int t = 0; t < VPD_STAT_ROWS; ++t) {
+        a += (double)v1[t]; b += (double)v2[t];
+        partials[((size_t)t * 2) * C + c] = 0.f;          // leave the accumulator rows zeroed for the next producer
+        partials[((size_t)t * 2 + 1) * C + c] = 0.f;
+    }
+    *s1 = a; *s2 = b;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(
     float* partials, int T, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, float momentum, float eps,
     float* mean, float* rstd, float* scale, float* shift) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        // T == VPD_STAT_ROWS == 16: four rows per thread group, all eight loads in flight at once
-        float v1[4], v2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = g + 4 * k;
-            float* q = partials + ((size_t)t * 2) * C + c;
-            v1[k] = t < T ? q[0] : 0.f;
-            v2[k] = t < T ? q[C] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = g + 4 * k;
-            if (t < T) {
-                float* q = partials + ((size_t)t * 2) * C + c;
-                q[0] = 0.f; q[C] = 0.f;      // leave the accumulator rows zeroed for the next producer
-            }
-            s1 += (double)v1[k];
-            s2 += (double)v2[k];
-        }
-    }
-    sh[0][g][cl] = s1; sh[1][g][cl] = s2;
-    __syncthreads();
-    if (g == 0 && c < C) {
-        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-        const double mu = s1 / (double)count;
-        double var = s2 / (double)count - mu * mu;
-        var = var > 0.0 ? var : 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)eps));
-        mean[c] = (float)mu;
-        rstd[c] = r;
-        const float sc = gamma[c] * r;
-        scale[c] = sc;
-        shift[c] = beta[c] - (float)mu * sc;
-        if (running_mean) {
-            const double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-        }
+    (void)T;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s1, s2;
+    stat_rows_take(partials, C, c, &s1, &s2);
+    const double mu = s1 / (double)count;
+    double var = s2 / (double)count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu;
+    rstd[c] = r;
+    const float sc = gamma[c] * r;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean) {
+        const double unb = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
 }
 
 hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, partials, T, C, count, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, T, C, count, gamma,
                        beta, rm, rv, momentum, eps, mean, rstd, scale, shift);
     return hipGetLastError();
 }
@@ -276,45 +269,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
 }
 
 // pass 1b: partials -> dgamma, dbeta (fp32 grads) and the apply coefficients
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
     float* partials, int T, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ rstd, float* dgamma, float* dbeta, float* coef) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-        // T == VPD_STAT_ROWS == 16: four rows per thread group, all eight loads in flight at once
-        float v1[4], v2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = g + 4 * k;
-            float* q = partials + ((size_t)t * 2) * C + c;
-            v1[k] = t < T ? q[0] : 0.f;
-            v2[k] = t < T ? q[C] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = g + 4 * k;
-            if (t < T) {
-                float* q = partials + ((size_t)t * 2) * C + c;
-                q[0] = 0.f; q[C] = 0.f;
-            }
-            s1 += (double)v1[k];
-            s2 += (double)v2[k];
-        }
-    }
-    sh[0][g][cl] = s1; sh[1][g][cl] = s2;
-    __syncthreads();
-    if (g == 0 && c < C) {
-        s1 = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-        s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        coef[c] = gamma[c] * rstd[c];
-        coef[C + c] = (float)(s1 / (double)count);
-        coef[2 * C + c] = (float)(s2 / (double)count);
-    }
+    (void)T;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s1, s2;
+    stat_rows_take(partials, C, c, &s1, &s2);
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    coef[c] = gamma[c] * rstd[c];
+    coef[C + c] = (float)(s1 / (double)count);
+    coef[2 * C + c] = (float)(s2 / (double)count);
 }
 
 // pass 2: dz = c1 * (g - c2 - xhat * c3); optionally write g back over dy
@@ -376,7 +343,7 @@ hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* ga
     if (p.C % 8 || p.C > 2048 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, s, p.partials,
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, p.coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
@@ -400,6 +367,10 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
     *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
     LD8(mu, p.mean + c) LD8(rs, p.rstd + c) LD8(sc, p.scale + c) LD8(shf, p.shift + c)
+    float c1[8], c2[8], c3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c1[j] = 0.f; c2[j] = 0.f; c3[j] = 0.f; }
+    if (p.pass == 2) { LD8(c1, p.coef + c) LD8(c2, p.coef + p.C + c) LD8(c3, p.coef + 2 * p.C + c) }
 #undef LD8
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
@@ -412,7 +383,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
             const int r = m - b * HWz;
             const int y = r / p.Wz;
             const int x = r - y * p.Wz;
-            float z[8], g[8];
+            float z[8], g[8], o[8];
             unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = 0.f;
@@ -441,13 +412,14 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
             for (int j = 0; j < 8; ++j) {
                 const float a = z[j] * sc[j] + shf[j];
                 g[j] = a > 0.f ? g[j] : 0.f;
-                // sums over the bf16-rounded g that pass 2 will read
-                g[j] = bf2f(f2bf(g[j]));
+                const float xh = (z[j] - mu[j]) * rs[j];
                 a1[j] += g[j];
-                a2[j] += g[j] * ((z[j] - mu[j]) * rs[j]);
+                a2[j] += g[j] * xh;
+                o[j] = c1[j] * (g[j] - c2[j] - xh * c3[j]);      // pass 2 only (coefficients are 0 in pass 1)
             }
-            *reinterpret_cast<uint4*>(p.g + (size_t)m * p.C + c) = pack8(g);
+            if (p.pass == 2) *reinterpret_cast<uint4*>(p.dz + (size_t)m * p.C + c) = pack8(o);
         }
+    if (p.pass == 2) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = a1[j]; sh[threadIdx.x][8 + j] = a2[j]; }
     __syncthreads();
@@ -463,17 +435,17 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
 
 hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, const float* gamma, float* dgamma,
                                     float* dbeta, float* coef, bf16_t* dz, hipStream_t s) {
+    // Two passes over (d_pool, argmax, z): pass 1 = the BN-backward sums of g (max-pool routing + ReLU mask, never
+    // materialised); finalize; pass 2 recomputes g and writes dz.  Saves writing and re-reading the 134 MB g tensor.
     StemPoolBwdParams p = p0;
     if (p.C % 8 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
+    p.pass = 1; p.coef = coef; p.dz = dz;
     hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, p.partials,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, s, p.partials,
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, coef);
-    BnBwdParams q = {};
-    q.dy = p.g; q.dy_rw = nullptr; q.z = p.z; q.act = nullptr; q.mean = p.mean; q.rstd = p.rstd; q.coef = coef;
-    q.partials = p.partials; q.dz = dz; q.dzHp = p.Hz; q.dzWp = p.Wz; q.dzpad = 0;
-    q.M = p.M; q.H = p.Hz; q.W = p.Wz; q.C = p.C; q.write_g = 0;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)q.M * (q.C / 8))), dim3(256), 0, s, q);
+    p.pass = 2;
+    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
     return hipGetLastError();
 }

@@ -6,9 +6,12 @@
 // Shared epilogue: acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr].
 // Stores bf16 NHWC (8 B per lane), optional eval epilogue (scale/shift/residual/ReLU), optional
 // read-modify-write accumulate, optional per-channel sum / sum-of-squares of the stored values.
+// s1 / s2: the caller's per-lane partial sum / sum of squares of the stored values (accumulated here, reduced and
+// published by conv_stats_flush -- once per tile, or once per block in the persistent kernel).
 template <int BM, int BN, int WM, int WN>
 static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
-                                                     int mtile, int n0, unsigned char* smem) {
+                                                     int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                     float (&s2)[BN / WN / 16][4]) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -23,11 +26,6 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     const int m0 = mtile * BM;
     const int HW = p.Hs * p.Ws;
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
-    float s1[NI][4], s2[NI][4];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
 
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
@@ -83,6 +81,23 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
         }
     }
 
+}
+
+// Reduce the per-lane partial statistics over the 16 pixel lanes and the WM pixel-waves, then ONE atomic per
+// channel and block into accumulator row `row`.  Contains a block barrier: call from all MFMA-layout threads.
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, float (&s1)[BN / WN / 16][4],
+                                                        float (&s2)[BN / WN / 16][4], int row, int n0,
+                                                        unsigned char* smem) {
+    constexpr int WTN = BN / WN;
+    constexpr int NI = WTN / 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
     if (p.stats) {
         // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
         float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
@@ -110,7 +125,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
             // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
-            atomicAdd(&p.stats[((size_t)(mtile & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
+            atomicAdd(&p.stats[((size_t)(row & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
         }
     }
 }

@@ -130,7 +130,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         if (s + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
     }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
+#pragma unroll
+    for (int a = 0; a < BN / WN / 16; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
 
@@ -278,7 +284,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
         }
     }
     __syncthreads();                               // LDS is reused by the statistics reduction
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
+#pragma unroll
+    for (int a = 0; a < BN / WN / 16; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
 
@@ -293,8 +305,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
 // since the MFMA waves only arrive after finishing step s-1 it also frees ring stage (s+2)%3.
 // 256-pixel tiles halve the weight bytes streamed per FLOP with respect to the 128-pixel kernels.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int HROWS>
-__global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
+// HB: halo buffers (1 when the conv has a single 64-channel chunk: the smaller footprint lets two blocks share a
+// CU and overlap each other's prologue / epilogue); WPS: launch-bounds waves per SIMD (4 = two blocks per CU).
+template <int BM, int BN, int HROWS, int HB, int WPS>
+__global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
     constexpr int WN = BN / 64;
     constexpr int WM = 4 / WN;
     constexpr int WTM = BM / WM;
@@ -308,8 +322,8 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
     constexpr int PER_STEP = W_PER + H_PER;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [2][HBUF]
-    bf16_t* sW = sH + 2 * HBUF;                                   // [NS][WSTAGE]
+    bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [HB][HBUF]
+    bf16_t* sW = sH + HB * HBUF;                                  // [NS][WSTAGE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
             int gp = gp0 + hp;
             gp = gp < g.total_pix ? gp : g.total_pix - 1;
             const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ (hp & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (cc & 1) * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (cc & (HB - 1)) * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
         };
         auto issue_w = [&](int step, int stage) __attribute__((always_inline)) {
             const int cc = step / 9;
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
 
     int s = 0;
     for (int cc = 0; cc < nchunks; ++cc) {
-        const bf16_t* cH = sH + (cc & 1) * HBUF;
+        const bf16_t* cH = sH + (cc & (HB - 1)) * HBUF;
         for (int tap = 0; tap < 9; ++tap, ++s) {
             __builtin_amdgcn_s_barrier();                         // READY_s
             if (p.ablate & 2) continue;
@@ -432,17 +446,164 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
         }
     }
     __builtin_amdgcn_s_barrier();                                 // END
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, smem);
+    float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
+#pragma unroll
+    for (int a = 0; a < BN / WN / 16; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
 
-template <int BM, int BN, int HROWS>
+// ---------------------------------------------------------------------------
+// Persistent 64 -> 64 channel 3x3 stride-1 convolution (ResNet layer1, forward and data-gradient).
+// K is only 576, so a per-tile block would spend most of its life re-streaming the 73.7 KB of weights and
+// in prologue / epilogue latency.  Here one block per CU keeps ALL NINE weight taps resident in LDS and
+// walks over pixel tiles: the four loader waves fetch the next tile's halo into the other buffer while the
+// four MFMA waves run the 9 taps x 2 K-halves of the current tile out of LDS without any barrier, then store.
+// One barrier per 128-pixel tile.
+// ---------------------------------------------------------------------------
+template <int HROWS>
+__global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles) {
+    constexpr int BM = 128, BN = 64, WM = 4, WN = 1;
+    constexpr int WTM = BM / WM;
+    constexpr int MI = WTM / 16, NI = 4;
+    constexpr int HBUF = HROWS * 64;
+    constexpr int HPASS = HROWS / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                 // [9][64*64] resident weights
+    bf16_t* sH = sW + 9 * BN * 64;                                // [2][HBUF]
+    unsigned char* red = reinterpret_cast<unsigned char*>(sH + 2 * HBUF);      // statistics scratch (2 KiB)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int G = gridDim.x;
+
+    if (wave >= 4) {
+        const int lw = wave - 4;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        auto issue_halo = [&](int mtile, int buf) __attribute__((always_inline)) {
+            const int gr0 = mtile * g.TR;
+            int prow0;
+            if (g.multi) prow0 = (gr0 / H) * (H + 2);
+            else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+            const int gp0 = prow0 * Wp;
+#pragma unroll
+            for (int k = 0; k < HPASS; ++k) {
+                const int hp = (lw + 4 * k) * 8 + lrow;
+                int gp = gp0 + hp;
+                gp = gp < g.total_pix ? gp : g.total_pix - 1;
+                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ (hp & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
+            }
+        };
+        // resident weights: tap t (in loop order) -> slice w0 + ir*wrs + ic*wcs, rows n, 64 channels
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = (lw + 4 * i) * 8 + lrow;
+                const bf16_t* src = p.w + ((size_t)wsl * 64 + n) * 64 + ((piece ^ (n & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        }
+        issue_halo(blockIdx.x, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // B_0
+        int i = 0;
+        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+            if (t + G < ntiles && !(p.ablate & 4)) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // B_{i+1}
+        }
+        if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
+        conv_finalize_tail(p, red);
+        return;
+    }
+
+    const int wm = wave;                                          // WN == 1
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    int hbase[MI];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = wm * WTM + b * 16 + fr;
+        const int lr = m / W;
+        const int xx = m - lr * W;
+        const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+        hbase[b] = hrow * Wp + xx;
+    }
+    // statistics stay in registers across this block's tiles: one reduction + 128 atomics per BLOCK, not per tile
+    float st1[NI][4], st2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    __builtin_amdgcn_s_barrier();                                 // B_0
+    int i = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+        const bf16_t* cH = sH + (i & 1) * HBUF;
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (p.ablate & 2) break;
+            const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
+            const bf16_t* cW = sW + tap * BN * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfm[MI];
+                const int chunk = kk * 4 + fq;
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int r = a * 16 + fr;
+                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int r = hbase[b] + toff;
+                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN>(p, acc, t, 0, st1, st2);
+        __builtin_amdgcn_s_barrier();                             // B_{i+1}
+    }
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
+    conv_finalize_tail(p, red);
+}
+
+template <int HROWS>
+static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    const int ntiles = (p.M + 127) / 128;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    const size_t lds = ((size_t)9 * 64 + 2 * HROWS) * 64 * sizeof(bf16_t) + 2048;
+    ConvParams q = p;
+    q.fin.nblocks = grid;
+    hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS>), dim3(grid), dim3(512), lds, stream, q, g, ntiles);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int HROWS, int HB, int WPS>
 static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
-    const size_t lds = ((size_t)2 * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
+    const size_t lds = ((size_t)HB * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS>), grid, dim3(512), lds, stream, q, g);
+    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS>), grid, dim3(512), lds, stream, q, g);
     return hipGetLastError();
 }
 
@@ -510,6 +671,8 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             const long t128 = (long)((p.M + 127) / 128) * (p.Co / 128);
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
             if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 0;    // few pixel tiles: 64-channel tiles fill the chip
+        } else if (p.Kc == 64 && p.Co == 64 && halo_geom(p, 128, 224, g)) {
+            return 4;      // 64 -> 64 channels (layer1): persistent blocks with resident weights
         }
     }
     return 3;
@@ -523,9 +686,10 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
-        case 0: return launch_ws<128, 64, 288>(p, g, stream);
-        case 1: return launch_ws<256, 128, 352>(p, g, stream);
-        case 2: return launch_ws<128, 128, 288>(p, g, stream);
+        case 0: return launch_ws<128, 64, 288, 2, 2>(p, g, stream);
+        case 1: return launch_ws<256, 128, 352, 2, 2>(p, g, stream);
+        case 2: return launch_ws<128, 128, 288, 2, 2>(p, g, stream);
+        case 4: return launch_c64<224>(p, g, stream);
         default: break;
     }
     // the statistics accumulator rows only depend on the block index, so the tile choice is free

@@ -38,9 +38,10 @@ struct StemPoolBwdParams {
     const unsigned char* idx;
     const bf16_t* z;                    // dense [N][Hz][Wz][C]
     const float* mean; const float* rstd; const float* scale; const float* shift;
-    bf16_t* g;                          // dense [M][C] out
+    bf16_t* g;                          // unused (g is recomputed, never stored)
     float* partials;
     int M, Hz, Wz, Ho, Wo, C, ppb;
+    int pass; const float* coef; bf16_t* dz;    // filled by the launcher
 };
 
 struct PackDesc {                       // one convolution's weight tensors

@@ -488,7 +488,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         q.fin.scale = c.bn_scale(cv.bn); q.fin.shift = c.bn_shift(cv.bn);
         q.fin.count = (float)q.M; q.fin.momentum = kBnMomentum; q.fin.eps = kBnEps;
     }
-    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q) & 3, conv_flops(cv, c.n));   // class 4 (64->64) shares slot 0
     return vpd_launch_conv(q, c.s);
 }
 
@@ -520,7 +520,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         q.taps.nr = cv.k; q.taps.nc = cv.k;
         q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
         q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
-        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q) & 3, conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
     // the parity-class launches of a stride-2 dgrad are one timed unit (gather kernel)
