@@ -74,6 +74,15 @@ struct BnFin {
     int nblocks;
 };
 
+// Output sub-grid of one launch (or of one parity class of a merged stride-2 data-gradient launch).
+struct ConvGeo {
+    int Hs, Ws, M, oph, opw;
+};
+struct ConvClass {
+    ConvGeo geo;
+    TapSet taps;
+};
+
 // One implicit-GEMM convolution launch (forward conv, or data-gradient conv).
 // Output pixels are enumerated on a sub-grid (Hs x Ws per image); output pixel
 // (y, x) of the sub-grid lands at (y*osub+oph, x*osub+opw) of tensor Y and
@@ -95,6 +104,10 @@ struct ConvParams {
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
     BnFin fin;                                  // fused finalize of `stats` (forward, train mode)
+    // gather kernel only: extra parity classes of a stride-2 data gradient, selected by blockIdx.z (class 0 is
+    // described by the fields above); ncls == 0 or 1 means a single class
+    int ncls;
+    ConvClass cls[3];
 };
 
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the

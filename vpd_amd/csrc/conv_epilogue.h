@@ -11,7 +11,7 @@
 template <int BM, int BN, int WM, int WN>
 static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
                                                      int mtile, int n0, float (&s1)[BN / WN / 16][4],
-                                                     float (&s2)[BN / WN / 16][4]) {
+                                                     float (&s2)[BN / WN / 16][4], const ConvGeo& geo) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -24,20 +24,20 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     const int fr = lane & 15;
     const int fq = lane >> 4;
     const int m0 = mtile * BM;
-    const int HW = p.Hs * p.Ws;
+    const int HW = geo.Hs * geo.Ws;
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
 
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = m0 + wm * WTM + b * 16 + fr;
-        const bool valid = m < p.M;
-        const int mc = valid ? m : p.M - 1;
+        const bool valid = m < geo.M;
+        const int mc = valid ? m : geo.M - 1;
         const int bi = mc / HW;
         const int r = mc - bi * HW;
-        const int yy = r / p.Ws;
-        const int xx = r - yy * p.Ws;
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + p.oph + p.ypad) * p.yWp +
-                             (xx * p.osub + p.opw + p.ypad)) * p.yC;
+        const int yy = r / geo.Ws;
+        const int xx = r - yy * geo.Ws;
+        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp +
+                             (xx * p.osub + geo.opw + p.ypad)) * p.yC;
         size_t roff = 0;
         if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
 #pragma unroll

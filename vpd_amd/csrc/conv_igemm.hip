@@ -39,34 +39,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int mtile = blockIdx.x;
     const int n0 = blockIdx.y * BN;
     const int m0 = mtile * BM;
+    // parity class of a merged stride-2 data gradient (blockIdx.z); class 0 lives in the top-level fields
+    ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    TapSet taps = p.taps;
+    switch (blockIdx.z) {
+        case 1: geo = p.cls[0].geo; taps = p.cls[0].taps; break;
+        case 2: geo = p.cls[1].geo; taps = p.cls[1].taps; break;
+        case 3: geo = p.cls[2].geo; taps = p.cls[2].taps; break;
+        default: break;
+    }
+    if (m0 >= geo.M) return;
 
     const int piece = tid & 7;
     const int row0 = tid >> 3;
 
     // per-thread gather bases (element offsets into x) for its PR pixel rows
     int pixbase[PR];
-    const int HW = p.Hs * p.Ws;
+    const int HW = geo.Hs * geo.Ws;
 #pragma unroll
     for (int i = 0; i < PR; ++i) {
         int m = m0 + row0 + 32 * i;
-        m = m < p.M ? m : p.M - 1;
+        m = m < geo.M ? m : geo.M - 1;
         const int b = m / HW;
         const int r = m - b * HW;
-        const int yy = r / p.Ws;
-        const int xx = r - yy * p.Ws;
+        const int yy = r / geo.Ws;
+        const int xx = r - yy * geo.Ws;
         pixbase[i] = ((b * p.xHp + yy * p.istr) * p.xWp + xx * p.istr) * p.xC + piece * 8;
     }
     const int kchunks = p.Kc >> 6;
-    const int nsteps = p.taps.nr * p.taps.nc * kchunks;
+    const int nsteps = taps.nr * taps.nc * kchunks;
 
     u32x4 rp[PR], rw[WR];
     auto load_step = [&](int s) __attribute__((always_inline)) {
         const int tap = s / kchunks;
         const int cc = s - tap * kchunks;
-        const int ir = tap / p.taps.nc;
-        const int ic = tap - ir * p.taps.nc;
-        const int toff = ((p.taps.dy0 + ir * p.taps.dys) * p.xWp + (p.taps.dx0 + ic * p.taps.dxs)) * p.xC + cc * 64;
-        const int wsl = p.taps.w0 + ir * p.taps.wrs + ic * p.taps.wcs;
+        const int ir = tap / taps.nc;
+        const int ic = tap - ir * taps.nc;
+        const int toff = ((taps.dy0 + ir * taps.dys) * p.xWp + (taps.dx0 + ic * taps.dxs)) * p.xC + cc * 64;
+        const int wsl = taps.w0 + ir * taps.wrs + ic * taps.wcs;
 #pragma unroll
         for (int i = 0; i < PR; ++i)
             rp[i] = *reinterpret_cast<const u32x4*>(p.x + pixbase[i] + toff);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
@@ -173,6 +183,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
     bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [HB][HROWS*64]
     bf16_t* sW = sH + HB * HROWS * 64;                            // [2][BN*64]
 
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
     for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
     bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                 // [HB][HBUF]
     bf16_t* sW = sH + HB * HBUF;                                  // [NS][WSTAGE]
 
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
     for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2);
+    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
@@ -476,6 +488,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
     bf16_t* sH = sW + 9 * BN * 64;                                // [2][HBUF]
     unsigned char* red = reinterpret_cast<unsigned char*>(sH + 2 * HBUF);      // statistics scratch (2 KiB)
 
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -579,7 +592,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN>(p, acc, t, 0, st1, st2);
+        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN>(p, acc, t, 0, st1, st2, geo);
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
@@ -642,7 +655,9 @@ static bool halo_eligible(const ConvParams& p) {
 
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
-    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    int maxM = p.M;
+    for (int k = 1; k < p.ncls; ++k) maxM = p.cls[k - 1].geo.M > maxM ? p.cls[k - 1].geo.M : maxM;
+    dim3 grid((maxM + BM - 1) / BM, p.Co / BN, p.ncls > 1 ? p.ncls : 1);
     const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);

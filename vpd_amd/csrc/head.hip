@@ -57,61 +57,50 @@ hipError_t vpd_launch_avgpool_bwd(const float* dpooled, int H, int W, int C, int
     return hipGetLastError();
 }
 
-// Small fp32 GEMM, 32x32 output tile per block, K staged 32 at a time in LDS.
+// Small fp32 GEMM on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bitwise an fp32 fma chain, so the
+// head keeps fp32 accuracy).  One wave per 16x16 output tile, operands straight from global memory (these
+// matrices are at most 512 wide and L2-resident), K walked 4 at a time.
 __global__ __launch_bounds__(256) void sgemm_small_kernel(const float* A, const float* B, float* Y, const float* bias,
                                                           int M, int N, int K, int ta, int tb, int relu) {
-    __shared__ float sA[32][33];   // [m][k]
-    __shared__ float sB[32][33];   // [k][n]
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // ty 0..7
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float acc[4] = {0, 0, 0, 0};                                  // rows ty, ty+8, ty+16, ty+24; col tx
-    for (int k0 = 0; k0 < K; k0 += 32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = ty + 8 * i;
-            // A tile element (m = m0 + r, k = k0 + tx)  -- or transposed assignment for coalescing
-            {
-                int m, k;
-                if (ta) { m = m0 + tx; k = k0 + r; } else { m = m0 + r; k = k0 + tx; }
-                float v = 0.f;
-                if (m < M && k < K) v = ta ? A[(size_t)k * M + m] : A[(size_t)m * K + k];
-                if (ta) sA[tx][r] = v; else sA[r][tx] = v;
-            }
-            {
-                int k, n;
-                if (tb) { n = n0 + r; k = k0 + tx; } else { k = k0 + r; n = n0 + tx; }
-                float v = 0.f;
-                if (n < N && k < K) v = tb ? B[(size_t)n * K + k] : B[(size_t)k * N + n];
-                if (tb) sB[tx][r] = v; else sB[r][tx] = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float bv = sB[k][tx];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += sA[ty + 8 * i][k] * bv;
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int tiles_n = (N + 15) >> 4;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    if (tm * 16 >= M) return;
+    const int r = lane & 15, kq = lane >> 4;
+    const int m = tm * 16 + r, n = tn * 16 + r;
+    const bool mok = m < M, nok = n < N;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t a_m = ta ? (size_t)(mok ? m : 0) : (size_t)(mok ? m : 0) * K;
+    const size_t a_k = ta ? (size_t)M : 1;
+    const size_t b_n = tb ? (size_t)(nok ? n : 0) * K : (size_t)(nok ? n : 0);
+    const size_t b_k = tb ? 1 : (size_t)N;
+#pragma unroll 8
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const bool kok = k < K;
+        const float av = (mok && kok) ? A[a_m + (size_t)k * a_k] : 0.f;
+        const float bv = (nok && kok) ? B[b_n + (size_t)k * b_k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
-    const int n = n0 + tx;
-    if (n < N) {
+    // acc[j] = Y[tm*16 + 4*kq + j][tn*16 + r]
+    if (nok) {
         const float bb = bias ? bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + ty + 8 * i;
-            if (m < M) {
-                float v = acc[i] + bb;
+        for (int j = 0; j < 4; ++j) {
+            const int mm = tm * 16 + 4 * kq + j;
+            if (mm < M) {
+                float v = acc[j] + bb;
                 if (relu) v = v > 0.f ? v : 0.f;
-                Y[(size_t)m * N + n] = v;
+                Y[(size_t)mm * N + n] = v;
             }
         }
     }
 }
 hipError_t vpd_launch_sgemm(const float* A, const float* B, float* Y, const float* bias, int M, int N, int K, int ta,
                             int tb, int relu, hipStream_t s) {
-    dim3 grid((N + 31) / 32, (M + 31) / 32);
-    hipLaunchKernelGGL(sgemm_small_kernel, grid, dim3(256), 0, s, A, B, Y, bias, M, N, K, ta, tb, relu);
+    const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, A, B, Y, bias, M, N, K, ta, tb, relu);
     return hipGetLastError();
 }
 

@@ -523,27 +523,35 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q) & 3, conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
-    // the parity-class launches of a stride-2 dgrad are one timed unit (gather kernel)
+    // stride 2: the four input-pixel parity classes are ONE launch (grid.z = class).  Only taps r with
+    // (ph + pad - r) even contribute: r = rf, rf+2, ... reading dz row  y + (ph + pad - r)/2  (+1 for the border).
     TimeScope ts(c.p, c.s, 3, conv_flops(cv, c.n));
-    // stride 2: one launch per input-pixel parity class; only taps r with (ph + pad - r) even
-    // contribute: r = rf, rf+2, ... with dz row  y + (ph + pad - r)/2  (+1 for the border)
+    q.osub = 2;
+    int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
-            q.Hs = (cv.Hin - ph + 1) / 2; q.Ws = (cv.Win - pw + 1) / 2;
-            if (q.Hs <= 0 || q.Ws <= 0) continue;
-            q.osub = 2; q.oph = ph; q.opw = pw;
-            q.M = c.n * q.Hs * q.Ws;
+            ConvClass k;
+            k.geo.Hs = (cv.Hin - ph + 1) / 2; k.geo.Ws = (cv.Win - pw + 1) / 2;
+            if (k.geo.Hs <= 0 || k.geo.Ws <= 0) continue;
+            k.geo.oph = ph; k.geo.opw = pw;
+            k.geo.M = c.n * k.geo.Hs * k.geo.Ws;
             const int rf = (ph + cv.pad) % 2, tf = (pw + cv.pad) % 2;
-            q.taps.nr = rf < cv.k ? (cv.k - rf + 1) / 2 : 0;
-            q.taps.nc = tf < cv.k ? (cv.k - tf + 1) / 2 : 0;
-            if (q.taps.nr == 0 || q.taps.nc == 0) continue;   // caller zero-fills / overwrites those pixels
-            q.taps.dy0 = (ph + cv.pad - rf) / 2 + 1; q.taps.dys = -1;
-            q.taps.dx0 = (pw + cv.pad - tf) / 2 + 1; q.taps.dxs = -1;
-            q.taps.w0 = rf * cv.k + tf; q.taps.wrs = 2 * cv.k; q.taps.wcs = 2;
-            e = vpd_launch_conv(q, c.s);
-            if (e != hipSuccess) return e;
+            k.taps.nr = rf < cv.k ? (cv.k - rf + 1) / 2 : 0;
+            k.taps.nc = tf < cv.k ? (cv.k - tf + 1) / 2 : 0;
+            if (k.taps.nr == 0 || k.taps.nc == 0) continue;   // caller zero-fills / overwrites those pixels
+            k.taps.dy0 = (ph + cv.pad - rf) / 2 + 1; k.taps.dys = -1;
+            k.taps.dx0 = (pw + cv.pad - tf) / 2 + 1; k.taps.dxs = -1;
+            k.taps.w0 = rf * cv.k + tf; k.taps.wrs = 2 * cv.k; k.taps.wcs = 2;
+            if (ncls == 0) {
+                q.Hs = k.geo.Hs; q.Ws = k.geo.Ws; q.M = k.geo.M; q.oph = ph; q.opw = pw; q.taps = k.taps;
+            } else {
+                q.cls[ncls - 1] = k;
+            }
+            ++ncls;
         }
-    return e;
+    if (ncls == 0) return hipSuccess;
+    q.ncls = ncls;
+    return vpd_launch_conv(q, c.s);
 }
 
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
