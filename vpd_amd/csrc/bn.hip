@@ -338,11 +338,12 @@ int vpd_bn_bwd_blocks(int M, int C, int* ppb_out) {
 }
 
 hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* gamma, float* dgamma, float* dbeta,
-                             hipStream_t s) {
+                             hipStream_t s, bool reduce_done) {
     BnBwdParams p = p0;
     if (p.C % 8 || p.C > 2048 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
+    // reduce_done: the producing data-gradient kernel already masked dy and accumulated (sum g, sum g*xhat)
+    if (!reduce_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, s, p.partials,
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, p.coef);

@@ -198,12 +198,104 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// MFMA-wave body of conv_wgrad_halo_kernel for taps [T0, T1): ci columns 16*ctile .. +15, all 64 co.
+template <int T0, int T1>
+static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, const WgHaloGeom& g, const bf16_t* ring,
+                                                       int STAGE, int nch, int ctile, int lane) {
+    constexpr int NT = T1 - T0;
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    // chunk-invariant LDS element offsets (within a stage) of every transposed read of this lane.
+    // dz rows are 32*ks + 8*gq + 4*h + q: the swizzle only looks at row bits 1 and 3, so k-step 1 is +32 rows.
+    int offA[4][2], offB[2][NT][2];
+    {
+        const int ra = 8 * gq + q;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = ra + 4 * h;
+                const int col = a * 16 + 4 * pp;
+                offA[a][h] = r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pk = 32 * ks + 8 * gq + 4 * h + q;      // pixel of the chunk this lane addresses
+                const int lr = pk / W;
+                const int xx = pk - lr * W;
+                const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+                const int hmv = hrow * Wp + xx;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int tt = T0 + t;
+                    const int r = hmv + (p.taps.dy0 + (tt / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tt % 3) * p.taps.dxs);
+                    const int col = ctile * 16 + 4 * pp;
+                    offB[ks][t][h] = 64 * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+                }
+            }
+    }
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    auto frag = [&](const bf16_t* st, int o0, int o1) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o1));
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    for (int c = 0; c < nch; ++c) {
+        __builtin_amdgcn_s_barrier();                             // READY_c
+        if (p.ablate & 2) continue;
+        const bf16_t* st = ring + (c % 3) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 az[4], bx[NT];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) az[a] = frag(st + ks * 32 * 64, offA[a][0], offA[a][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bx[t] = frag(st, offB[ks][t][0], offB[ks][t][1]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMA block (hipcc would sink them)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[t], acc[t][a], 0, 0, 0);
+        }
+    }
+
+    // acc[t][a][j] = partial dW[tap T0+t][co0 + a*16 + 4*gq + j][ci0 + 16*ctile + i16]
+    if (p.ablate & 8) return;
+    const int kct = p.Kc >> 6;
+    const int co0 = (blockIdx.x / kct) * 64;
+    const int ci0 = (blockIdx.x % kct) * 64;
+    float* slab = p.slab + (size_t)blockIdx.y * 9 * p.Co * p.Kc;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tt = T0 + t;
+        const int wsl = p.taps.w0 + (tt / 3) * p.taps.wrs + (tt % 3) * p.taps.wcs;
+        float* o = slab + ((size_t)wsl * p.Co + co0) * p.Kc + ci0 + 16 * ctile + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
+    }
+}
+
 #define WG_CH 64           // pixels per chunk = two MFMA K-steps (vpd_wgrad_split assumes 64)
 #define WG_NS 3            // ring stages
 
 // NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS)
 template <int NPASS>
-__global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
+__global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
     constexpr int HROWS = 32 * NPASS;
     constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile then halo
     constexpr int PER_CHUNK = 2 + NPASS;                          // LDS-DMA instructions per loader wave per chunk
@@ -212,7 +304,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // 0..3 MFMA waves, 4..7 loader waves
+    // waves 0..7: MFMA (ci tile = wave & 3, tap half = wave >> 2: two MFMA waves share each SIMD so one computes
+    // while the other waits for its LDS reads); waves 8..11: loaders
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.Ws, H = p.Hs, Wp = W + 2;
     const int kct = p.Kc >> 6;
     const int co0 = (blockIdx.x / kct) * 64;
@@ -223,9 +317,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams 
     chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
     const int nch = chunk_end - chunk_begin;                      // >= 1 by construction of ksplit
 
-    if (wave >= 4) {
+    if (wave >= 8) {
         // ------------------------- loader waves -------------------------
-        const int lw = wave - 4;
+        const int lw = wave - 8;
         const int piece = lane & 7;
         const int lrow = lane >> 3;                               // row within an 8-row wave instruction
         auto issue = [&](int c) __attribute__((always_inline)) {
@@ -263,6 +357,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams 
                 __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + WG_CH * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
         };
+        if (p.ablate & 1) {
+            for (int c = 0; c < nch; ++c) __builtin_amdgcn_s_barrier();
+            return;
+        }
         issue(0);
         if (nch > 1) issue(1);
         for (int c = 0; c < nch; ++c) {
@@ -276,82 +374,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_halo_kernel(const WgradParams 
     }
 
     // ------------------------- MFMA waves -------------------------
-    f32x4 acc[9][4];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-    // chunk-invariant LDS element offsets (within a stage) of every transposed read of this lane.
-    // dz rows are 32*ks + 8*gq + 4*h + q: the swizzle only looks at row bits 1 and 3, so k-step 1 is +32 rows.
-    int offA[4][2], offB[2][9][2];
-    {
-        const int ra = 8 * gq + q;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = ra + 4 * h;
-                const int col = a * 16 + 4 * pp;
-                offA[a][h] = r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
-            }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pk = 32 * ks + 8 * gq + 4 * h + q;      // pixel of the chunk this lane addresses
-                const int lr = pk / W;
-                const int xx = pk - lr * W;
-                const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
-                const int hmv = hrow * Wp + xx;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int r = hmv + (p.taps.dy0 + (t / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (t % 3) * p.taps.dxs);
-                    const int col = wave * 16 + 4 * pp;
-                    offB[ks][t][h] = WG_CH * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
-                }
-            }
-    }
-    typedef s16x4 __attribute__((address_space(3))) * lds_p;
-    auto frag = [&](const bf16_t* st, int o0, int o1) __attribute__((always_inline)) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o1));
-        s16x8 v;
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        return __builtin_bit_cast(bf16x8, v);
-    };
-
-    for (int c = 0; c < nch; ++c) {
-        __builtin_amdgcn_s_barrier();                             // READY_c
-        const bf16_t* st = ring + (c % WG_NS) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 az[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) az[a] = frag(st + ks * 32 * 64, offA[a][0], offA[a][1]);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const bf16x8 bx = frag(st, offB[ks][t][0], offB[ks][t][1]);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx, acc[t][a], 0, 0, 0);
-            }
-        }
-    }
-
-    // acc[t][a][j] = partial dW[tap t][co0 + a*16 + 4*gq + j][ci0 + 16*wave + i16]
-    float* slab = p.slab + (size_t)blockIdx.y * 9 * p.Co * p.Kc;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
-        float* o = slab + ((size_t)wsl * p.Co + co0) * p.Kc + ci0 + 16 * wave + i16;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
-    }
+    const int ctile = wave & 3;
+    if (wave < 4) wgrad_mfma_half<0, 5>(p, g, ring, STAGE, nch, ctile, lane);
+    else wgrad_mfma_half<5, 9>(p, g, ring, STAGE, nch, ctile, lane);
 }
 
 // dw[e] = sum over all splits of slab[split][e].  A block owns 64 float4 outputs; its `groups` thread
@@ -416,16 +441,18 @@ size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float)
 hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     WgradParams p = p0;
+    static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+    p.ablate = ablate;
     WgHaloGeom g;
     if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
         const int tiles = (p.Co / 64) * (p.Kc / 64);
         g.ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, &g.cpb);
         const int npass = (g.NHP + 31) / 32;            // 3..5
         const size_t lds = (size_t)WG_NS * (WG_CH + 32 * npass) * 64 * sizeof(bf16_t);
-        if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
-        else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
-        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(512), lds, stream, p, g);
-        if (p.defer_reduce) return hipGetLastError();
+        if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        if (p.defer_reduce || (p.ablate & 16)) return hipGetLastError();
         const long n4 = (long)9 * p.Co * p.Kc / 4;
         const int groups = g.ksplit < 16 ? g.ksplit : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,

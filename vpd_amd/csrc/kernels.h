@@ -71,7 +71,7 @@ hipError_t vpd_launch_bn_apply(const BnApplyParams& p, hipStream_t s);
 hipError_t vpd_launch_stem_pool(const StemPoolParams& p, hipStream_t s);
 int vpd_bn_bwd_blocks(int M, int C, int* ppb_out);
 hipError_t vpd_launch_bn_bwd(const BnBwdParams& p, float count, const float* gamma, float* dgamma, float* dbeta,
-                             hipStream_t s);
+                             hipStream_t s, bool reduce_done = false);
 hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p, float count, const float* gamma, float* dgamma,
                                     float* dbeta, float* coef, bf16_t* dz, hipStream_t s);
 

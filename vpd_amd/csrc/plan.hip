@@ -505,9 +505,18 @@ hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) 
 }
 
 // data-gradient of a conv: dz (padded, border 1) -> dx (dense [n][Hin][Win][Ci])
-hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
+// fuse_bn: the conv-BN-ReLU whose output gradient this launch produces (stride-1 launches only): its BN-backward
+// reduction happens in the epilogue (see ConvParams::bz)
+hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
+                          const ConvInfo* fuse_bn = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
+    if (fuse_bn && cv.stride == 1) {
+        q.bz = c.b16(fuse_bn->z_off);
+        q.bscale = c.bn_scale(fuse_bn->bn); q.bshift = c.bn_shift(fuse_bn->bn);
+        q.bmean = c.bn_mean(fuse_bn->bn); q.brstd = c.bn_rstd(fuse_bn->bn);
+        q.stats = c.f32(c.p->partial_off);
+    }
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
     q.w = c.b16(c.p->arena_off) + cv.dgr_off;
     q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
@@ -592,7 +601,7 @@ hipError_t run_bn_apply(const Ctx& c, const ConvInfo& cv, int res_kind, const bf
 // act != null: ReLU mask from the stored activation (needed when a residual was added before the ReLU);
 // relu_from_z: mask recomputed as scale*z + shift > 0 (plain conv-BN-ReLU), which saves reading the activation
 hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
-                      int write_g, float* grads, bool relu_from_z = false) {
+                      int write_g, float* grads, bool relu_from_z = false, bool reduce_done = false) {
     BnBwdParams b;
     memset(&b, 0, sizeof b);
     b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
@@ -601,8 +610,10 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     b.partials = c.f32(c.p->partial_off);
     b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
-    if (relu_from_z) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
-    return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s);
+    if (relu_from_z && !reduce_done) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
+    if (reduce_done) b.act = nullptr;        // dy already holds g (masked by the producing dgrad kernel)
+    return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s,
+                             reduce_done);
 }
 
 #define LCHECK(expr)                                   \
@@ -845,8 +856,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
         LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
         LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
-        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
+        static const bool no_fuse = getenv("VPD_NO_FUSED_BNBWD") && atoi(getenv("VPD_NO_FUSED_BNBWD"));
+        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, no_fuse ? nullptr : &B.c1));       // conv2 is always stride 1
+        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true, !no_fuse));
         LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
