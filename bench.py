@@ -153,9 +153,19 @@ def main():
                               "avg_launch_us": 1e3 * v["ms"] / v["launches"],
                               "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        traffic, traffic_note = None, None
+        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            rows = [v for k, v in pmc["kernels"].items() if dom.split("<")[0] in k]
+            n = sum(r["launches"] for r in rows)
+            traffic = sum(r["launches"] * (2 * r["fetch_KB_per_launch"] + r["write_KB_per_launch"]) for r in rows) / n * 1024
+            traffic_note = pmc["note"]
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"],
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": kernels[dom]["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                    "frac": kernels[dom]["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_note": traffic_note,
                     "whole_step_frac": value / world * flop / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12),
                     "kernels": kernels,
                     "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region; "

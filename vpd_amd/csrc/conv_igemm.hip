@@ -675,9 +675,9 @@ extern "C" int vpd_conv_bm(int M, int Co) {
     return 128;
 }
 
-// Kernel selection.  Classes (also the timing classes of vpd_plan_read_timing):
-//   0 conv3x3_ws<128,64>  1 conv3x3_ws<256,128>  2 conv3x3_ws<128,128>  3 every other conv kernel
-//   (conv3x3_halo<128,64> for shapes the ws tiles do not fit, conv_igemm gather kernel)
+// Kernel selection = timing class of vpd_plan_read_timing (one class per kernel function):
+//   0 conv3x3_c64_persistent_kernel<224>   1 conv3x3_ws_kernel<256,128,352>   2 conv3x3_ws_kernel<128,128,288>
+//   3 conv3x3_ws_kernel<128,64,288>        4 conv_igemm_kernel (gather; also the legacy conv3x3_halo fallback)
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
     static const int no_ws = getenv("VPD_NO_WS") ? atoi(getenv("VPD_NO_WS")) : 0;
     if (halo_eligible(p) && !no_ws) {
@@ -685,12 +685,12 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
             const long t128 = (long)((p.M + 127) / 128) * (p.Co / 128);
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
-            if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 0;    // few pixel tiles: 64-channel tiles fill the chip
+            if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 3;    // few pixel tiles: 64-channel tiles fill the chip
         } else if (p.Kc == 64 && p.Co == 64 && halo_geom(p, 128, 224, g)) {
-            return 4;      // 64 -> 64 channels (layer1): persistent blocks with resident weights
+            return 0;      // 64 -> 64 channels (layer1): persistent blocks with resident weights
         }
     }
-    return 3;
+    return 4;
 }
 int vpd_conv_kernel_class(const ConvParams& p) { HaloGeom g; return vpd_conv_kernel_class(p, &g); }
 
@@ -701,10 +701,10 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
-        case 0: return launch_ws<128, 64, 288, 2, 2>(p, g, stream);
+        case 0: return launch_c64<224>(p, g, stream);
         case 1: return launch_ws<256, 128, 352, 2, 2>(p, g, stream);
         case 2: return launch_ws<128, 128, 288, 2, 2>(p, g, stream);
-        case 4: return launch_c64<224>(p, g, stream);
+        case 3: return launch_ws<128, 64, 288, 2, 2>(p, g, stream);
         default: break;
     }
     // the statistics accumulator rows only depend on the block index, so the tile choice is free

@@ -438,6 +438,15 @@ bool vpd_wgrad_overwrites(const WgradParams& p) {
 
 size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float); }   // ksplit * tiles <= 256
 
+hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
+    const int ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, nullptr);
+    const long n4 = (long)9 * p.Co * p.Kc / 4;
+    const int groups = ksplit < 16 ? ksplit : 16;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
+                       (const float4*)p.slab, (float4*)p.dw, n4, ksplit, groups);
+    return hipGetLastError();
+}
+
 hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     WgradParams p = p0;
@@ -453,11 +462,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || (p.ablate & 16)) return hipGetLastError();
-        const long n4 = (long)9 * p.Co * p.Kc / 4;
-        const int groups = g.ksplit < 16 ? g.ksplit : 16;
-        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
-                           (const float4*)p.slab, (float4*)p.dw, n4, g.ksplit, groups);
-        return hipGetLastError();
+        return vpd_launch_wgrad_reduce(p, stream);
     }
     const int tiles = (p.Co / 64) * (p.Kc / 64) * p.taps.nr * p.taps.nc;
     const int nchunks = (p.M + 127) / 128;

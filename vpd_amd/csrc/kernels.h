@@ -55,7 +55,8 @@ struct PackDesc {                       // one convolution's weight tensors
 };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
-int vpd_conv_kernel_class(const ConvParams& p);      // 0..3, see conv_igemm.hip
+int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
+hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
 size_t vpd_wgrad_slab_bytes();

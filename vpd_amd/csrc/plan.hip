@@ -440,7 +440,7 @@ struct Ctx {
     float* bn_eshift(const BnInfo& b) const { return f32(b.fl_off) + 8 * b.C; }
 };
 
-// timing classes: 0..3 = vpd_conv_kernel_class (ws<256,64>, ws<256,128>, ws<128,128>, other), 4 = wgrad
+// timing classes: 0..4 = vpd_conv_kernel_class, 5 = conv_wgrad_halo_kernel (without its slab reduce), 6 = conv_wgrad_kernel
 struct TimeScope {
     vpd_plan* p; hipStream_t s; int idx = -1;
     TimeScope(vpd_plan* p_, hipStream_t s_, int cls, double flops) : p(p_), s(s_) {
@@ -488,7 +488,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         q.fin.scale = c.bn_scale(cv.bn); q.fin.shift = c.bn_shift(cv.bn);
         q.fin.count = (float)q.M; q.fin.momentum = kBnMomentum; q.fin.eps = kBnEps;
     }
-    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q) & 3, conv_flops(cv, c.n));   // class 4 (64->64) shares slot 0
+    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
     return vpd_launch_conv(q, c.s);
 }
 
@@ -529,12 +529,12 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         q.taps.nr = cv.k; q.taps.nc = cv.k;
         q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
         q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
-        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q) & 3, conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
     // stride 2: the four input-pixel parity classes are ONE launch (grid.z = class).  Only taps r with
     // (ph + pad - r) even contribute: r = rf, rf+2, ... reading dz row  y + (ph + pad - r)/2  (+1 for the border).
-    TimeScope ts(c.p, c.s, 3, conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
     q.osub = 2;
     int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
@@ -582,7 +582,17 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
         hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, st);
         if (e != hipSuccess) return e;
     }
-    TimeScope ts(c.p, st, 4, conv_flops(cv, c.n));
+    if (vpd_wgrad_overwrites(q) && !q.defer_reduce) {      // time the MFMA kernel alone, then sum its slab
+        hipError_t e;
+        {
+            TimeScope ts(c.p, st, 5, conv_flops(cv, c.n));
+            q.defer_reduce = 1;
+            e = vpd_launch_wgrad(q, st);
+        }
+        if (e != hipSuccess) return e;
+        return vpd_launch_wgrad_reduce(q, st);
+    }
+    TimeScope ts(c.p, st, vpd_wgrad_overwrites(q) ? 5 : 6, conv_flops(cv, c.n));
     return vpd_launch_wgrad(q, st);
 }
 
@@ -914,7 +924,7 @@ extern "C" int vpd_plan_set_timing(vpd_plan_t* p, int enable) {
 
 // Sums (and clears) the recorded launches: out[4*cls + {0,1,2}] = {launches, milliseconds, flops}
 extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
-    if (!p || !out || nclasses < 5) return fail("bad argument");
+    if (!p || !out || nclasses < 7) return fail("bad argument");
     for (int i = 0; i < 3 * nclasses; ++i) out[i] = 0.0;
     for (auto& t : p->timed) {
         HCHECK(hipEventSynchronize(t.b));
