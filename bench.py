@@ -143,7 +143,7 @@ def main():
         for _ in range(args.profile_steps):
             one_step()
         torch.cuda.synchronize(device)
-        cls = eng.read_timing(pl)
+        cls = eng.read_timing(pl) if args.profile_steps > 0 else {}
         eng.set_timing(pl, False)
         kernels = {}
         for k, v in cls.items():
@@ -152,6 +152,8 @@ def main():
                               "ms_per_step": v["ms"] / args.profile_steps,
                               "avg_launch_us": 1e3 * v["ms"] / v["launches"],
                               "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+        if not kernels:      # --profile-steps 0 (used under rocprofv3): no event timing, no roofline object
+            kernels = {"(not timed)": {"ms_per_step": 0.0, "tflops": 0.0}}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)

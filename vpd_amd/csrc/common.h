@@ -108,10 +108,6 @@ struct ConvParams {
     // described by the fields above); ncls == 0 or 1 means a single class
     int ncls;
     ConvClass cls[3];
-    // data-gradient launches feeding a conv-BN-ReLU: fuse the BN-backward reduction into the epilogue.  With
-    // bz != null (dense z of that BN, same [M][Co] indexing as y) the stored value is g = dy * [bscale*z + bshift > 0]
-    // and `stats` accumulates (sum g, sum g * xhat) with xhat = (z - bmean) * brstd instead of (sum, sum of squares).
-    const bf16_t* bz; const float* bscale; const float* bshift; const float* bmean; const float* brstd;
 };
 
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the

@@ -65,35 +65,10 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
                 v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
                 v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
             }
-            float xh[4] = {0.f, 0.f, 0.f, 0.f};
-            if (p.bz) {      // fused BN-backward reduce: ReLU mask recomputed from z, store g, accumulate (g, g*xhat)
-                const uint2 zv = *reinterpret_cast<const uint2*>(p.bz + (size_t)mc * p.yC + n);
-                const float z4[4] = {bf2f((unsigned short)(zv.x & 0xffff)), bf2f((unsigned short)(zv.x >> 16)),
-                                     bf2f((unsigned short)(zv.y & 0xffff)), bf2f((unsigned short)(zv.y >> 16))};
-                const float4 sc = *reinterpret_cast<const float4*>(p.bscale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(p.bshift + n);
-                const float4 mu = *reinterpret_cast<const float4*>(p.bmean + n);
-                const float4 rs = *reinterpret_cast<const float4*>(p.brstd + n);
-                const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
-                const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, rss[4] = {rs.x, rs.y, rs.z, rs.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = (z4[j] * scs[j] + shs[j]) > 0.f ? v[j] : 0.f;
-                    xh[j] = (z4[j] - mus[j]) * rss[j];
-                }
-            }
             uint2 ov;
             ov.x = pack2bf(v[0], v[1]);
             ov.y = pack2bf(v[2], v[3]);
-            if (valid && p.bz) {
-                *reinterpret_cast<uint2*>(dst) = ov;
-                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
-                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
-                s1[a][0] += q0; s2[a][0] += q0 * xh[0];
-                s1[a][1] += q1; s2[a][1] += q1 * xh[1];
-                s1[a][2] += q2; s2[a][2] += q2 * xh[2];
-                s1[a][3] += q3; s2[a][3] += q3 * xh[3];
-            } else if (valid) {
+            if (valid) {
                 *reinterpret_cast<uint2*>(dst) = ov;
                 // statistics are taken over the bf16-rounded values actually stored
                 const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));

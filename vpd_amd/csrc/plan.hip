@@ -505,18 +505,9 @@ hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) 
 }
 
 // data-gradient of a conv: dz (padded, border 1) -> dx (dense [n][Hin][Win][Ci])
-// fuse_bn: the conv-BN-ReLU whose output gradient this launch produces (stride-1 launches only): its BN-backward
-// reduction happens in the epilogue (see ConvParams::bz)
-hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
-                          const ConvInfo* fuse_bn = nullptr) {
+hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
     ConvParams q;
     memset(&q, 0, sizeof q);
-    if (fuse_bn && cv.stride == 1) {
-        q.bz = c.b16(fuse_bn->z_off);
-        q.bscale = c.bn_scale(fuse_bn->bn); q.bshift = c.bn_shift(fuse_bn->bn);
-        q.bmean = c.bn_mean(fuse_bn->bn); q.brstd = c.bn_rstd(fuse_bn->bn);
-        q.stats = c.f32(c.p->partial_off);
-    }
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
     q.w = c.b16(c.p->arena_off) + cv.dgr_off;
     q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
@@ -866,9 +857,10 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
         LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
         LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-        static const bool no_fuse = getenv("VPD_NO_FUSED_BNBWD") && atoi(getenv("VPD_NO_FUSED_BNBWD"));
-        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, no_fuse ? nullptr : &B.c1));       // conv2 is always stride 1
-        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true, !no_fuse));
+        // (a variant that fused bn1's backward reduction into this dgrad's epilogue was measured 6 % SLOWER end to
+        //  end -- the extra epilogue code bloats every conv kernel -- and was removed)
+        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
+        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
         LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
