@@ -8,7 +8,14 @@
 // read-modify-write accumulate, optional per-channel sum / sum-of-squares of the stored values.
 // s1 / s2: the caller's per-lane partial sum / sum of squares of the stored values (accumulated here, reduced and
 // published by conv_stats_flush -- once per tile, or once per block in the persistent kernel).
-template <int BM, int BN, int WM, int WN>
+// EPM: epilogue mode fixed at compile time (dead branches cost registers and issue slots in every conv kernel):
+//   0 plain store, 1 store + per-channel statistics (train forward), 2 accumulate onto y (data gradient on top of
+//   the identity path), 3 eval epilogue (scale/shift, residual, ReLU); -1 decides at run time (legacy kernels).
+static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p) {
+    return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
+}
+
+template <int BM, int BN, int WM, int WN, int EPM = -1>
 static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
                                                      int mtile, int n0, float (&s1)[BN / WN / 16][4],
                                                      float (&s2)[BN / WN / 16][4], const ConvGeo& geo) {
@@ -25,6 +32,9 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     const int fq = lane >> 4;
     const int m0 = mtile * BM;
     const int HW = geo.Hs * geo.Ws;
+    const bool do_eval = EPM < 0 ? (p.ep_scale != nullptr) : (EPM == 3);
+    const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2);
+    const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
 
 #pragma unroll
@@ -39,12 +49,12 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
         const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp +
                              (xx * p.osub + geo.opw + p.ypad)) * p.yC;
         size_t roff = 0;
-        if (p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+        if (do_eval && p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
             const int n = n0 + wn * WTN + a * 16 + 4 * fq;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (p.ep_scale) {
+            if (do_eval) {
                 const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
                 const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
@@ -60,7 +70,7 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
                 }
             }
             bf16_t* dst = p.y + yoff + n;
-            if (p.accumulate && valid) {
+            if (do_acc && valid) {
                 const uint2 ov = *reinterpret_cast<const uint2*>(dst);
                 v[0] += bf2f((unsigned short)(ov.x & 0xffff)); v[1] += bf2f((unsigned short)(ov.x >> 16));
                 v[2] += bf2f((unsigned short)(ov.y & 0xffff)); v[3] += bf2f((unsigned short)(ov.y >> 16));
@@ -70,6 +80,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
             ov.y = pack2bf(v[2], v[3]);
             if (valid) {
                 *reinterpret_cast<uint2*>(dst) = ov;
+            }
+            if (do_stats && valid) {
                 // statistics are taken over the bf16-rounded values actually stored
                 const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
                 const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));

@@ -17,7 +17,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int EPM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM;          // pixels per wave
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
+    conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
 // ---------------------------------------------------------------------------
 // HB: halo buffers (1 when the conv has a single 64-channel chunk: the smaller footprint lets two blocks share a
 // CU and overlap each other's prologue / epilogue); WPS: launch-bounds waves per SIMD (4 = two blocks per CU).
-template <int BM, int BN, int HROWS, int HB, int WPS>
+template <int BM, int BN, int HROWS, int HB, int WPS, int EPM>
 __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
     constexpr int WN = BN / 64;
     constexpr int WM = 4 / WN;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
     for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
+    conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     conv_finalize_tail(p, smem);
 }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
 // four MFMA waves run the 9 taps x 2 K-halves of the current tile out of LDS without any barrier, then store.
 // One barrier per 128-pixel tile.
 // ---------------------------------------------------------------------------
-template <int HROWS>
+template <int HROWS, int EPM>
 __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles) {
     constexpr int BM = 128, BN = 64, WM = 4, WN = 1;
     constexpr int WTM = BM / WM;
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN>(p, acc, t, 0, st1, st2, geo);
+        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
@@ -606,7 +606,12 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
     const size_t lds = ((size_t)9 * 64 + 2 * HROWS) * 64 * sizeof(bf16_t) + 2048;
     ConvParams q = p;
     q.fin.nblocks = grid;
-    hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS>), dim3(grid), dim3(512), lds, stream, q, g, ntiles);
+    switch (conv_ep_mode(q)) {
+        case 0: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 1: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 2: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        default: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+    }
     return hipGetLastError();
 }
 
@@ -616,7 +621,12 @@ static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t 
     const size_t lds = ((size_t)HB * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS>), grid, dim3(512), lds, stream, q, g);
+    switch (conv_ep_mode(q)) {
+        case 0: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0>), grid, dim3(512), lds, stream, q, g); break;
+        case 1: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1>), grid, dim3(512), lds, stream, q, g); break;
+        case 2: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2>), grid, dim3(512), lds, stream, q, g); break;
+        default: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3>), grid, dim3(512), lds, stream, q, g); break;
+    }
     return hipGetLastError();
 }
 
@@ -661,7 +671,12 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), lds, stream, q);
+    switch (conv_ep_mode(q)) {
+        case 0: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, q); break;
+        default: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, stream, q); break;
+    }
     return hipGetLastError();
 }
 
