@@ -203,6 +203,7 @@ hipError_t vpd_launch_stem_pool(const StemPoolParams& p, hipStream_t s) {
 // Each block owns `ppb` consecutive pixels; a thread owns 8 channels.
 // partials layout [T][2][C].
 // ---------------------------------------------------------------------------
+template <int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p) {
     __shared__ float sh[256][17];
     const int cv = p.C >> 3;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
     *reinterpret_cast<float4*>(rs + 4) = *reinterpret_cast<const float4*>(p.rstd + c + 4);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { msc[j] = 0.f; msh[j] = 1.f; }
-    if (p.mscale) {
+    if (MASK == 2) {
         *reinterpret_cast<float4*>(msc) = *reinterpret_cast<const float4*>(p.mscale + c);
         *reinterpret_cast<float4*>(msc + 4) = *reinterpret_cast<const float4*>(p.mscale + c + 4);
         *reinterpret_cast<float4*>(msh) = *reinterpret_cast<const float4*>(p.mshift + c);
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
             float g[8], z[8];
             unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.C + c), g);
             unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
-            if (p.act) {
+            if (MASK == 1) {
                 const int b = m / HW;
                 const int r = m - b * HW;
                 const int y = r / p.W;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
                             p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * p.C + c), a);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
-            } else if (p.mscale) {
+            } else if (MASK == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
             }
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 }
 
 // pass 2: dz = c1 * (g - c2 - xhat * c3); optionally write g back over dy
+template <int MASK, int WRITE_G>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) {
     const int cv = p.C >> 3;
     const long total = (long)p.M * cv;
@@ -299,14 +301,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
         float g[8], z[8], mu[8], rs[8], c1[8], c2[8], c3[8];
         unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.C + c), g);
         unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * p.C + c), z);
-        if (p.act) {
+        if (MASK == 1) {
             float a[8];
             unpack8(*reinterpret_cast<const uint4*>(
                         p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * p.C + c), a);
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
-            if (p.write_g) *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * p.C + c) = pack8(g);
-        } else if (p.mscale) {
+            if (WRITE_G) *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * p.C + c) = pack8(g);
+        } else if (MASK == 2) {
             float msc[8], msh[8];
             *reinterpret_cast<float4*>(msc) = *reinterpret_cast<const float4*>(p.mscale + c);
             *reinterpret_cast<float4*>(msc + 4) = *reinterpret_cast<const float4*>(p.mscale + c + 4);
@@ -343,11 +345,20 @@ hipError_t vpd_launch_bn_bwd(const BnBwdParams& p0, float count, const float* ga
     if (p.C % 8 || p.C > 2048 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     // reduce_done: the producing data-gradient kernel already masked dy and accumulated (sum g, sum g*xhat)
-    if (!reduce_done) hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(T), dim3(256), 0, s, p);
+    const int mask = p.act ? 1 : (p.mscale ? 2 : 0);
+    if (!reduce_done) {
+        if (mask == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(T), dim3(256), 0, s, p);
+        else if (mask == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(T), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(T), dim3(256), 0, s, p);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, s, p.partials,
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, p.coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid((long)p.M * (p.C / 8))), dim3(256), 0, s, p);
+    const dim3 ag(ew_grid((long)p.M * (p.C / 8)));
+    if (mask == 1 && p.write_g) hipLaunchKernelGGL((bn_bwd_apply_kernel<1, 1>), ag, dim3(256), 0, s, p);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_apply_kernel<1, 0>), ag, dim3(256), 0, s, p);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<2, 0>), ag, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<0, 0>), ag, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

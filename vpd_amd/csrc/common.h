@@ -12,6 +12,13 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VPD_WAVE 64
+// Diagnostics (tools/bench_conv.py, VPD_ABLATE env) are compiled in only with -DVPD_ENABLE_ABLATE: even never-taken
+// branches cost registers and issue slots in the hot loops.
+#ifdef VPD_ENABLE_ABLATE
+#define VPD_ABL(p, bit) ((p).ablate & (bit))
+#else
+#define VPD_ABL(p, bit) 0
+#endif
 // per-channel statistics are accumulated into this many [2][C] fp32 rows (row = producer block % rows)
 #define VPD_STAT_ROWS 16
 

@@ -261,9 +261,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
             // are past the previous step's LDS reads
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (step + 1 < nsteps && !(p.ablate & 1)) issue_w(step + 1, (step + 1) & 1);
-            if (HALO2 && tap == 0 && cc + 1 < nchunks && !(p.ablate & 4)) issue_halo(cc + 1, (cc + 1) & 1);
-            if (p.ablate & 2) continue;
+            if (step + 1 < nsteps && !VPD_ABL(p, 1)) issue_w(step + 1, (step + 1) & 1);
+            if (HALO2 && tap == 0 && cc + 1 < nchunks && !VPD_ABL(p, 4)) issue_halo(cc + 1, (cc + 1) & 1);
+            if (VPD_ABL(p, 2)) continue;
 
             const int ir = tap / 3, ic = tap - ir * 3;
             const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
             if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
             __builtin_amdgcn_s_barrier();                         // READY_s
             const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;   // tail: harmless reload into a free stage
-            if (p.ablate & 1) continue;
+            if (VPD_ABL(p, 1)) continue;
             issue_w(sw, (s + 2) % NS);
             const int cc = s / 9;
             const int tap = s - cc * 9;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         const bf16_t* cH = sH + (cc & (HB - 1)) * HBUF;
         for (int tap = 0; tap < 9; ++tap, ++s) {
             __builtin_amdgcn_s_barrier();                         // READY_s
-            if (p.ablate & 2) continue;
+            if (VPD_ABL(p, 2)) continue;
             const int ir = tap / 3, ic = tap - ir * 3;
             const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
             const bf16_t* cW = sW + (s % NS) * WSTAGE;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         __builtin_amdgcn_s_barrier();                             // B_0
         int i = 0;
         for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
-            if (t + G < ntiles && !(p.ablate & 4)) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
+            if (t + G < ntiles && !VPD_ABL(p, 4)) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (p.ablate & 2) break;
+            if (VPD_ABL(p, 2)) break;
             const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
             const bf16_t* cW = sW + tap * BN * 64;
 #pragma unroll
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (!(p.ablate & 8)) conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        if (!VPD_ABL(p, 8)) conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);

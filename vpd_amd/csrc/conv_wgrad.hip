@@ -254,7 +254,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 
     for (int c = 0; c < nch; ++c) {
         __builtin_amdgcn_s_barrier();                             // READY_c
-        if (p.ablate & 2) continue;
+        if (VPD_ABL(p, 2)) continue;
         const bf16_t* st = ring + (c % 3) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -273,7 +273,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
     }
 
     // acc[t][a][j] = partial dW[tap T0+t][co0 + a*16 + 4*gq + j][ci0 + 16*ctile + i16]
-    if (p.ablate & 8) return;
+    if (VPD_ABL(p, 8)) return;
     const int kct = p.Kc >> 6;
     const int co0 = (blockIdx.x / kct) * 64;
     const int ci0 = (blockIdx.x % kct) * 64;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
                 __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + WG_CH * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
         };
-        if (p.ablate & 1) {
+        if (VPD_ABL(p, 1)) {
             for (int c = 0; c < nch; ++c) __builtin_amdgcn_s_barrier();
             return;
         }
@@ -461,7 +461,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
-        if (p.defer_reduce || (p.ablate & 16)) return hipGetLastError();
+        if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
         return vpd_launch_wgrad_reduce(p, stream);
     }
     const int tiles = (p.Co / 64) * (p.Kc / 64) * p.taps.nr * p.taps.nc;
