@@ -31,38 +31,52 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
 #define PACK_CHUNK 1024
 #define SLAB_CHUNK 64        // outputs per block of the slab-summing branch of unpack_grads_kernel
 
-// master fp32 OIHW -> bf16 forward layout [tap][Co][Kc] and dgrad layout [tap][Ci][Co]
+// master fp32 OIHW -> bf16 forward layout [tap][Co][Ci] and dgrad layout [tap][Ci][Co].
+// One block transposes a 32(co) x 32(ci) x taps tile through LDS: the OIHW reads are 32 contiguous runs of
+// 32*taps floats, the forward layout is written in 64-byte runs along ci and the dgrad layout in 64-byte runs
+// along co (a plain element-wise gather re-fetched every source line ~5x: FETCH_SIZE 410 MB for 85 MB of weights).
+// The stem (7x7, Ci <= 8, row-tap packing with zero fill) keeps the element-wise form.
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* descs, const int* blockmap,
                                                            const float* master, bf16_t* arena) {
+    __shared__ float tile[32][32 * 9 + 1];
     const PackDesc d = descs[blockmap[2 * blockIdx.x]];
-    const long e0 = (long)blockmap[2 * blockIdx.x + 1] * PACK_CHUNK;
+    const int chunk = blockmap[2 * blockIdx.x + 1];
     const float* src = master + d.src_off;
     const int khw = d.kh * d.kw;
-    const long nf = (long)d.ntaps * d.Co * d.Kc;
-    for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < nf; e += 256) {
-        const int kc = (int)(e % d.Kc);
-        const long q = e / d.Kc;
-        const int co = (int)(q % d.Co);
-        const int tap = (int)(q / d.Co);
-        float v = 0.f;
-        if (d.stem) {                   // tap = kernel row r; kc = t*8 + c
+    if (d.stem) {
+        const long e0 = (long)chunk * PACK_CHUNK;
+        const long nf = (long)d.ntaps * d.Co * d.Kc;
+        for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < nf; e += 256) {
+            const int kc = (int)(e % d.Kc);
+            const long q = e / d.Kc;
+            const int co = (int)(q % d.Co);
+            const int tap = (int)(q / d.Co);      // tap = kernel row r; kc = t*8 + c
             const int t = kc >> 3, c = kc & 7;
+            float v = 0.f;
             if (t < d.kw && c < d.Ci) v = src[((size_t)(co * d.Ci + c) * d.kh + tap) * d.kw + t];
-        } else {
-            v = src[((size_t)co * d.Ci + kc) * khw + tap];
+            arena[d.fwd_off + e] = (bf16_t)v;
         }
-        arena[d.fwd_off + e] = (bf16_t)v;
+        return;
     }
-    if (d.dgr_off >= 0) {
-        const long nd = (long)khw * d.Ci * d.Co;
-        for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < nd; e += 256) {
-            const int co = (int)(e % d.Co);
-            const long q = e / d.Co;
-            const int ci = (int)(q % d.Ci);
-            const int tap = (int)(q / d.Ci);
-            arena[d.dgr_off + e] = (bf16_t)src[((size_t)co * d.Ci + ci) * khw + tap];
+    const int tci = d.Ci >> 5;
+    const int co0 = (chunk / tci) * 32, ci0 = (chunk % tci) * 32;
+    const int run = 32 * khw;                      // contiguous floats per co row of the tile
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int r = i / run, k = i - r * run;
+        tile[r][k] = src[((size_t)(co0 + r) * d.Ci + ci0) * khw + k];
+    }
+    __syncthreads();
+    // forward: dst[(tap*Co + co)*Ci + ci]; lanes run along ci
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+        const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+        arena[d.fwd_off + ((size_t)tap * d.Co + co0 + co) * d.Ci + ci0 + ci] = (bf16_t)tile[co][ci * khw + tap];
+    }
+    // dgrad: dst[(tap*Ci + ci)*Co + co]; lanes run along co
+    if (d.dgr_off >= 0)
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {
+            const int co = i & 31, ci = (i >> 5) & 31, tap = i >> 10;
+            arena[d.dgr_off + ((size_t)tap * d.Ci + ci0 + ci) * d.Co + co0 + co] = (bf16_t)tile[co][ci * khw + tap];
         }
-    }
 }
 hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* master, bf16_t* arena, hipStream_t s) {

@@ -270,7 +270,9 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         const long long nf = (long long)c.ntaps * c.Co * c.Kc;
         const long long ns = (long long)c.Co * c.Ci * c.k * c.k;
         const long long npk = nf > ns ? nf : ns;
-        for (long long ch = 0; ch * 1024 < npk; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
+        // pack kernel: 32x32 (co x ci) tiles for ordinary convs, PACK_CHUNK element chunks for the stem
+        const long long npack = c.stem ? (npk + 1023) / 1024 : (long long)(c.Co / 32) * (c.Ci / 32);
+        for (long long ch = 0; ch < npack; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
         const long long uchunk = d.slab_off >= 0 ? 64 : 1024;     // SLAB_CHUNK / PACK_CHUNK of unpack_grads_kernel
         for (long long ch = 0; ch * uchunk < ns; ++ch) {
             p->bmap_unpack[bucket].push_back(id);
