@@ -615,6 +615,152 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Persistent stem convolution (7x7 stride 2 on the 8-channel, border-3 NHWC input; 64 output channels).
+// A tile is 128 output pixels of whole output rows; the 2*TR+5 raw input rows it needs are one contiguous
+// range, staged ONCE per tile by LDS-DMA (plain copy: the 32-byte pixel pitch of consecutive output
+// pixels is already bank-conflict free for ds_read_b128).  Each of the 7 kernel rows is one 64-deep K-step
+// whose pixel fragments are read straight out of the raw rows (8 column taps x 8 channels contiguous),
+// instead of the gather kernel's 7 x 128 B per output pixel (14x read amplification).  The 7 weight
+// taps (56 KiB) stay resident; structure as conv3x3_c64_persistent_kernel.
+// ---------------------------------------------------------------------------
+template <int HROWS, int EPM>
+__global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvParams p, int TR, int ntiles, long xelems) {
+    constexpr int BM = 128, BN = 64, WM = 4, WN = 1;
+    constexpr int WTM = BM / WM;
+    constexpr int MI = WTM / 16, NI = 4;
+    constexpr int HBUF = HROWS * 64;
+    constexpr int HPASS = HROWS / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                 // [7][64*64] resident weights
+    bf16_t* sH = sW + 7 * BN * 64;                                // [2][HBUF] raw input rows
+    unsigned char* red = reinterpret_cast<unsigned char*>(sH + 2 * HBUF);
+
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W0 = p.Ws, H0 = p.Hs, Wp = p.xWp, Hp = p.xHp;
+    const int G = gridDim.x;
+
+    if (wave >= 4) {
+        const int lw = wave - 4;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        auto issue_rows = [&](int mtile, int buf) __attribute__((always_inline)) {
+            const int gr0 = mtile * TR;                           // global output row = b*H0 + y0
+            const int b = gr0 / H0, y0 = gr0 - b * H0;
+            const long e0 = ((long)(b * Hp + 2 * y0) * Wp) * 8;   // first element of input row 2*y0 (padded coords)
+#pragma unroll
+            for (int k = 0; k < HPASS; ++k) {
+                const int row = (lw + 4 * k) * 8 + lrow;
+                long e = e0 + (long)row * 64 + piece * 8;
+                e = e < xelems - 8 ? e : xelems - 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.x + e), (lptr_t)(sH + buf * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const int wsl = p.taps.w0 + t * p.taps.wrs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = (lw + 4 * i) * 8 + lrow;
+                const bf16_t* src = p.w + ((size_t)wsl * 64 + n) * 64 + ((piece ^ (n & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        }
+        issue_rows(blockIdx.x, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // B_0
+        int i = 0;
+        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+            if (t + G < ntiles) issue_rows(t + G, (i + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // B_{i+1}
+        }
+        if (EPM == 1) __builtin_amdgcn_s_barrier();               // matches the barrier inside conv_stats_flush
+        conv_finalize_tail(p, red);
+        return;
+    }
+
+    const int wm = wave;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    int pbase[MI];                                                // element offset of (input row 2*lr, pixel 2*xx) in the tile
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = wm * WTM + b * 16 + fr;
+        const int lr = m / W0;
+        const int xx = m - lr * W0;
+        pbase[b] = (2 * lr * Wp + 2 * xx) * 8;
+    }
+    float st1[NI][4], st2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    __builtin_amdgcn_s_barrier();                                 // B_0
+    int i = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+        const bf16_t* cH = sH + (i & 1) * HBUF;
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const bf16_t* cW = sW + r * BN * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfm[MI];
+                const int chunk = kk * 4 + fq;                    // column tap t = chunk (8 channels each)
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int rr = a * 16 + fr;
+                    af[a] = *reinterpret_cast<const bf16x8*>(cW + rr * 64 + ((chunk ^ (rr & 7)) << 3));
+                }
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + pbase[b] + (r * Wp + chunk) * 8);
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        __builtin_amdgcn_s_barrier();                             // B_{i+1}
+    }
+    if (EPM == 1) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
+    conv_finalize_tail(p, red);
+}
+
+// stem shape test + launch; returns false when the generic gather kernel has to take it
+static bool stem_eligible(const ConvParams& p, int* TR) {
+    if (!(p.xC == 8 && p.Kc == 64 && p.Co == 64 && p.istr == 2 && p.osub == 1 && p.taps.nr == 7 && p.taps.nc == 1 &&
+          p.taps.dy0 == 0 && p.taps.dys == 1 && p.taps.dx0 == 0 && p.ypad == 0 && !p.accumulate && !p.ep_scale))
+        return false;
+    if (p.Ws <= 0 || 128 % p.Ws != 0) return false;
+    *TR = 128 / p.Ws;
+    if (*TR > p.Hs || p.Hs % *TR != 0) return false;
+    const int rows = ((2 * *TR + 5) * p.xWp + 7) / 8;            // 128-byte LDS rows of the raw input range
+    return rows <= 160 && p.M % 128 == 0;
+}
+
+static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
+    const int ntiles = p.M / 128;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048;
+    const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
+    ConvParams q = p;
+    q.fin.nblocks = grid;
+    if (p.stats) hipLaunchKernelGGL((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
+    else hipLaunchKernelGGL((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int HROWS, int HB, int WPS>
 static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
@@ -693,8 +839,11 @@ extern "C" int vpd_conv_bm(int M, int Co) {
 // Kernel selection = timing class of vpd_plan_read_timing (one class per kernel function):
 //   0 conv3x3_c64_persistent_kernel<224>   1 conv3x3_ws_kernel<256,128,352>   2 conv3x3_ws_kernel<128,128,288>
 //   3 conv3x3_ws_kernel<128,64,288>        4 conv_igemm_kernel (gather; also the legacy conv3x3_halo fallback)
+//   5 conv_stem_persistent_kernel<160>
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
     static const int no_ws = getenv("VPD_NO_WS") ? atoi(getenv("VPD_NO_WS")) : 0;
+    int tr_stem;
+    if (!no_ws && stem_eligible(p, &tr_stem)) return 5;        // conv_stem_persistent_kernel
     if (halo_eligible(p) && !no_ws) {
         if (p.Co % 128 == 0) {
             const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
@@ -720,6 +869,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         case 1: return launch_ws<256, 128, 352, 2, 2>(p, g, stream);
         case 2: return launch_ws<128, 128, 288, 2, 2>(p, g, stream);
         case 3: return launch_ws<128, 64, 288, 2, 2>(p, g, stream);
+        case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }
     // the statistics accumulator rows only depend on the block index, so the tile choice is free

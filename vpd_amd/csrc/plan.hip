@@ -490,7 +490,8 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         q.fin.scale = c.bn_scale(cv.bn); q.fin.shift = c.bn_shift(cv.bn);
         q.fin.count = (float)q.M; q.fin.momentum = kBnMomentum; q.fin.eps = kBnEps;
     }
-    TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
+    const int kc = vpd_conv_kernel_class(q);
+    TimeScope ts(c.p, c.s, kc == 5 ? 7 : kc, conv_flops(cv, c.n));      // slot 7: stem kernel (5, 6 are the wgrads)
     return vpd_launch_conv(q, c.s);
 }
 
@@ -918,7 +919,7 @@ extern "C" int vpd_plan_set_timing(vpd_plan_t* p, int enable) {
 
 // Sums (and clears) the recorded launches: out[4*cls + {0,1,2}] = {launches, milliseconds, flops}
 extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
-    if (!p || !out || nclasses < 7) return fail("bad argument");
+    if (!p || !out || nclasses < 8) return fail("bad argument");
     for (int i = 0; i < 3 * nclasses; ++i) out[i] = 0.0;
     for (auto& t : p->timed) {
         HCHECK(hipEventSynchronize(t.b));
