@@ -209,9 +209,11 @@ def test_stem_conv_and_wgrad():
 
     L = _lib()
     dzd = dz.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-    dw = torch.zeros(7, co, 64, dtype=torch.float32, device="cuda")
-    _check(L.vpd_op_wgrad(ptr(dzd), ptr(xp), ptr(dw), n, ho, wo, co, 0, h + 6, w + 8, 8, ho, wo, 2, 64, co, taps,
-                          None, stream()))
-    torch.cuda.synchronize()
-    got = dw.cpu().view(7, co, 8, 8)[:, :, :7, :c].permute(1, 3, 0, 2)   # -> [co][c][r][t]
-    assert rel_l2(got, wr.grad) < REL_TOL
+    slab = torch.empty(L.vpd_op_wgrad_slab_bytes() // 4, dtype=torch.float32, device="cuda")
+    for use_slab in (False, True):        # generic (atomics) kernel, then the raw-row stem kernel + slab
+        dw = torch.zeros(7, co, 64, dtype=torch.float32, device="cuda")
+        _check(L.vpd_op_wgrad(ptr(dzd), ptr(xp), ptr(dw), n, ho, wo, co, 0, h + 6, w + 8, 8, ho, wo, 2, 64, co, taps,
+                              ptr(slab) if use_slab else None, stream()))
+        torch.cuda.synchronize()
+        got = dw.cpu().view(7, co, 8, 8)[:, :, :7, :c].permute(1, 3, 0, 2)   # -> [co][c][r][t]
+        assert rel_l2(got, wr.grad) < REL_TOL, use_slab

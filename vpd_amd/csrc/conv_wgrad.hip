@@ -379,6 +379,163 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
     else wgrad_mfma_half<5, 9>(p, g, ring, STAGE, nch, ctile, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Stem weight gradient (7x7 stride 2, 8-channel border-3 input, 64 output channels):
+//   dw[r][co][t*8 + c] += sum_m dz[m][co] * xin[2y + r][2x + t][c]
+// Same structure as conv_wgrad_halo_kernel (loader waves, 3-stage ring of 64-pixel chunks, two MFMA waves per
+// SIMD with the 7 kernel rows split 4 / 3, slab + reduce), but the x operand is the RAW input rows of the chunk
+// (one contiguous range, plain LDS-DMA copy): the transposing read takes a per-lane address, so the 64 values
+// (8 column taps x 8 channels) of an output pixel are read in place at its 32-byte pixel pitch -- the gather
+// kernel staged 7 x 128 B per output pixel instead of 64 B.
+// ---------------------------------------------------------------------------
+template <int R0, int R1>
+static __device__ __forceinline__ void wgrad_stem_half(const WgradParams& p, const bf16_t* ring, int STAGE, int nch,
+                                                       int ctile, int lane) {
+    constexpr int NT = R1 - R0;
+    const int W0 = p.Ws, Wp = p.xWp;
+    f32x4 acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    int offA[4][2], baseB[2][2];
+    {
+        const int ra = 8 * gq + q;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = ra + 4 * h;
+                const int col = a * 16 + 4 * pp;
+                offA[a][h] = r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pk = 32 * ks + 8 * gq + 4 * h + q;      // output pixel of the chunk this lane addresses
+                const int lr = pk / W0;
+                const int xx = pk - lr * W0;
+                baseB[ks][h] = 64 * 64 + (2 * lr * Wp + 2 * xx) * 8 + ctile * 16 + 4 * pp;
+            }
+    }
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    auto frag = [&](const bf16_t* st, int o0, int o1) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(st + o1));
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    for (int c = 0; c < nch; ++c) {
+        __builtin_amdgcn_s_barrier();                             // READY_c
+        const bf16_t* st = ring + (c % 3) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 az[4], bx[NT];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) az[a] = frag(st + ks * 32 * 64, offA[a][0], offA[a][1]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ro = (R0 + t) * Wp * 8;
+                bx[t] = frag(st, baseB[ks][0] + ro, baseB[ks][1] + ro);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[t], acc[t][a], 0, 0, 0);
+        }
+    }
+    // acc[t][a][j] = partial dW[row R0+t][co a*16 + 4*gq + j][16*ctile + i16]
+    float* slab = p.slab + (size_t)blockIdx.y * 7 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* o = slab + ((size_t)(R0 + t) * 64) * 64 + 16 * ctile + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * 64] = acc[t][a][j];
+    }
+}
+
+__global__ __launch_bounds__(768) void conv_wgrad_stem_kernel(const WgradParams p, int TR, int cpb, long xelems) {
+    constexpr int NPASS = 4, HROWS = 32 * NPASS;
+    constexpr int STAGE = (64 + HROWS) * 64;
+    constexpr int PER_CHUNK = 2 + NPASS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W0 = p.Ws, H0 = p.Hs;
+    const int nchunks_total = (p.M + 63) / 64;
+    const int chunk_begin = blockIdx.y * cpb;
+    int chunk_end = chunk_begin + cpb;
+    chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
+    const int nch = chunk_end - chunk_begin;
+
+    if (wave >= 8) {
+        const int lw = wave - 8;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        auto issue = [&](int c) __attribute__((always_inline)) {
+            const int ch = chunk_begin + c;
+            bf16_t* st = ring + (c % 3) * STAGE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (lw + 4 * i) * 8 + lrow;
+                const int m = ch * 64 + row;
+                const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+                const bf16_t* src = p.x + cpc * 8;                 // top border rows of image 0 are zero
+                if (m < p.M) {
+                    const int b = m / (H0 * W0);
+                    const int r = m - b * H0 * W0;
+                    const int yy = r / W0;
+                    const int xx = r - yy * W0;
+                    src = p.dz + ((size_t)(b * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + cpc * 8;
+                }
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+            const int gr0 = ch * TR;
+            const int b = gr0 / H0, y0 = gr0 - b * H0;
+            const long e0 = ((long)(b * p.xHp + 2 * y0) * p.xWp) * 8;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int row = (lw + 4 * i) * 8 + lrow;
+                long e = e0 + (long)row * 64 + piece * 8;
+                e = e < xelems - 8 ? e : xelems - 8;
+                __builtin_amdgcn_global_load_lds((wg_gptr_t)(p.x + e), (wg_lptr_t)(st + 64 * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        };
+        issue(0);
+        if (nch > 1) issue(1);
+        for (int c = 0; c < nch; ++c) {
+            if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + 2 < nch) issue(c + 2);
+        }
+        return;
+    }
+    const int ctile = wave & 3;
+    if (wave < 4) wgrad_stem_half<0, 4>(p, ring, STAGE, nch, ctile, lane);
+    else wgrad_stem_half<4, 7>(p, ring, STAGE, nch, ctile, lane);
+}
+
+static bool wg_stem_eligible(const WgradParams& p, int* TR) {
+    if (!(p.slab && p.xC == 8 && p.Kc == 64 && p.Co == 64 && p.istr == 2 && p.taps.nr == 7 && p.taps.nc == 1 &&
+          p.taps.dy0 == 0 && p.taps.dys == 1 && p.taps.dx0 == 0 && p.taps.w0 == 0 && p.taps.wrs == 1))
+        return false;
+    if (p.Ws <= 0 || 64 % p.Ws != 0) return false;
+    *TR = 64 / p.Ws;
+    if (*TR > p.Hs || p.Hs % *TR != 0 || p.M % 64 != 0) return false;
+    return ((2 * *TR + 5) * p.xWp + 7) / 8 <= 128;
+}
+
 // dw[e] = sum over all splits of slab[split][e].  A block owns 64 float4 outputs; its `groups` thread
 // groups each sum every groups-th split (coalesced 1-KiB rows), then one LDS pass adds the groups.
 __global__ __launch_bounds__(1024) void wgrad_slab_reduce_kernel(const float4* slab, float4* dw, long n4, int ksplit,
@@ -427,7 +584,10 @@ bool vpd_wgrad_halo_shape_ok(int H, int W) {
 }
 
 // true when vpd_launch_wgrad will take the halo + slab path, which OVERWRITES dw (no pre-zeroing needed)
+static bool wg_stem_eligible(const WgradParams& p, int* TR);
 bool vpd_wgrad_overwrites(const WgradParams& p) {
+    int tr_stem;
+    if (wg_stem_eligible(p, &tr_stem)) return true;
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
     WgHaloGeom g;
     return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && p.istr == 1 && p.xC == p.Kc && p.xHp == p.Hs + 2 &&
@@ -452,6 +612,21 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     WgradParams p = p0;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     p.ablate = ablate;
+    int tr_stem;
+    if (wg_stem_eligible(p, &tr_stem)) {
+        const int nchunks = p.M / 64;
+        int ksplit = nchunks < 256 ? nchunks : 256;
+        const int cpb = (nchunks + ksplit - 1) / ksplit;
+        ksplit = (nchunks + cpb - 1) / cpb;
+        const size_t lds = (size_t)3 * (64 + 128) * 64 * sizeof(bf16_t);
+        const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;
+        hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(1, ksplit), dim3(768), lds, stream, p, tr_stem, cpb, xelems);
+        const long n4 = (long)7 * 64 * 64 / 4;
+        const int groups = ksplit < 16 ? ksplit : 16;
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
+                           (const float4*)p.slab, (float4*)p.dw, n4, ksplit, groups);
+        return hipGetLastError();
+    }
     WgHaloGeom g;
     if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
         const int tiles = (p.Co / 64) * (p.Kc / 64);

@@ -166,6 +166,8 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     }
     c.wg_off = p->wg_elems;
     p->wg_elems += (long long)c.ntaps * Co * c.Kc;
+    if (stem && p->train && p->slab_elems == 0)      // the stem wgrad's split slab (shared region, summed at once)
+        p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
     if (!stem && k == 3 && stride == 1 && p->train && vpd_wgrad_halo_shape_ok(c.Hout, c.Wout)) {
         // halo wgrad conv.  Default: ONE shared slab, summed right after each wgrad launch while it is still in
         // the Infinity Cache (measured 45.5k crops/s).  VPD_DEFER_SLAB=1: per-conv slabs kept until one
@@ -173,7 +175,7 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
         static const bool defer = getenv("VPD_DEFER_SLAB") && atoi(getenv("VPD_DEFER_SLAB"));
         p->defer_slab = defer;
         c.slab_off = defer ? p->slab_elems : 0;
-        if (defer || p->slab_elems == 0) p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
+        if (defer) p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
     }
 }
 
@@ -566,7 +568,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.dw = c.f32(c.p->wg_off) + cv.wg_off;
-    q.slab = cv.slab_off >= 0 ? c.f32(c.p->slab_off) + cv.slab_off : nullptr;
+    q.slab = cv.slab_off >= 0 ? c.f32(c.p->slab_off) + cv.slab_off : (cv.stem ? c.f32(c.p->slab_off) : nullptr);
     q.defer_reduce = c.p->defer_slab ? 1 : 0;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
@@ -576,7 +578,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
         hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, st);
         if (e != hipSuccess) return e;
     }
-    if (vpd_wgrad_overwrites(q) && !q.defer_reduce) {      // time the MFMA kernel alone, then sum its slab
+    if (vpd_wgrad_overwrites(q) && !q.defer_reduce && !cv.stem) {      // time the MFMA kernel alone, then sum its slab
         hipError_t e;
         {
             TimeScope ts(c.p, st, 5, conv_flops(cv, c.n));
