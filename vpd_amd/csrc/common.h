@@ -44,6 +44,20 @@ static __device__ __forceinline__ uint4 pack8(const float* f) {
     v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
     return v;
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k..16k+15); every lane gets the total.  Four v_add_f32_dpp
+// (xor 1, xor 2 inside the quad, then the mirrored half and the mirrored row) instead of four ds_bpermute + add.
+template <int CTRL>
+static __device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);      // row_half_mirror
+    v += dpp_move<0x140>(v);      // row_mirror
+    return v;
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -117,12 +117,7 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
         for (int a = 0; a < NI; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float u = s1[a][j], v = s2[a][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    u += __shfl_xor(u, o, 64);
-                    v += __shfl_xor(v, o, 64);
-                }
+                const float u = row16_sum(s1[a][j]), v = row16_sum(s2[a][j]);
                 if (fr == 0) {
                     const int c = wn * WTN + a * 16 + 4 * fq + j;
                     red[(wm * 2 + 0) * BN + c] = u;
