@@ -50,8 +50,6 @@ struct PackDesc {                       // one convolution's weight tensors
     long long dgr_off;                  // bf16 [kh*kw][Ci][Co] offset (dgrad layout) or -1
     long long wg_off;                   // fp32 [ntaps][Co][Kc] offset in the wgrad scratch
     int Co, Ci, kh, kw, Kc, ntaps, stem;
-    long long slab_off;                 // fp32 element offset of this conv's split slabs, or -1 (gradient is in wg scratch)
-    int HWout;                          // output pixels per image (M = n * HWout decides the number of slabs)
 };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
@@ -95,6 +93,6 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
 hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* master, bf16_t* arena, hipStream_t s);
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
-                                   const float* wg, const float* slabs, int n, float* grads, hipStream_t s);
+                                   const float* wg, float* grads, hipStream_t s);
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                             double eps, double wd, int step, hipStream_t s);

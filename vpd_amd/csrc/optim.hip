@@ -29,7 +29,6 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
 }
 
 #define PACK_CHUNK 1024
-#define SLAB_CHUNK 64        // outputs per block of the slab-summing branch of unpack_grads_kernel
 
 // master fp32 OIHW -> bf16 forward layout [tap][Co][Ci] and dgrad layout [tap][Ci][Co].
 // One block transposes a 32(co) x 32(ci) x taps tile through LDS: the OIHW reads are 32 contiguous runs of
@@ -86,47 +85,13 @@ hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int
 }
 
 // Gradient of every conv of a bucket -> flat gradient buffer in the reference's OIHW order, one launch.
-//  * convs whose weight gradient sits in the wgrad scratch ([tap][Co][Kc] fp32): gather into OIHW;
-//  * convs computed by the halo kernel: sum their split slabs (slab[split][tap][Co][Ci], read in slab
-//    order so the loads are coalesced) and scatter the sums to OIHW.
+// Every conv's weight gradient sits in the wgrad scratch as [tap][Co][Kc] fp32: gather into OIHW.
 __global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* descs, const int* blockmap, const float* wg,
-                                                           const float* slabs, int n, float* grads) {
+                                                           float* grads) {
     const PackDesc d = descs[blockmap[2 * blockIdx.x]];
     const long e0 = (long)blockmap[2 * blockIdx.x + 1] * PACK_CHUNK;
     const int khw = d.kh * d.kw;
     const long ns = (long)d.Co * d.Ci * khw;
-    if (d.slab_off >= 0) {
-        // blocks of a slab conv own SLAB_CHUNK consecutive outputs (in [tap][Co][Ci] order); the four 64-thread
-        // groups each sum every fourth split, eight independent loads in flight, then combine through LDS
-        __shared__ float sh[4][SLAB_CHUNK];
-        const int ksplit = vpd_wgrad_split(n * d.HWout, d.Co, d.Kc, nullptr);
-        const float* sl = slabs + d.slab_off;
-        const int o = threadIdx.x & (SLAB_CHUNK - 1), gi = threadIdx.x / SLAB_CHUNK;
-        const long e = (long)blockmap[2 * blockIdx.x + 1] * SLAB_CHUNK + o;
-        float acc = 0.f;
-        if (e < ns) {
-            int s = gi;
-            for (; s + 28 < ksplit; s += 32) {
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = sl[(long)(s + 4 * k) * ns + e];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc += v[k];
-            }
-            for (; s < ksplit; s += 4) acc += sl[(long)s * ns + e];
-        }
-        sh[gi][o] = acc;
-        __syncthreads();
-        if (gi == 0 && e < ns) {
-            acc += sh[1][o] + sh[2][o] + sh[3][o];
-            const int ci = (int)(e % d.Ci);
-            const long q = e / d.Ci;
-            const int co = (int)(q % d.Co);
-            const int tap = (int)(q / d.Co);
-            grads[d.src_off + ((long)co * d.Ci + ci) * khw + tap] = acc;
-        }
-        return;
-    }
     const float* src = wg + d.wg_off;
     for (long e = e0 + threadIdx.x; e < e0 + PACK_CHUNK && e < ns; e += 256) {
         const int tap = (int)(e % khw);
@@ -144,9 +109,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* descs
     }
 }
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
-                                   const float* wg, const float* slabs, int n, float* grads, hipStream_t s) {
+                                   const float* wg, float* grads, hipStream_t s) {
     (void)ndesc;
-    hipLaunchKernelGGL(unpack_grads_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, wg, slabs, n, grads);
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, wg, grads);
     return hipGetLastError();
 }
 

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/vpd_hip.h"
@@ -95,7 +96,6 @@ struct vpd_plan {
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
     size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, slab_off = 0, ticket_off = 0;
     bool fused_fin = true;
-    bool defer_slab = false;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
@@ -169,13 +169,9 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     if (stem && p->train && p->slab_elems == 0)      // the stem wgrad's split slab (shared region, summed at once)
         p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
     if (!stem && k == 3 && stride == 1 && p->train && vpd_wgrad_halo_shape_ok(c.Hout, c.Wout)) {
-        // halo wgrad conv.  Default: ONE shared slab, summed right after each wgrad launch while it is still in
-        // the Infinity Cache (measured 45.5k crops/s).  VPD_DEFER_SLAB=1: per-conv slabs kept until one
-        // bucket-level reduce (fewer launches, but 490 MB of slabs fall out of the cache: 43.2k crops/s).
-        static const bool defer = getenv("VPD_DEFER_SLAB") && atoi(getenv("VPD_DEFER_SLAB"));
-        p->defer_slab = defer;
-        c.slab_off = defer ? p->slab_elems : 0;
-        if (defer) p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
+        // halo wgrad conv: ONE shared slab, summed right after each wgrad launch while it is still in the Infinity
+        // Cache (per-conv slabs summed once per bucket were measured 4 % slower: 490 MB fall out of the cache)
+        c.slab_off = 0;
     }
 }
 
@@ -266,7 +262,6 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         PackDesc d;
         d.src_off = c.w_off; d.fwd_off = c.fwd_off; d.dgr_off = c.dgr_off; d.wg_off = c.wg_off;
         d.Co = c.Co; d.Ci = c.Ci; d.kh = c.k; d.kw = c.k; d.Kc = c.Kc; d.ntaps = c.ntaps; d.stem = c.stem ? 1 : 0;
-        d.slab_off = p->defer_slab ? c.slab_off : -1; d.HWout = c.Hout * c.Wout;
         const int id = (int)p->descs.size();
         p->descs.push_back(d);
         const long long nf = (long long)c.ntaps * c.Co * c.Kc;
@@ -275,7 +270,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         // pack kernel: 32x32 (co x ci) tiles for ordinary convs, PACK_CHUNK element chunks for the stem
         const long long npack = c.stem ? (npk + 1023) / 1024 : (long long)(c.Co / 32) * (c.Ci / 32);
         for (long long ch = 0; ch < npack; ++ch) { p->bmap_pack.push_back(id); p->bmap_pack.push_back((int)ch); }
-        const long long uchunk = d.slab_off >= 0 ? 64 : 1024;     // SLAB_CHUNK / PACK_CHUNK of unpack_grads_kernel
+        const long long uchunk = 1024;     // PACK_CHUNK of unpack_grads_kernel
         for (long long ch = 0; ch * uchunk < ns; ++ch) {
             p->bmap_unpack[bucket].push_back(id);
             p->bmap_unpack[bucket].push_back((int)ch);
@@ -357,7 +352,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             S.dzd_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
-        p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
+        p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? 2 * p->slab_elems : 1) * 4);      // two slabs, used alternately
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
@@ -559,8 +554,11 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     return vpd_launch_conv(q, c.s);
 }
 
+// The halo kernel leaves split partials in a slab; `reduce` (may be null) is called instead of summing the slab on
+// `st`, so the caller can move that bandwidth-bound sum to a side stream, beside the next MFMA kernels.
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
-                          hipStream_t st) {
+                          hipStream_t st, int slab_index = 0,
+                          const std::function<hipError_t(const WgradParams&)>* reduce = nullptr) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -568,8 +566,9 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.dw = c.f32(c.p->wg_off) + cv.wg_off;
-    q.slab = cv.slab_off >= 0 ? c.f32(c.p->slab_off) + cv.slab_off : (cv.stem ? c.f32(c.p->slab_off) : nullptr);
-    q.defer_reduce = c.p->defer_slab ? 1 : 0;
+    float* slab = c.f32(c.p->slab_off) + (size_t)slab_index * c.p->slab_elems;
+    q.slab = cv.slab_off >= 0 ? slab + cv.slab_off : (cv.stem ? slab : nullptr);
+    q.defer_reduce = 0;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
@@ -586,7 +585,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
             e = vpd_launch_wgrad(q, st);
         }
         if (e != hipSuccess) return e;
-        return vpd_launch_wgrad_reduce(q, st);
+        return reduce ? (*reduce)(q) : vpd_launch_wgrad_reduce(q, st);
     }
     TimeScope ts(c.p, st, vpd_wgrad_overwrites(q) ? 5 : 6, conv_flops(cv, c.n));
     return vpd_launch_wgrad(q, st);
@@ -816,8 +815,41 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         }
         return p->ev_pool2[p->ev_next++];
     };
+    // VPD_SIDE_REDUCE=1 (experiment, measured 6 % SLOWER: 49.4k vs 52.5k crops/s on the same box): the 38 MB slab
+    // of each weight-gradient kernel is summed on `side` while the main stream goes on with the data gradient; two
+    // slabs alternate, so the next weight-gradient kernel only waits for the sum before last.  Like the two-stream
+    // backward, cross-stream hand-offs cost more than the overlap returns on this part.
+    static const bool side_reduce = getenv("VPD_SIDE_REDUCE") && atoi(getenv("VPD_SIDE_REDUCE"));
+    const bool sred = side_reduce && !fork;
+    if (sred && !p->side) LCHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    int slab_turn = 0;
+    hipEvent_t slab_free[2] = {nullptr, nullptr};
+    bool side_used = false;
+    const std::function<hipError_t(const WgradParams&)> reduce_on_side = [&](const WgradParams& q) -> hipError_t {
+        hipEvent_t e = next_event();
+        hipError_t r = hipEventRecord(e, s);
+        if (r != hipSuccess) return r;
+        r = hipStreamWaitEvent(p->side, e, 0);
+        if (r != hipSuccess) return r;
+        r = vpd_launch_wgrad_reduce(q, p->side);
+        if (r != hipSuccess) return r;
+        hipEvent_t f = next_event();
+        r = hipEventRecord(f, p->side);
+        slab_free[slab_turn] = f;
+        side_used = true;
+        return r;
+    };
     // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
     auto fork_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
+        if (sred && !cv.stem) {
+            slab_turn ^= 1;
+            if (slab_free[slab_turn]) {      // the sum that last read this slab
+                hipError_t r = hipStreamWaitEvent(s, slab_free[slab_turn], 0);
+                if (r != hipSuccess) return r;
+                slab_free[slab_turn] = nullptr;
+            }
+            return run_conv_wgrad(c, cv, dz, dzpad, x, s, slab_turn, &reduce_on_side);
+        }
         if (fork) {
             hipEvent_t e = next_event();
             hipError_t r = hipEventRecord(e, s);
@@ -830,7 +862,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     // main stream must not overwrite a dz buffer the side stream may still be reading
     hipEvent_t dz_free[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     auto join_side = [&]() -> hipError_t {      // main waits for everything enqueued on the side stream so far
-        if (!fork) return hipSuccess;
+        if (!fork && !(sred && side_used)) return hipSuccess;
         hipEvent_t e = next_event();
         hipError_t r = hipEventRecord(e, p->side);
         if (r != hipSuccess) return r;
@@ -842,7 +874,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         if (nb > 0)
             LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
                                            reinterpret_cast<const int*>(ws + p->bmap_unpack_off[b]), nb,
-                                           c.f32(p->wg_off), c.f32(p->slab_off), n, grads, s));
+                                           c.f32(p->wg_off), grads, s));
         if (bucket_events && bucket_events[b]) LCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
         return 0;
     };
@@ -897,6 +929,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
         LCHECK(vpd_launch_stem_pool_bwd(sb, (float)sb.M, params + p->stem.bn.w_off, grads + p->stem.bn.w_off,
                                         grads + p->stem.bn.b_off, c.bn_coef(p->stem.bn), c.b16(p->dz0_off), s));
+        LCHECK(join_side());      // the stem's kernel sums its own slab (slab 0) on the main stream
         LCHECK(fork_wgrad(p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
     }
     return unpack_bucket(3);
