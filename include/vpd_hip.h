@@ -78,6 +78,9 @@ int vpd_pack_weights(vpd_plan_t* plan, const float* params, const float* bn_runn
 int vpd_forward_eval(vpd_plan_t* plan, const float* params, const float* x, int n, float* emb_out,
                      const float* target, float* loss_step, double* loss_accum, void* workspace, void* stream);
 
+/* x == NULL in vpd_forward_eval / vpd_forward_train: the input batch was already written to the plan's stem staging
+ * buffer by vpd_plan_stage_crops (below); the fp32 NCHW batch is then never materialised. */
+
 /* Train-mode forward + loss: encoder(img) -> [fcn_time] -> F.mse_loss(reduction='sum')
  * (train_vpd_model.py:83-88) with train-mode BatchNorm (batch statistics, running-stat
  * update momentum 0.1).  target: f32 [N][emb_dim or 2*emb_dim].  loss_step[0] = this
@@ -101,6 +104,36 @@ int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam
 
 /* hipGraph-captured eval forward for a fixed batch size (apply_vpd_model.py:152-168 inner
  * loop at BATCH_SIZE crops per call).  Capture binds the pointers given here. */
+/* ---- train-time input pipeline on the device (the step right before the hot path) ----
+ * One item of GenericDataset.__getitem__ (vpd_dataset/single_frame.py:168-206) from the decoded PNGs on:
+ * u8 RGB -> /255 -> ColorJitter(brightness .2, contrast .2, saturation .05, hue .05) -> Normalize(mean, std)
+ * (vpd_dataset/common.py:52-60, :87-92), mask noise (single_frame.py:178-191), flow decode u8/255 - 0.5
+ * (common.py:62-69), concat + h-flip with x-flow negation (single_frame.py:193-203), RandomResizedCrop = crop +
+ * bilinear resize to out_dim (common.py:49-50, :80).  The random DECISIONS are the caller's (one vpd_aug_params per
+ * crop, sampled on the host in torchvision's order of draws); the device work is deterministic given them. */
+typedef struct vpd_aug_params {
+    int order[4];        /* ColorJitter ops in application order: 0 brightness, 1 contrast, 2 saturation, 3 hue; -1 = none */
+    float factor[4];     /* brightness, contrast, saturation factors, hue shift (indexed by op id) */
+    int flip;            /* h-flip (and negate flow x) */
+    int noise;           /* add noise_sd * N(0,1) to the normalised RGB where mask != 0 */
+    int crop_i, crop_j, crop_h, crop_w;   /* crop window (top, left, height, width) in the flipped image */
+    unsigned int seed_lo, seed_hi;        /* Philox key of the device noise generator (when noise == NULL) */
+} vpd_aug_params;
+
+/* rgb_u8 [n][height][width][3] (RGB), flow_u8 [n][height][width][2] (x, y) or NULL (3-channel model), mask_u8
+ * [n][height][width] or NULL, noise f32 [n][3][height][width] standard-normal draws or NULL (device Philox),
+ * params: DEVICE array of n; mean_std6: HOST array {mean r,g,b, std r,g,b}; scratch: n floats on the device.
+ * out_nchw: f32 [n][3 or 5][out_dim][out_dim] = the reference's batch['img'] (single_frame.py:206). */
+int vpd_augment_crops(const unsigned char* rgb_u8, const unsigned char* flow_u8, const unsigned char* mask_u8,
+                      const float* noise, const vpd_aug_params* params, int n, int height, int width, int out_dim,
+                      const float* mean_std6, float noise_sd, float* out_nchw, float* scratch, void* stream);
+/* Same pipeline, written straight into the plan's stem staging buffer (bf16 NHWC, zero border): follow with
+ * vpd_forward_train / vpd_forward_eval with x == NULL.  out_dim is the plan's img size. */
+int vpd_plan_stage_crops(vpd_plan_t* plan, const unsigned char* rgb_u8, const unsigned char* flow_u8,
+                         const unsigned char* mask_u8, const float* noise, const vpd_aug_params* params, int n,
+                         int height, int width, const float* mean_std6, float noise_sd, float* scratch,
+                         void* workspace, void* stream);
+
 int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x, int n, float* emb_out,
                            void* workspace, void* stream);
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);

@@ -1,0 +1,128 @@
+"""Device input pipeline (row f1) through the C ABI against its CPU oracle, on seeded u8 crops.
+
+Tolerance: the pipeline is fp32 elementwise arithmetic in torchvision's operation order (FMA contraction is
+switched off in augment.hip); what is left is the summation order of the contrast op's grey mean (a 16384-term
+fp32 sum) -> 2e-5 absolute on values of magnitude <= ~6."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-5
+MEAN_STD = ((0.3411329922282787, 0.46349889258964044, 0.5162481674015696),
+            (0.16302619019820488, 0.17092395707914718, 0.19266662199338647))
+
+
+def _crops(n, h, w, seed):
+    rs = np.random.RandomState(seed)
+    # smooth-ish images with flat regions (r == g == b ties and saturated pixels exercise the hue branches)
+    rgb = rs.randint(0, 256, (n, h, w, 3)).astype(np.uint8)
+    rgb[:, : h // 4, : w // 4, :] = rgb[:, : h // 4, : w // 4, :1]           # grey block
+    rgb[:, h // 2:, : w // 8, :] = 255                                          # white block
+    rgb[:, : h // 8, w // 2:, :] = 0                                            # black block
+    flow = np.clip(np.round(124 + 12 * rs.randn(n, h, w, 2)), 0, 255).astype(np.uint8)
+    mask = ((rs.rand(n, h, w) > 0.4) * 255).astype(np.uint8)
+    noise = rs.randn(n, 3, h, w).astype(np.float32)
+    return rgb, flow, mask, noise
+
+
+def _oracle_batch(rgb, flow, mask, noise, params, out_dim):
+    from oracle import augment_oracle as AO
+    outs = []
+    for k in range(rgb.shape[0]):
+        p = {'order': [int(v) for v in params['order'][k]], 'factors': tuple(float(v) for v in params['factor'][k]),
+             'flip': bool(params['flip'][k]), 'noise': bool(params['noise'][k]),
+             'crop': tuple(int(v) for v in params['crop'][k])}
+        outs.append(AO.augment_item(rgb[k], None if flow is None else flow[k], None if mask is None else mask[k],
+                                    None if noise is None else torch.from_numpy(noise[k]), p, MEAN_STD[0], MEAN_STD[1],
+                                    out_dim))
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("shape", [(6, 128, 128, 128, True), (5, 96, 112, 128, True), (4, 64, 64, 64, False)],
+                         ids=["128sq_flow", "96x112_to_128_flow", "64sq_rgb"])
+def test_augment_matches_oracle(shape):
+    from vpd_amd import augment as A
+    n, h, w, out_dim, use_flow = shape
+    rgb, flow, mask, noise = _crops(n, h, w, seed=n * 7 + h)
+    if not use_flow:
+        flow = None
+    params = A.sample_params(n, h, w, generator=torch.Generator().manual_seed(h + w))
+    params['noise'][0], params['noise'][1] = 1, 0
+    params['flip'][0], params['flip'][1] = 1, 0
+    params['order'][2] = (3, 1, 0, 2)          # hue and brightness before the contrast mean
+    params['order'][3] = (1, -1, -1, 3)        # a partial jitter
+    params['crop'][1] = (0, 0, h, w)           # full window (pure resize, or exact copy when h == w == out)
+    aug = A.CropAugmenter("cuda:0", MEAN_STD, out_dim, use_flow)
+    dev = lambda a: None if a is None else torch.from_numpy(a).cuda()
+    got = aug(dev(rgb), dev(flow), dev(mask), params, noise=dev(noise)).cpu()
+    exp = _oracle_batch(rgb, flow, mask, noise, params, out_dim)
+    assert got.shape == exp.shape == (n, 5 if use_flow else 3, out_dim, out_dim)
+    err = (got - exp).abs()
+    assert float(err.max()) <= ATOL, "max abs err %.3g at %s" % (float(err.max()), np.unravel_index(int(err.argmax()), err.shape))
+
+
+def test_no_augmentation_is_bit_exact_loader():
+    """identity_params: the device output equals (u8/255 - mean)/std and u8/255 - 0.5 bit for bit."""
+    from vpd_amd import augment as A
+    n, h = 3, 128
+    rgb, flow, _, _ = _crops(n, h, h, seed=1)
+    aug = A.CropAugmenter("cuda:0", MEAN_STD, h, True)
+    got = aug(torch.from_numpy(rgb).cuda(), torch.from_numpy(flow).cuda(), None, A.identity_params(n, h, h)).cpu()
+    exp = _oracle_batch(rgb, flow, None, None, A.identity_params(n, h, h), h)
+    assert torch.equal(got, exp)
+
+
+def test_device_noise_statistics_and_determinism():
+    from vpd_amd import augment as A
+    n, h = 4, 128
+    rgb, flow, mask, _ = _crops(n, h, h, seed=2)
+    p = A.identity_params(n, h, h)
+    p['noise'] = 1
+    p['seed'] = (1234, 5)
+    aug = A.CropAugmenter("cuda:0", MEAN_STD, h, True)
+    args = (torch.from_numpy(rgb).cuda(), torch.from_numpy(flow).cuda(), torch.from_numpy(mask).cuda())
+    a = aug(*args, p).cpu()
+    b = aug(*args, p).cpu()
+    assert torch.equal(a, b)                                   # counter-based: same key, same noise
+    clean = aug(*args, A.identity_params(n, h, h)).cpu()
+    d = (a - clean)[:, :3]
+    m = (torch.from_numpy(mask) != 0).unsqueeze(1).expand(-1, 3, -1, -1)
+    assert torch.all(d[~m] == 0) and torch.equal(a[:, 3:], clean[:, 3:])
+    z = d[m] / math.sqrt(0.05)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.1            # normal kurtosis
+    p2 = p.copy()
+    p2['seed'] = (1235, 5)
+    assert not torch.equal(aug(*args, p2).cpu(), a)
+
+
+def test_staged_input_equals_fp32_batch_path():
+    """vpd_plan_stage_crops + forward(x = NULL) == vpd_augment_crops -> fp32 batch -> forward(x): same embeddings
+    bit for bit (both round the same fp32 values to bf16 once)."""
+    from vpd_amd import augment as A
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    n, h = 6, 128
+    rgb, flow, mask, noise = _crops(n, h, h, seed=3)
+    params = A.sample_params(n, h, h, generator=torch.Generator().manual_seed(9))
+    enc = RGBF_EmbeddingModel("resnet18", 32, True, torch.device("cuda:0"))
+    enc.reset_parameters(seed=0)
+    eng = enc.engine
+    aug = A.CropAugmenter("cuda:0", MEAN_STD, h, True)
+    dv = [torch.from_numpy(a).cuda() for a in (rgb, flow, mask)]
+    nz = torch.from_numpy(noise).cuda()
+    img = aug(dv[0], dv[1], dv[2], params, noise=nz)
+    tgt = torch.randn(n, 32, device="cuda")
+    e1 = eng.forward_eval(img).clone()
+    staged = aug.stage(eng, dv[0], dv[1], dv[2], params, train=False, noise=nz)
+    e2 = eng.forward_eval(None, staged=staged).clone()
+    assert torch.equal(e1, e2)
+    enc.train()
+    t1 = eng.forward_train(img, tgt, accumulate_loss=False).clone()
+    l1 = float(eng.loss_step.item())
+    staged = aug.stage(eng, dv[0], dv[1], dv[2], params, train=True, noise=nz)
+    t2 = eng.forward_train(None, tgt, accumulate_loss=False, staged=staged).clone()
+    assert torch.equal(t1, t2) and l1 == float(eng.loss_step.item())

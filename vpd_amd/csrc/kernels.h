@@ -96,3 +96,10 @@ hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int
                                    const float* wg, float* grads, hipStream_t s);
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                             double eps, double wd, int step, hipStream_t s);
+
+// augment.hip (declared with the public vpd_aug_params of include/vpd_hip.h)
+struct vpd_aug_params;
+hipError_t vpd_launch_augment(const unsigned char* rgb, const unsigned char* flow, const unsigned char* mask,
+                              const float* noise, const vpd_aug_params* params, int N, int H, int W, int out_dim,
+                              const float* mean_std6, float noise_sd, float* out_nchw, bf16_t* xin, int xHp, int xWp,
+                              int xpad, float* cmean_scratch, hipStream_t s);

@@ -665,7 +665,7 @@ int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* 
 int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, float* emb_out, const float* target,
                      float* loss_step, double* loss_accum, char* ws, hipStream_t s) {
     Ctx c{p, ws, s, params, n};
-    LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
+    if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, false, nullptr, nullptr, nullptr, 0));
     {
         StemPoolParams sp;
@@ -729,7 +729,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
     LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes + 256, s));     // accumulator rows + ticket
-    LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
+    if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     // stem: conv -> batch stats -> BN+ReLU+maxpool
     LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0,
                         bn_running, p->fused_fin));
@@ -933,6 +933,32 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(fork_wgrad(p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
     }
     return unpack_bucket(3);
+}
+
+extern "C" int vpd_augment_crops(const unsigned char* rgb_u8, const unsigned char* flow_u8, const unsigned char* mask_u8,
+                                 const float* noise, const vpd_aug_params* params, int n, int height, int width,
+                                 int out_dim, const float* mean_std6, float noise_sd, float* out_nchw, float* scratch,
+                                 void* stream) {
+    if (!rgb_u8 || !params || !mean_std6 || !out_nchw || !scratch) return fail("null argument");
+    if (n < 1 || height < 1 || width < 1 || out_dim < 1) return fail("bad shape");
+    LCHECK(vpd_launch_augment(rgb_u8, flow_u8, mask_u8, noise, params, n, height, width, out_dim, mean_std6, noise_sd,
+                              out_nchw, nullptr, 0, 0, 0, scratch, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_plan_stage_crops(vpd_plan_t* p, const unsigned char* rgb_u8, const unsigned char* flow_u8,
+                                    const unsigned char* mask_u8, const float* noise, const vpd_aug_params* params,
+                                    int n, int height, int width, const float* mean_std6, float noise_sd,
+                                    float* scratch, void* workspace, void* stream) {
+    if (check_call(p, workspace, n)) return -1;
+    if (!rgb_u8 || !params || !mean_std6 || !scratch) return fail("null argument");
+    if (p->H != p->W) return fail("the input pipeline resizes to a square img_dim");
+    if ((p->c_in == 5) != (flow_u8 != nullptr)) return fail("flow_u8 must be given exactly when the plan has 5 input channels");
+    char* ws = (char*)workspace;
+    LCHECK(vpd_launch_augment(rgb_u8, flow_u8, mask_u8, noise, params, n, height, width, p->H, mean_std6, noise_sd,
+                              nullptr, reinterpret_cast<bf16_t*>(ws + p->xin_off), p->xHp, p->xWp, 3, scratch,
+                              (hipStream_t)stream));
+    return 0;
 }
 
 extern "C" int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,

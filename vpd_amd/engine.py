@@ -176,9 +176,13 @@ class StudentEngine:
         assert x.dtype == torch.float32 and x.is_contiguous() and x.is_cuda
 
     # -- forward / backward / step ---------------------------------------------
-    def forward_eval(self, x, target=None, motion=False, out=None, accumulate_loss=True):
-        self._check_input(x, self.c_in)
-        n, _, h, w = x.shape
+    def forward_eval(self, x, target=None, motion=False, out=None, accumulate_loss=True, staged=None):
+        if staged is not None:
+            n, h = staged
+            w = h
+        else:
+            self._check_input(x, self.c_in)
+            n, _, h, w = x.shape
         pl = self.plan(h, w, n, False, motion)
         self._ensure_packed(pl)
         emb = out if out is not None else torch.empty((n, self.emb_dim), dtype=torch.float32, device=self.device)
@@ -188,9 +192,25 @@ class StudentEngine:
                                      _ptr(pl.workspace), self._stream()), "vpd_forward_eval")
         return emb
 
-    def forward_train(self, x, target=None, motion=False, accumulate_loss=True):
-        self._check_input(x, self.c_in)
-        n, _, h, w = x.shape
+    def stage_crops(self, rgb_u8, flow_u8, mask_u8, params_dev, noise, img_dim, mean_std6, noise_sd, scratch, train,
+                    motion=False):
+        """Device input pipeline (vpd_amd.augment) writing straight into the plan's stem staging buffer; follow with
+        forward_train / forward_eval(x=None, staged=(n, img_dim))."""
+        n, h, w, _ = rgb_u8.shape
+        pl = self.plan(img_dim, img_dim, n, train, motion)
+        ms = (C.c_float * 6)(*mean_std6)
+        check(lib().vpd_plan_stage_crops(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), _ptr(mask_u8), _ptr(noise),
+                                         _ptr(params_dev), n, h, w, ms, float(noise_sd), _ptr(scratch),
+                                         _ptr(pl.workspace), self._stream()), "vpd_plan_stage_crops")
+        return pl
+
+    def forward_train(self, x, target=None, motion=False, accumulate_loss=True, staged=None):
+        if staged is not None:      # (n, img_dim): the batch is already in the staging buffer (stage_crops)
+            n, h = staged
+            w = h
+        else:
+            self._check_input(x, self.c_in)
+            n, _, h, w = x.shape
         pl = self.plan(h, w, n, True, motion)
         self._ensure_packed(pl)
         emb = torch.empty((n, self.emb_dim), dtype=torch.float32, device=self.device)
