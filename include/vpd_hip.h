@@ -122,7 +122,7 @@ typedef struct vpd_aug_params {
 
 /* rgb_u8 [n][height][width][3] (RGB), flow_u8 [n][height][width][2] (x, y) or NULL (3-channel model), mask_u8
  * [n][height][width] or NULL, noise f32 [n][3][height][width] standard-normal draws or NULL (device Philox),
- * params: DEVICE array of n; mean_std6: HOST array {mean r,g,b, std r,g,b}; scratch: n floats on the device.
+ * params: DEVICE array of n; mean_std6: HOST array {mean r,g,b, std r,g,b}; scratch: 8 * n floats on the device.
  * out_nchw: f32 [n][3 or 5][out_dim][out_dim] = the reference's batch['img'] (single_frame.py:206). */
 int vpd_augment_crops(const unsigned char* rgb_u8, const unsigned char* flow_u8, const unsigned char* mask_u8,
                       const float* noise, const vpd_aug_params* params, int n, int height, int width, int out_dim,

@@ -126,3 +126,30 @@ def test_staged_input_equals_fp32_batch_path():
     staged = aug.stage(eng, dv[0], dv[1], dv[2], params, train=True, noise=nz)
     t2 = eng.forward_train(None, tgt, accumulate_loss=False, staged=staged).clone()
     assert torch.equal(t1, t2) and l1 == float(eng.loss_step.item())
+
+
+def test_trainer_epoch_on_raw_u8_batches():
+    """ModelTrainer.epoch with an augmenter consumes raw u8 batches (device pipeline + staged forward) and, with
+    augmentation off, returns the same epoch loss as the fp32 batches of the same crops."""
+    from torch.utils.data import DataLoader
+    from vpd_amd import augment as A
+    from vpd_amd.data import SyntheticCrops
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    losses = []
+    for raw in (False, True):
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, torch.device("cuda:0"))
+        enc.reset_parameters(seed=0)
+        aug = A.CropAugmenter("cuda:0", MEAN_STD, 64, True) if raw else None
+        tr = ModelTrainer(enc, motion=False, augmenter=aug, augment=False)
+        opt, scaler = tr.get_optimizer(5e-4)
+        ds = SyntheticCrops(24, 5, 64, 32, False, MEAN_STD, seed=3, raw_u8=raw)
+        losses.append([tr.epoch(DataLoader(ds, batch_size=8), opt, scaler) for _ in range(2)])
+    assert losses[0] == losses[1], losses
+    # with augmentation on: runs, finite, and differs from the un-augmented loss
+    enc = RGBF_EmbeddingModel("resnet18", 32, True, torch.device("cuda:0"))
+    enc.reset_parameters(seed=0)
+    tr = ModelTrainer(enc, motion=False, augmenter=A.CropAugmenter("cuda:0", MEAN_STD, 64, True), augment=True)
+    opt, scaler = tr.get_optimizer(5e-4)
+    la = tr.epoch(DataLoader(SyntheticCrops(24, 5, 64, 32, False, MEAN_STD, seed=3, raw_u8=True), batch_size=8), opt, scaler)
+    assert math.isfinite(la) and la != losses[1][0]

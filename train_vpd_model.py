@@ -40,6 +40,9 @@ def get_args():
     # extensions (not in the reference)
     parser.add_argument('--synthetic', type=int, help='train on N seeded synthetic crops per epoch')
     parser.add_argument('--synthetic_emb_dim', type=int, default=128)
+    parser.add_argument('--gpu_augment', action='store_true',
+                        help='loaders hand over decoded u8 crops; ColorJitter / mask noise / RandomResizedCrop / '
+                             'normalisation run on the GPU (vpd_amd/augment.py) instead of flips-only on the CPU')
     return parser.parse_args()
 
 
@@ -59,7 +62,7 @@ def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
 
 def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, motion, encoder_arch, save_dir,
          model_select_window, checkpoint_frequency, pretrained, emb_dir, penn_dir, no_test_video, min_pose_score,
-         synthetic=None, synthetic_emb_dim=128):
+         synthetic=None, synthetic_emb_dim=128, gpu_augment=False):
     device = 'cuda'
     rank, world = 0, 1
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
@@ -71,7 +74,8 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     if synthetic is not None:
         use_flow = flow_img is not None
         emb_dim = synthetic_emb_dim
-        mk = lambda n, seed: SyntheticCrops(n, 5 if use_flow else 3, img_dim, emb_dim, motion, rgb_mean_std, seed)
+        mk = lambda n, seed: SyntheticCrops(n, 5 if use_flow else 3, img_dim, emb_dim, motion, rgb_mean_std, seed,
+                                            raw_u8=gpu_augment)
         train_dataset, val_dataset = mk(synthetic, 1 + rank), mk(max(synthetic // 5, 1), 1001 + rank)
     else:
         dataset_kwargs = {'img_dim': img_dim, 'flow_img_name': flow_img, 'embed_time': motion,
@@ -79,6 +83,7 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
         if min_pose_score is not None:
             dataset_kwargs['min_pose_score'] = min_pose_score
         train_dataset, val_dataset, emb_dim = load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video)
+        train_dataset.raw_u8 = val_dataset.raw_u8 = gpu_augment
 
     if rank == 0:
         print('Device:', device)
@@ -103,7 +108,11 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, flow_img is not None, device, pretrained=pretrained)
     if world > 1:      # same initial weights on every rank
         torch.distributed.broadcast(encoder.engine.params, 0)
-    trainer = ModelTrainer(encoder, motion)
+    augmenter = None
+    if gpu_augment:
+        from vpd_amd.augment import CropAugmenter
+        augmenter = CropAugmenter(encoder.device, rgb_mean_std, img_dim, flow_img is not None)
+    trainer = ModelTrainer(encoder, motion, augmenter=augmenter)
     optimizer, scaler = trainer.get_optimizer(learning_rate)
 
     if rank == 0:

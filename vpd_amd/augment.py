@@ -126,8 +126,8 @@ class CropAugmenter:
         c = params['crop']
         assert (c[:, 0] >= 0).all() and (c[:, 1] >= 0).all() and (c[:, 2] >= 1).all() and (c[:, 3] >= 1).all() and \
             (c[:, 0] + c[:, 2] <= h).all() and (c[:, 1] + c[:, 3] <= w).all(), 'crop window outside the image'
-        if self._scratch is None or self._scratch.numel() < n:
-            self._scratch = torch.empty(max(n, 256), dtype=torch.float32, device=self.device)
+        if self._scratch is None or self._scratch.numel() < 8 * n:       # 8 partial grey sums per crop
+            self._scratch = torch.empty(8 * max(n, 256), dtype=torch.float32, device=self.device)
         pdev = torch.from_numpy(params.view(np.uint8).reshape(n, 64)).to(self.device, non_blocking=True)
         return n, h, w, pdev
 

@@ -87,27 +87,38 @@ __device__ __forceinline__ Rgb load_rgb(const unsigned char* p) {
     return c;
 }
 
-// (1) grey mean of every crop at the point where its contrast op runs
+// (1) grey mean of every crop at the point where its contrast op runs.  AUG_MEAN_PARTS blocks per crop write partial
+// sums; the consumer adds them in a fixed order (deterministic, unlike atomics).
+#define AUG_MEAN_PARTS 8
 __global__ __launch_bounds__(256) void aug_contrast_mean_kernel(const unsigned char* rgb, const vpd_aug_params* params,
-                                                                int HW, float* cmean) {
+                                                                int HW, float* partial) {
     __shared__ float sh[4];
-    const int n = blockIdx.x;
+    const int n = blockIdx.y, part = blockIdx.x;
     const vpd_aug_params a = params[n];
     int kc = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (a.order[k] == 1) kc = k;
     if (kc < 0) {
-        if (threadIdx.x == 0) cmean[n] = 0.f;
+        if (threadIdx.x == 0) partial[n * AUG_MEAN_PARTS + part] = 0.f;
         return;
     }
     const unsigned char* img = rgb + (size_t)n * HW * 3;
+    const int per = (HW + AUG_MEAN_PARTS - 1) / AUG_MEAN_PARTS;
+    const int beg = part * per;
+    const int end = beg + per < HW ? beg + per : HW;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) acc += grey(jitter(load_rgb(img + 3 * (size_t)i), a, 0, kc, 0.f));
+    for (int i = beg + threadIdx.x; i < end; i += 256) acc += grey(jitter(load_rgb(img + 3 * (size_t)i), a, 0, kc, 0.f));
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) cmean[n] = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)HW;
+    if (threadIdx.x == 0) partial[n * AUG_MEAN_PARTS + part] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float aug_contrast_mean(const float* partial, int n, int HW) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < AUG_MEAN_PARTS; ++i) t += partial[n * AUG_MEAN_PARTS + i];
+    return t / (float)HW;
 }
 
 // Philox4x32-10 (Salmon et al. 2011): counter-based, so a source pixel's noise does not depend on who asks for it
@@ -192,37 +203,83 @@ __device__ __forceinline__ void bilinear_axis(int d, int in_size, int out_size, 
     *l0 = 1.f - w1;
 }
 
+#define AUG_ROWS 4            // output rows per block
+#define AUG_SRC_ROWS 8        // staged source rows (enough for any up-sampling and down-sampling up to 2x)
+#define AUG_SRC_W 256         // widest staged crop window
+
+__device__ __forceinline__ void aug_store(const AugArgs& g, int n, int oy, int ox, const float o[5]) {
+    if (g.out_nchw) {
+        const size_t plane = (size_t)g.out_dim * g.out_dim;
+        float* dst = g.out_nchw + (size_t)n * g.C * plane + (size_t)oy * g.out_dim + ox;
+        for (int c = 0; c < g.C; ++c) dst[c * plane] = o[c];
+    }
+    if (g.xin) {
+        float v8[8] = {o[0], o[1], o[2], o[3], o[4], 0.f, 0.f, 0.f};
+        *reinterpret_cast<uint4*>(g.xin + (((size_t)n * g.xHp + oy + g.xpad) * g.xWp + ox + g.xpad) * 8) = pack8(v8);
+    }
+}
+
+// One block = AUG_ROWS output rows of one crop.  The source rows they interpolate from are transformed ONCE into
+// LDS (jitter + hue cost ~1.5 k instructions per source pixel: the kernel is ALU-bound, so each source pixel must
+// not be recomputed by its four consumers), then every thread blends from LDS.
 __global__ __launch_bounds__(128) void aug_apply_kernel(const AugArgs g) {
+    __shared__ float src[AUG_SRC_ROWS][AUG_SRC_W][5];
     const int n = blockIdx.y;
-    const int oy = blockIdx.x;
+    const int oy0 = blockIdx.x * AUG_ROWS;
     const vpd_aug_params a = g.params[n];
-    const float cmean = g.cmean[n];
-    for (int ox = threadIdx.x; ox < g.out_dim; ox += 128) {
-        float o[5];
-        if (a.crop_h == g.out_dim && a.crop_w == g.out_dim) {      // no resize: exact copy of the window
-            source_pixel(g, a, n, cmean, a.crop_i + oy, a.crop_j + ox, o);
-        } else {
-            int y0, y1, x0, x1;
-            float ly0, ly1, lx0, lx1;
-            bilinear_axis(oy, a.crop_h, g.out_dim, &y0, &y1, &ly0, &ly1);
+    const float cmean = aug_contrast_mean(g.cmean, n, g.H * g.W);
+    int oy_last = oy0 + AUG_ROWS - 1;
+    oy_last = oy_last < g.out_dim ? oy_last : g.out_dim - 1;
+    if (a.crop_h == g.out_dim && a.crop_w == g.out_dim) {          // no resize: exact copy of the window
+        for (int oy = oy0; oy <= oy_last; ++oy)
+            for (int ox = threadIdx.x; ox < g.out_dim; ox += 128) {
+                float o[5];
+                source_pixel(g, a, n, cmean, a.crop_i + oy, a.crop_j + ox, o);
+                aug_store(g, n, oy, ox, o);
+            }
+        return;
+    }
+    int ya, yb, t0, t1;
+    float l0, l1;
+    bilinear_axis(oy0, a.crop_h, g.out_dim, &ya, &t1, &l0, &l1);
+    bilinear_axis(oy_last, a.crop_h, g.out_dim, &t0, &yb, &l0, &l1);
+    const int nrows = yb - ya + 1;
+    const bool staged = nrows <= AUG_SRC_ROWS && a.crop_w <= AUG_SRC_W;      // block-uniform
+    if (staged) {
+        for (int i = threadIdx.x; i < nrows * a.crop_w; i += 128) {
+            const int r = i / a.crop_w, x = i - r * a.crop_w;
+            float v[5];
+            source_pixel(g, a, n, cmean, a.crop_i + ya + r, a.crop_j + x, v);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) src[r][x][c] = v[c];
+        }
+        __syncthreads();
+    }
+    for (int oy = oy0; oy <= oy_last; ++oy) {
+        int y0, y1;
+        float ly0, ly1;
+        bilinear_axis(oy, a.crop_h, g.out_dim, &y0, &y1, &ly0, &ly1);
+        for (int ox = threadIdx.x; ox < g.out_dim; ox += 128) {
+            int x0, x1;
+            float lx0, lx1;
             bilinear_axis(ox, a.crop_w, g.out_dim, &x0, &x1, &lx0, &lx1);
-            float v00[5], v01[5], v10[5], v11[5];
-            source_pixel(g, a, n, cmean, a.crop_i + y0, a.crop_j + x0, v00);
-            source_pixel(g, a, n, cmean, a.crop_i + y0, a.crop_j + x1, v01);
-            source_pixel(g, a, n, cmean, a.crop_i + y1, a.crop_j + x0, v10);
-            source_pixel(g, a, n, cmean, a.crop_i + y1, a.crop_j + x1, v11);
+            float v00[5], v01[5], v10[5], v11[5], o[5];
+            if (staged) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    v00[c] = src[y0 - ya][x0][c]; v01[c] = src[y0 - ya][x1][c];
+                    v10[c] = src[y1 - ya][x0][c]; v11[c] = src[y1 - ya][x1][c];
+                }
+            } else {
+                source_pixel(g, a, n, cmean, a.crop_i + y0, a.crop_j + x0, v00);
+                source_pixel(g, a, n, cmean, a.crop_i + y0, a.crop_j + x1, v01);
+                source_pixel(g, a, n, cmean, a.crop_i + y1, a.crop_j + x0, v10);
+                source_pixel(g, a, n, cmean, a.crop_i + y1, a.crop_j + x1, v11);
+            }
 #pragma unroll
             for (int c = 0; c < 5; ++c)
                 o[c] = ly0 * (lx0 * v00[c] + lx1 * v01[c]) + ly1 * (lx0 * v10[c] + lx1 * v11[c]);
-        }
-        if (g.out_nchw) {
-            const size_t plane = (size_t)g.out_dim * g.out_dim;
-            float* dst = g.out_nchw + (size_t)n * g.C * plane + (size_t)oy * g.out_dim + ox;
-            for (int c = 0; c < g.C; ++c) dst[c * plane] = o[c];
-        }
-        if (g.xin) {
-            float v8[8] = {o[0], o[1], o[2], o[3], o[4], 0.f, 0.f, 0.f};
-            *reinterpret_cast<uint4*>(g.xin + (((size_t)n * g.xHp + oy + g.xpad) * g.xWp + ox + g.xpad) * 8) = pack8(v8);
+            aug_store(g, n, oy, ox, o);
         }
     }
 }
@@ -233,13 +290,13 @@ hipError_t vpd_launch_augment(const unsigned char* rgb, const unsigned char* flo
                               const float* noise, const vpd_aug_params* params, int N, int H, int W, int out_dim,
                               const float* mean_std6, float noise_sd, float* out_nchw, bf16_t* xin, int xHp, int xWp,
                               int xpad, float* cmean_scratch, hipStream_t s) {
-    hipLaunchKernelGGL(aug_contrast_mean_kernel, dim3(N), dim3(256), 0, s, rgb, params, H * W, cmean_scratch);
+    hipLaunchKernelGGL(aug_contrast_mean_kernel, dim3(AUG_MEAN_PARTS, N), dim3(256), 0, s, rgb, params, H * W, cmean_scratch);
     AugArgs g;
     g.rgb = rgb; g.flow = flow; g.mask = mask; g.noise = noise; g.params = params; g.cmean = cmean_scratch;
     g.N = N; g.H = H; g.W = W; g.out_dim = out_dim; g.C = flow ? 5 : 3;
     for (int i = 0; i < 3; ++i) { g.mean[i] = mean_std6[i]; g.std[i] = mean_std6[3 + i]; }
     g.noise_sd = noise_sd;
     g.out_nchw = out_nchw; g.xin = xin; g.xHp = xHp; g.xWp = xWp; g.xpad = xpad;
-    hipLaunchKernelGGL(aug_apply_kernel, dim3(out_dim, N), dim3(128), 0, s, g);
+    hipLaunchKernelGGL(aug_apply_kernel, dim3((out_dim + AUG_ROWS - 1) / AUG_ROWS, N), dim3(128), 0, s, g);
     return hipGetLastError();
 }

@@ -6,7 +6,9 @@
       teacher .emb.pkl ingestion (pose-score filter :35-44/:236-242, embed_time pairing
       :247-258), unseeded 80/20 split (:263), sampling WITH replacement for a constant
       epoch length (common.py:104-108), h-flip with x-flow negation (:199-203).
-      NOT yet implemented (next row f1): ColorJitter, mask noise, RandomResizedCrop.
+      ColorJitter, mask noise and RandomResizedCrop run on the DEVICE (vpd_amd/augment.py): with raw_u8=True
+      an item is the decoded u8 arrays + the flip decision, and ModelTrainer(augmenter=...) does the rest.
+      The CPU float path (raw_u8=False) does flips only.
 * FrameDataset ..................... vpd_dataset/single_frame.py:361-403 (orig + h-flip views)
 * SyntheticCrops ................... seeded crops in the reference's value ranges
 
@@ -67,10 +69,28 @@ def _pose_score(meta):
 
 class TeacherEmbDataset(torch.utils.data.Dataset):
 
-    def __init__(self, data, img_dir, img_dim, rgb_mean_std, target_len, flow_img_name=None, augment=True):
+    def __init__(self, data, img_dir, img_dim, rgb_mean_std, target_len, flow_img_name=None, augment=True,
+                 raw_u8=False):
         self.data, self.img_dir, self.img_dim = data, img_dir, img_dim
         self.rgb_mean_std, self.target_len = rgb_mean_std, target_len
-        self.flow_img_name, self.augment = flow_img_name, augment
+        self.flow_img_name, self.augment, self.raw_u8 = flow_img_name, augment, raw_u8
+
+    def _raw_item(self, video_name, frame_num, emb, flip):
+        """Decoded u8 arrays for the device pipeline: rgb [H,W,3], flow [H,W,2] (x, y), mask [H,W] (all zero
+        -> no noise anywhere -- when the item has no <frame>.mask.png, single_frame.py:181-183)."""
+        d = os.path.join(self.img_dir, video_name)
+        item = {'emb': torch.as_tensor(emb, dtype=torch.float32), 'flip': int(flip),
+                'rgb_u8': torch.from_numpy(_load_png(os.path.join(d, '{}.png'.format(frame_num)),
+                                                     self.img_dim).astype(np.uint8))}
+        if self.flow_img_name is not None:
+            fl = _load_png(os.path.join(d, '{}.{}.png'.format(frame_num, self.flow_img_name)), self.img_dim)
+            item['flow_u8'] = torch.from_numpy(fl[:, :, ::-1][:, :, :2].astype(np.uint8).copy())
+        mask_path = os.path.join(d, '{}.mask.png'.format(frame_num))
+        if os.path.exists(mask_path):
+            item['mask_u8'] = torch.from_numpy(_load_png(mask_path, self.img_dim)[:, :, 2].astype(np.uint8).copy())
+        else:
+            item['mask_u8'] = torch.zeros((self.img_dim, self.img_dim), dtype=torch.uint8)
+        return item
 
     def __len__(self):
         return self.target_len
@@ -81,6 +101,8 @@ class TeacherEmbDataset(torch.utils.data.Dataset):
         if len(emb.shape) == 2:
             flip = self.augment and random.getrandbits(1) > 0
             emb = emb[int(flip), :]
+        if self.raw_u8:
+            return self._raw_item(video_name, frame_num, emb, flip)
         img = load_rgb(os.path.join(self.img_dir, video_name, '{}.png'.format(frame_num)), self.img_dim,
                        self.rgb_mean_std)
         if self.flow_img_name is not None:
@@ -175,7 +197,8 @@ def list_crop_dir(crop_dir):
 class SyntheticCrops(torch.utils.data.Dataset):
     """Seeded synthetic crops + teacher targets in the reference's value ranges (no files)."""
 
-    def __init__(self, length, c_in, img_dim, emb_dim, motion, rgb_mean_std, seed=0):
+    def __init__(self, length, c_in, img_dim, emb_dim, motion, rgb_mean_std, seed=0, raw_u8=False):
+        self.raw_u8 = raw_u8
         self.length, self.c_in, self.img_dim, self.emb_dim, self.motion = length, c_in, img_dim, emb_dim, motion
         self.mean = torch.tensor(rgb_mean_std[0]).view(3, 1, 1)
         self.std = torch.tensor(rgb_mean_std[1]).view(3, 1, 1)
@@ -186,12 +209,20 @@ class SyntheticCrops(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
-        rgb = torch.randint(0, 256, (3, self.img_dim, self.img_dim), generator=g).float() / 255.
-        img = (rgb - self.mean) / self.std
+        rgb = torch.randint(0, 256, (3, self.img_dim, self.img_dim), generator=g)
+        fl = None
         if self.c_in > 3:
             fl = (124 + 12 * torch.randn((self.c_in - 3, self.img_dim, self.img_dim), generator=g)).round().clamp(0, 255)
-            img = torch.cat((img, fl / 255. - 0.5))
         t = torch.randn(self.emb_dim, generator=g)
         if self.motion:
             t = torch.cat((t, t - torch.randn(self.emb_dim, generator=g)))
+        if self.raw_u8:      # the same crops as decoded u8 arrays, for the device input pipeline
+            item = {'emb': t, 'rgb_u8': rgb.permute(1, 2, 0).to(torch.uint8).contiguous(), 'flip': 0,
+                    'mask_u8': torch.full((self.img_dim, self.img_dim), 255, dtype=torch.uint8)}
+            if fl is not None:
+                item['flow_u8'] = fl.permute(1, 2, 0).to(torch.uint8).contiguous()
+            return item
+        img = (rgb.float() / 255. - self.mean) / self.std
+        if fl is not None:
+            img = torch.cat((img, fl / 255. - 0.5))
         return {'emb': t, 'img': img}

@@ -46,8 +46,13 @@ class FusedAdamW(torch.optim.Optimizer):
 class ModelTrainer:
     """Class for training the encoder. Discarded after training"""
 
-    def __init__(self, encoder, motion, process_group=None):
+    def __init__(self, encoder, motion, process_group=None, augmenter=None, augment=True):
+        """augmenter: a vpd_amd.augment.CropAugmenter -> epoch() also accepts RAW batches
+        {'rgb_u8': u8[B,H,W,3], 'flow_u8': u8[B,H,W,2], 'mask_u8': u8[B,H,W] (optional), 'flip': int[B] (optional,
+        decided by the dataset because it selects the teacher row), 'emb'} and runs the reference's per-item
+        transforms (vpd_dataset/single_frame.py:168-206) on the device, straight into the stem's staging buffer."""
         device = encoder.device
+        self.augmenter, self.augment = augmenter, bool(augment)
         self.encoder = encoder.to(device)
         self.motion = bool(motion)
         if motion:
@@ -68,6 +73,28 @@ class ModelTrainer:
             eng.forward_eval(img, gt, motion=self.motion)
         return _Loss(self)
 
+    def _forward_loss_raw(self, batch, train):
+        from .augment import sample_params
+        if self.augmenter is None:
+            raise RuntimeError("raw u8 batches need ModelTrainer(..., augmenter=CropAugmenter(...))")
+        eng = self.encoder.engine
+        dev = lambda t: None if t is None else t.to(eng.device, non_blocking=True).contiguous()
+        rgb = dev(batch['rgb_u8'])
+        n, h, w, _ = rgb.shape
+        # like the reference validation batches are augmented too: augmentation is a property
+        # of the dataset objects, which are all built with augment=True (vpd_dataset/single_frame.py:267-272)
+        params = sample_params(n, h, w, augment=self.augment, flip=False)
+        if 'flip' in batch:
+            params['flip'] = batch['flip'].numpy() if hasattr(batch['flip'], 'numpy') else batch['flip']
+        staged = self.augmenter.stage(eng, rgb, dev(batch.get('flow_u8')), dev(batch.get('mask_u8')), params,
+                                      train=train, motion=self.motion)
+        gt = batch['emb'].to(eng.device, dtype=torch.float32, non_blocking=True).contiguous()
+        if train:
+            eng.forward_train(None, gt, motion=self.motion, staged=staged)
+        else:
+            eng.forward_eval(None, gt, motion=self.motion, staged=staged)
+        return _Loss(self)
+
     def _backward(self):
         eng = self.encoder.engine
         if self._reducer is not None:
@@ -85,8 +112,12 @@ class ModelTrainer:
         eng.loss_accum.zero_()          # the epoch accumulator of train_vpd_model.py:73,93 lives on device
         epoch_emb_n = 0
         for batch in data_loader:
-            n = batch['img'].shape[0]
-            loss = self._forward_loss(batch['img'], batch['emb'], train=optimizer is not None)
+            if 'rgb_u8' in batch:
+                n = batch['rgb_u8'].shape[0]
+                loss = self._forward_loss_raw(batch, train=optimizer is not None)
+            else:
+                n = batch['img'].shape[0]
+                loss = self._forward_loss(batch['img'], batch['emb'], train=optimizer is not None)
             if optimizer is not None:
                 step(optimizer, scaler, loss)
             epoch_emb_n += n
