@@ -7,7 +7,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from vpd_amd import paths as dataset_paths
-from vpd_amd.apply import apply_batch_size, embed_dataset, write_embeddings
+from vpd_amd.apply import StreamingWriter, apply_batch_size, embed_dataset
 from vpd_amd.data import FrameDataset, list_crop_dir
 from vpd_amd.io import load_json
 from vpd_amd.models.rgb import RGBF_EmbeddingModel
@@ -59,9 +59,11 @@ def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
 
     loader = DataLoader(ds, batch_size=apply_batch_size(jitter, no_flip), shuffle=False,
                         num_workers=max(os.cpu_count() // 2, 1), pin_memory=True)
-    all_embs = embed_dataset(encoder, loader, len(videos))
-    if out_dir is not None:
-        write_embeddings(out_dir, videos, all_embs)
+    # pickles are written as videos complete (the reference holds every embedding until the end, :153, :171-178)
+    frames_per_video = [0] * len(videos)
+    for t in tasks:
+        frames_per_video[t[0]] += 1
+    embed_dataset(encoder, loader, len(videos), writer=StreamingWriter(out_dir, videos, frames_per_video))
     print('Done!')
 
 

@@ -45,6 +45,30 @@ def test_apply_loop_pickles_match_reference_golden(tmp_path):
             assert rel <= 2e-2, rel            # bf16 student vs the fp32 reference
 
 
+def test_streaming_writer_equals_batch_writer(tmp_path):
+    """Row f4: pickles flushed as each video completes == pickles written at the end (same tuples, same order)."""
+    from vpd_amd.apply import StreamingWriter, embed_dataset, write_embeddings
+    from vpd_amd.io import load_pickle
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+    enc.load_state_dict(O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 5))
+    videos = ["v0", "v1", "v2", "empty"]
+    rs = np.random.RandomState(0)
+    tasks = [(v, f) for v, nf in ((0, 7), (1, 4), (2, 9)) for f in rs.permutation(nf)]      # frames out of order
+    imgs = O.synthetic_crops(len(tasks) * 2, 5, 64, 22).reshape(len(tasks), 2, 5, 64, 64)
+    mk = lambda: [{"video": torch.tensor([t[0] for t in tasks[s:s + 6]]), "frame": torch.tensor([int(t[1]) for t in tasks[s:s + 6]]),
+                   "img": imgs[s:s + 6]} for s in range(0, len(tasks), 6)]
+    write_embeddings(str(tmp_path / "a"), videos, embed_dataset(enc, mk(), len(videos)))
+    w = StreamingWriter(str(tmp_path / "b"), videos, [7, 4, 9, 0])
+    assert embed_dataset(enc, mk(), len(videos), writer=w) is None
+    assert w.written == ["v0", "v1", "v2"] and all(len(p) == 0 for p in w.pending)      # flushed in completion order
+    assert sorted(os.listdir(tmp_path / "a")) == sorted(os.listdir(tmp_path / "b")) == ["v0.emb.pkl", "v1.emb.pkl", "v2.emb.pkl"]
+    for v in ("v0", "v1", "v2"):
+        a, b = load_pickle(str(tmp_path / "a" / (v + ".emb.pkl"))), load_pickle(str(tmp_path / "b" / (v + ".emb.pkl")))
+        assert [t[0] for t in a] == [t[0] for t in b] == sorted(t[0] for t in a)
+        assert all(np.array_equal(x[1], y[1]) and x[2] == y[2] == {} for x, y in zip(a, b))
+
+
 def test_train_cli_synthetic_writes_reference_files(tmp_path):
     save = tmp_path / "run"
     r = subprocess.run([sys.executable, os.path.join(REPO, "train_vpd_model.py"), "diving48", "--save_dir", str(save),

@@ -20,12 +20,66 @@ def apply_batch_size(jitter, no_flip):
     return bs
 
 
-def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True):
-    """loader yields {'video': int[n], 'frame': int[n], 'img': f32[n,k,C,H,W]} -> list per video."""
+class StreamingWriter:
+    """Row f4: write <video>.emb.pkl as soon as the video's last frame is embedded instead of holding every
+    embedding of the data set in RAM until the end (reference apply_vpd_model.py:153, :171-178 holds 1 M of them).
+    Same files, same content: a list sorted by frame of (frame:int, f32[k,D] or f32[D], {})."""
+
+    def __init__(self, out_dir, videos, frames_per_video):
+        self.out_dir, self.videos = out_dir, list(videos)
+        self.remaining = list(frames_per_video)
+        self.pending = [list() for _ in self.videos]
+        self.written = []
+        if out_dir is not None:
+            os.makedirs(out_dir, exist_ok=True)
+
+    def add(self, video_id, item):
+        self.pending[video_id].append(item)
+        self.remaining[video_id] -= 1
+        if self.remaining[video_id] == 0:
+            self.flush(video_id)
+
+    def flush(self, video_id):
+        embs = self.pending[video_id]
+        if embs and self.out_dir is not None:
+            embs.sort(key=lambda t: t[0])
+            store_pickle(os.path.join(self.out_dir, '{}.emb.pkl'.format(self.videos[video_id])), embs)
+            self.written.append(self.videos[video_id])
+        self.pending[video_id] = []
+
+    def close(self):
+        for vid in range(len(self.videos)):      # videos whose frame count was over-estimated
+            if self.pending[vid]:
+                self.flush(vid)
+
+
+def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, writer=None):
+    """loader yields {'video': int[n], 'frame': int[n], 'img': f32[n,k,C,H,W]} -> list per video, or, with
+    `writer` (a StreamingWriter), pickles written as videos complete (returns None).
+
+    The embeddings of batch i travel to a pinned host buffer asynchronously; the host turns batch i-1 into tuples
+    (and pickles) while the GPU runs batch i."""
     eng = encoder.engine
     encoder.eval()
-    all_embs = [list() for _ in range(n_videos)]
+    all_embs = None if writer is not None else [list() for _ in range(n_videos)]
     graphs = {}
+    host = {}            # (n, slot) -> pinned host buffer
+    inflight = None      # (event, host buffer, video_ids, frame_nums, n_batch, k)
+
+    def drain(job):
+        ev, hbuf, video_ids, frame_nums, n_batch, k = job
+        ev.synchronize()
+        embs = hbuf.numpy().reshape((n_batch, k, -1))
+        for i in range(n_batch):
+            item = (frame_nums[i], embs[i, :, :].copy() if k > 1 else embs[i, 0, :].copy(), {})
+            if writer is not None:
+                writer.add(video_ids[i], item)
+            else:
+                all_embs[video_ids[i]].append(item)
+        if progress_cb is not None:
+            progress_cb(n_batch)
+
+    slot = 0
     for batch in loader:
         video_ids = batch['video'].tolist() if hasattr(batch['video'], 'tolist') else list(batch['video'])
         frame_nums = batch['frame'].tolist() if hasattr(batch['frame'], 'tolist') else list(batch['frame'])
@@ -44,14 +98,22 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True):
             pl, xin, out = graphs[n]
             xin.copy_(x, non_blocking=True)
             eng.launch_eval_graph(pl, n)
-            embs = out.cpu().numpy()
         else:
-            embs = encoder.embed(x)
-        embs = embs.reshape((n_batch, k, -1))
-        for i in range(n_batch):
-            all_embs[video_ids[i]].append((frame_nums[i], embs[i, :, :].copy() if k > 1 else embs[i, 0, :].copy(), {}))
-        if progress_cb is not None:
-            progress_cb(n_batch)
+            out = eng.forward_eval(x.to(eng.device, dtype=torch.float32).contiguous())
+        slot ^= 1
+        if (n, slot) not in host:
+            host[(n, slot)] = torch.empty((n, encoder.emb_dim), dtype=torch.float32).pin_memory()
+        hbuf = host[(n, slot)]
+        hbuf.copy_(out, non_blocking=True)          # stream order: after the forward, before the next one rewrites `out`
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(eng.device))
+        if inflight is not None:
+            drain(inflight)                          # host work of the previous batch overlaps this batch's forward
+        inflight = (ev, hbuf, video_ids, frame_nums, n_batch, k)
+    if inflight is not None:
+        drain(inflight)
+    if writer is not None:
+        writer.close()
     return all_embs
 
 

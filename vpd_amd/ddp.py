@@ -8,6 +8,8 @@ crops (train_vpd_model.py:87), so gradients are SUMMED, not averaged.
 The pure functions at the top have no GPU dependency and are what the gloo /
 world_size-2 CPU tests exercise.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -54,6 +56,11 @@ class GradBucketReducer:
 
     def reduce(self, plan):
         cur = torch.cuda.current_stream(self.engine.device)
+        if os.environ.get("VPD_DDP_OVERLAP", "1") == "0":
+            # diagnostic: no overlap -- all buckets reduced in line after backward (RCCL's persistent kernels
+            # hold CUs; whether overlapping them with 1-block-per-CU conv kernels pays is a measurement, not a given)
+            all_reduce_buckets(self.engine.grads, plan.buckets, self.group, async_op=False)
+            return
         works = []
         with torch.cuda.stream(self.comm_stream):
             for ev, (off, numel) in zip(self.events, plan.buckets):
