@@ -31,6 +31,35 @@ DIVING48_MEAN_STD = ((0.3411329922282787, 0.46349889258964044, 0.516248167401569
                      (0.16302619019820488, 0.17092395707914718, 0.19266662199338647))
 
 
+def train_flop_per_crop(arch, c_in, hw, emb_dim):
+    """Algorithmic FLOP of one training crop: 2 * (3 * MACs_fwd - MACs_stem) -- forward, data gradient
+    (none for the stem: the input needs no gradient) and weight gradient of every conv + fc."""
+    layers = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3),
+              "wide_resnet50_2": (3, 4, 6, 3), "wide_resnet101_2": (3, 4, 23, 3)}[arch]
+    bott = arch not in ("resnet18", "resnet34")
+    base = 128 if arch.startswith("wide") else 64
+    h = (hw + 6 - 7) // 2 + 1
+    stem = h * h * 64 * c_in * 49
+    macs = stem
+    h = (h + 2 - 3) // 2 + 1
+    inpl = 64
+    for s, (nblk, planes) in enumerate(zip(layers, (64, 128, 256, 512))):
+        for b in range(nblk):
+            stride = 2 if (b == 0 and s > 0) else 1
+            ho = (h + 2 - 3) // stride + 1
+            if bott:
+                width, outc = planes * base // 64, planes * 4
+                macs += h * h * width * inpl + ho * ho * width * width * 9 + ho * ho * outc * width
+            else:
+                outc = planes
+                macs += ho * ho * planes * inpl * 9 + ho * ho * planes * planes * 9
+            if stride != 1 or inpl != outc:
+                macs += ho * ho * outc * inpl
+            h, inpl = ho, outc
+    macs += inpl * emb_dim
+    return 2 * (3 * macs - stem)
+
+
 def synthetic_batch(n, device, seed):
     """Diving48-shaped crops in the reference's value ranges (vpd_dataset/common.py:52-69):
     RGB ~ U{0..255}/255 normalised with the diving48 mean/std; flow = clip(round(124+12 N(0,1)))/255 - 0.5."""
@@ -80,6 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="crops per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arch", default=ARCH, help="student architecture (default: the BASELINE config, resnet34)")
     ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
     args = ap.parse_args()
 
@@ -99,7 +129,7 @@ def main():
     from vpd_amd.trainer import ModelTrainer
 
     torch.manual_seed(0)
-    enc = RGBF_EmbeddingModel(ARCH, EMB_DIM, True, device)
+    enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device)
     enc.reset_parameters(seed=0)                 # reference init semantics, same weights on every rank
     trainer = ModelTrainer(enc, motion=False)
     optimizer, scaler = trainer.get_optimizer(5e-4)
@@ -136,7 +166,8 @@ def main():
     if rank == 0:
         crops = args.batch * world * args.steps
         value = crops / dt
-        flop = TRAIN_FLOP_PER_CROP[(ARCH, C_IN)]
+        flop = train_flop_per_crop(args.arch, C_IN, HW, EMB_DIM)
+        assert (args.arch, C_IN) not in TRAIN_FLOP_PER_CROP or flop == TRAIN_FLOP_PER_CROP[(args.arch, C_IN)]
         # ---- roofline of the dominant kernel class: HIP events around each conv launch, on its stream ----
         pl = eng.plan(HW, HW, args.batch, True, False)
         eng.set_timing(pl, True)
@@ -175,12 +206,12 @@ def main():
         out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "configs[1]: Diving48-shaped synthetic crops 128x128, ResNet-34 student (5-ch RGB+flow), "
+               "config": {"workload": "configs[1]: Diving48-shaped synthetic crops 128x128, %s student (5-ch RGB+flow), " % ("ResNet-34" if args.arch == ARCH else args.arch) +
                                       "emb_dim 128, sum-MSE + AdamW, batch=%d per GPU" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "flop_per_crop": flop, "loss_last_step": loss_now},
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.arch == ARCH:
             out["cpu_baseline"] = cpu_baseline()
     if world > 1:
         torch.distributed.barrier()

@@ -81,8 +81,32 @@ def _install_stubs():
             out = self.bn2(self.conv2(out))
             return self.relu(out + idn)
 
-    class Bottleneck(nn.Module):  # never instantiated (out of scope)
+    class Bottleneck(nn.Module):
+        """torchvision's Bottleneck from its published definition ("ResNet v1.5": the 3x3 conv carries the stride):
+        conv1x1 -> BN -> ReLU -> conv3x3(stride) -> BN -> ReLU -> conv1x1(x4) -> BN -> (+identity) -> ReLU."""
         expansion = 4
+
+        def __init__(self, inplanes, planes, stride=1, downsample=None, groups=1,
+                     base_width=64, dilation=1, norm_layer=None):
+            super().__init__()
+            norm_layer = norm_layer or nn.BatchNorm2d
+            width = int(planes * (base_width / 64.0)) * groups
+            self.conv1 = conv1x1(inplanes, width)
+            self.bn1 = norm_layer(width)
+            self.conv2 = nn.Conv2d(width, width, 3, stride, dilation, groups=groups, bias=False, dilation=dilation)
+            self.bn2 = norm_layer(width)
+            self.conv3 = conv1x1(width, planes * self.expansion)
+            self.bn3 = norm_layer(planes * self.expansion)
+            self.relu = nn.ReLU(inplace=True)
+            self.downsample = downsample
+            self.stride = stride
+
+        def forward(self, x):
+            idn = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            out = self.bn3(self.conv3(out))
+            return self.relu(out + idn)
 
     tvr.BasicBlock, tvr.Bottleneck, tvr.conv1x1 = BasicBlock, Bottleneck, conv1x1
     for name in ("resnet18", "resnet34", "resnet50", "resnet101", "wide_resnet50_2", "wide_resnet101_2"):
@@ -91,11 +115,11 @@ def _install_stubs():
     tv.transforms, tv.models = tvt, tvm
     sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt,
                         "torchvision.models": tvm, "torchvision.models.resnet": tvr})
-    return BasicBlock
+    return BasicBlock, Bottleneck
 
 
 def _import_reference():
-    basic_block = _install_stubs()
+    basic_block, bottleneck = _install_stubs()
     sys.path.insert(0, REF)
     import models.module as ref_module
     import models.rgb as ref_rgb
@@ -108,6 +132,12 @@ def _import_reference():
         cfg = ref_module.ENCODER_ARCH[arch]
         ref_module.ENCODER_ARCH[arch] = cfg._replace(
             pretrained_init=(lambda L: (lambda pretrained=False: ref_module.ResNet(basic_block, L, 3, 1000)))(layers))
+    # Bottleneck archs: the reference's own ResNet with its own ENCODER_ARCH layer lists / widths
+    for arch in ("resnet50", "resnet101", "wide_resnet50_2", "wide_resnet101_2"):
+        cfg = ref_module.ENCODER_ARCH[arch]
+        ref_module.ENCODER_ARCH[arch] = cfg._replace(
+            pretrained_init=(lambda c: (lambda pretrained=False: ref_module.ResNet(
+                bottleneck, c.layers, 3, 1000, width_per_group=c.width_per_group)))(cfg))
     return ref_module, ref_rgb, ref_util, ref_train, ref_io, ref_load
 
 
@@ -129,6 +159,9 @@ CASES = [
     ("r18_c5_d32_m1_n8", "resnet18", 5, 32, True, 8, 128, 5e-4),
     ("r18_c3_d128_m0_n5_hw64", "resnet18", 3, 128, False, 5, 64, 1e-3),
     ("r18_c5_d128_m1_n6_hw64", "resnet18", 5, 128, True, 6, 64, 5e-4),
+    # Bottleneck students (row f2)
+    ("r50_c5_d32_m0_n8", "resnet50", 5, 32, False, 8, 128, 5e-4),
+    ("wr50_c3_d32_m1_n6", "wide_resnet50_2", 3, 32, True, 6, 128, 5e-4),
 ]
 TAP_BNS = ["resnet.bn1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1",
            "resnet.layer3.1.bn2", "resnet.layer4.1.bn2"]
@@ -293,12 +326,16 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = _import_reference()
+    only = os.environ.get("GOLDEN_ONLY")        # comma-separated case names: regenerate just those
     for i, case in enumerate(CASES):
+        if only and case[0] not in only.split(","):
+            continue
         out = run_case(ref, *case, seed=100 + 10 * i)
         np.savez_compressed(os.path.join(OUT, case[0] + ".npz"), **out)
         print("wrote", case[0], "loss", float(out["loss_train"]), "traj", out["epoch_traj"])
-    np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
-    np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))
+    if not only:
+        np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
+        np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))
     print("done ->", OUT)
 
 

@@ -40,9 +40,17 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-# models/module.py:17-21 -- BasicBlock archs (Bottleneck archs are SURVEY 8f "next")
-ARCH_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+# models/module.py:17-32 -- ENCODER_ARCH: BasicBlock archs and the Bottleneck archs
+ARCH_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3),
+               "resnet101": (3, 4, 23, 3), "wide_resnet50_2": (3, 4, 6, 3), "wide_resnet101_2": (3, 4, 23, 3)}
+# Bottleneck (torchvision, used via models/module.py:6, :22-31): expansion 4; the 3x3 conv carries the stride
+# ("ResNet v1.5"); width = planes * (width_per_group / 64), width_per_group 64 or 128 (models/module.py:26-31)
+ARCH_BOTTLENECK_BASE_WIDTH = {"resnet50": 64, "resnet101": 64, "wide_resnet50_2": 128, "wide_resnet101_2": 128}
 STAGE_WIDTH = (64, 128, 256, 512)
+
+
+def arch_expansion(arch: str) -> int:
+    return 4 if arch in ARCH_BOTTLENECK_BASE_WIDTH else 1
 BN_EPS = 1e-5          # torch BatchNorm2d default, models/module.py:41-43
 BN_MOMENTUM = 0.1
 ADAMW_DEFAULTS = dict(beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01)
@@ -65,19 +73,29 @@ def encoder_schema(arch: str, c_in: int, emb_dim: int) -> "OrderedDict[str, Tupl
     sch["resnet.conv1.weight"] = ((64, c_in, 7, 7), "conv")
     bn("resnet.bn1", 64)
     inplanes = 64
+    exp = arch_expansion(arch)
     for li, (nblk, planes) in enumerate(zip(ARCH_LAYERS[arch], STAGE_WIDTH), start=1):
         for bi in range(nblk):
             stride = 2 if (bi == 0 and li > 1) else 1
             p = "resnet.layer%d.%d" % (li, bi)
-            sch[p + ".conv1.weight"] = ((planes, inplanes, 3, 3), "conv")
-            bn(p + ".bn1", planes)
-            sch[p + ".conv2.weight"] = ((planes, planes, 3, 3), "conv")
-            bn(p + ".bn2", planes)
-            if stride != 1 or inplanes != planes:
-                sch[p + ".downsample.0.weight"] = ((planes, inplanes, 1, 1), "conv")
-                bn(p + ".downsample.1", planes)
-            inplanes = planes
-    sch["resnet.fc.weight"] = ((emb_dim, 512), "fc_w")
+            if exp == 1:
+                sch[p + ".conv1.weight"] = ((planes, inplanes, 3, 3), "conv")
+                bn(p + ".bn1", planes)
+                sch[p + ".conv2.weight"] = ((planes, planes, 3, 3), "conv")
+                bn(p + ".bn2", planes)
+            else:
+                width = planes * ARCH_BOTTLENECK_BASE_WIDTH[arch] // 64
+                sch[p + ".conv1.weight"] = ((width, inplanes, 1, 1), "conv")
+                bn(p + ".bn1", width)
+                sch[p + ".conv2.weight"] = ((width, width, 3, 3), "conv")
+                bn(p + ".bn2", width)
+                sch[p + ".conv3.weight"] = ((planes * exp, width, 1, 1), "conv")
+                bn(p + ".bn3", planes * exp)
+            if stride != 1 or inplanes != planes * exp:
+                sch[p + ".downsample.0.weight"] = ((planes * exp, inplanes, 1, 1), "conv")
+                bn(p + ".downsample.1", planes * exp)
+            inplanes = planes * exp
+    sch["resnet.fc.weight"] = ((emb_dim, 512 * exp), "fc_w")
     sch["resnet.fc.bias"] = ((emb_dim,), "fc_b")
     return sch
 
@@ -213,10 +231,18 @@ def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, arch: str,
         for bi in range(nblk):
             p = "resnet.layer%d.%d" % (li, bi)
             stride = 2 if (bi == 0 and li > 1) else 1
-            o = _rb(F.conv2d(h, _wq(sd[p + ".conv1.weight"], q), None, stride=stride, padding=1), q)
-            o = _rb(F.relu(_bn(sd, p + ".bn1", o, train, taps)), q)
-            o = _rb(F.conv2d(o, _wq(sd[p + ".conv2.weight"], q), None, stride=1, padding=1), q)
-            o = _bn(sd, p + ".bn2", o, train, taps)
+            if (p + ".conv3.weight") in sd:      # Bottleneck: 1x1 -> 3x3 (stride) -> 1x1 (x4)
+                o = _rb(F.conv2d(h, _wq(sd[p + ".conv1.weight"], q), None, stride=1), q)
+                o = _rb(F.relu(_bn(sd, p + ".bn1", o, train, taps)), q)
+                o = _rb(F.conv2d(o, _wq(sd[p + ".conv2.weight"], q), None, stride=stride, padding=1), q)
+                o = _rb(F.relu(_bn(sd, p + ".bn2", o, train, taps)), q)
+                o = _rb(F.conv2d(o, _wq(sd[p + ".conv3.weight"], q), None, stride=1), q)
+                o = _bn(sd, p + ".bn3", o, train, taps)
+            else:                                # BasicBlock
+                o = _rb(F.conv2d(h, _wq(sd[p + ".conv1.weight"], q), None, stride=stride, padding=1), q)
+                o = _rb(F.relu(_bn(sd, p + ".bn1", o, train, taps)), q)
+                o = _rb(F.conv2d(o, _wq(sd[p + ".conv2.weight"], q), None, stride=1, padding=1), q)
+                o = _bn(sd, p + ".bn2", o, train, taps)
             if (p + ".downsample.0.weight") in sd:
                 idn = _rb(F.conv2d(h, _wq(sd[p + ".downsample.0.weight"], q), None, stride=stride), q)
                 idn = _bn(sd, p + ".downsample.1", idn, train, taps)

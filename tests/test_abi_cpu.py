@@ -76,8 +76,12 @@ def test_plan_rejects_bad_arguments():
     from vpd_amd._lib import lib
     L = lib()
     h = C.c_void_p()
-    assert L.vpd_plan_create(b"resnet50", 5, 128, 128, 128, 0, 4, 1, C.byref(h)) != 0
+    assert L.vpd_plan_create(b"effnet-b0", 5, 128, 128, 128, 0, 4, 1, C.byref(h)) != 0      # EfficientNet: out of scope
     assert b"unsupported arch" in L.vpd_last_error()
+    for arch in (b"resnet50", b"wide_resnet101_2"):          # Bottleneck archs plan without a GPU too
+        assert L.vpd_plan_create(arch, 5, 128, 128, 128, 0, 4, 1, C.byref(h)) == 0
+        assert L.vpd_plan_param_numel(h) > 20000000
+        L.vpd_plan_destroy(h)
     assert L.vpd_plan_create(b"resnet34", 9, 128, 128, 128, 0, 4, 1, C.byref(h)) != 0
     assert L.vpd_plan_create(b"resnet34", 5, 127, 128, 128, 0, 4, 1, C.byref(h)) != 0
 

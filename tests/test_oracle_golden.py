@@ -11,7 +11,7 @@ import torch
 from oracle import vpd_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "r*.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*r[0-9]*_c[0-9]_*.npz")))
 
 
 def sample_idx(numel, k=16):

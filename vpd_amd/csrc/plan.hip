@@ -57,14 +57,15 @@ struct ConvInfo {
     size_t z_off = 0;                    // dense bf16 conv output (train)
 };
 struct BlockInfo {
-    ConvInfo c1, c2, cd;
+    ConvInfo c1, c2, c3, cd;             // c3: Bottleneck's closing 1x1 conv (BasicBlock: unused)
     bool ds = false;
     int stage = 0;
-    size_t a1_off = 0, out_off = 0;      // padded bf16 activations
+    size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
     size_t dz2_off[2] = {0, 0}, dz1_off[2] = {0, 0}, dzd_off = 0, idn_off = 0;   // dz buffers ping-pong by block parity
+    size_t dz3_off = 0;                  // Bottleneck: dz of the closing 1x1 conv
 };
 struct TensorRow {
     int kind, is_dec;
@@ -80,6 +81,7 @@ struct LinInfo {
 
 struct vpd_plan {
     int c_in, H, W, D, motion, max_batch, train;
+    int bottleneck = 0, base_width = 64, feat = 512;     // Bottleneck archs: expansion 4, feat = 2048
     std::vector<int> layers;
     ConvInfo stem;
     std::vector<BlockInfo> blocks;
@@ -94,7 +96,7 @@ struct vpd_plan {
     // workspace offsets (bytes)
     size_t ws_bytes = 0;
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
-    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, slab_off = 0, ticket_off = 0;
+    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, T_off[2] = {0, 0}, slab_off = 0, ticket_off = 0;
     bool fused_fin = true;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
@@ -195,9 +197,14 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                                int max_batch, int train, vpd_plan_t** out) {
     if (!arch || !out) return fail("null argument");
     std::vector<int> layers;
+    int bottleneck = 0, base_width = 64;          // reference models/module.py:17-32 (ENCODER_ARCH)
     if (!strcmp(arch, "resnet18")) layers = {2, 2, 2, 2};
     else if (!strcmp(arch, "resnet34")) layers = {3, 4, 6, 3};
-    else return fail("unsupported arch (resnet18 | resnet34)");
+    else if (!strcmp(arch, "resnet50")) { layers = {3, 4, 6, 3}; bottleneck = 1; }
+    else if (!strcmp(arch, "resnet101")) { layers = {3, 4, 23, 3}; bottleneck = 1; }
+    else if (!strcmp(arch, "wide_resnet50_2")) { layers = {3, 4, 6, 3}; bottleneck = 1; base_width = 128; }
+    else if (!strcmp(arch, "wide_resnet101_2")) { layers = {3, 4, 23, 3}; bottleneck = 1; base_width = 128; }
+    else return fail("unsupported arch (resnet18 | resnet34 | resnet50 | resnet101 | wide_resnet50_2 | wide_resnet101_2)");
     if (c_in < 1 || c_in > 8) return fail("c_in must be in 1..8");
     if (img_h < 32 || img_w < 32 || (img_h % 2) || (img_w % 2)) return fail("img dims must be even and >= 32");
     if (emb_dim < 1 || max_batch < 1) return fail("bad emb_dim / max_batch");
@@ -205,6 +212,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     vpd_plan* p = new vpd_plan();
     p->c_in = c_in; p->H = img_h; p->W = img_w; p->D = emb_dim; p->motion = motion ? 1 : 0;
     p->max_batch = max_batch; p->train = train ? 1 : 0; p->layers = layers;
+    p->bottleneck = bottleneck; p->base_width = base_width; p->feat = bottleneck ? 2048 : 512;
 
     // ---- topology + flat tables (reference module order) ----
     add_conv(p, p->stem, c_in, 64, 7, 2, 3, img_h, img_w, true);
@@ -224,23 +232,36 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             BlockInfo& B = p->blocks[bi];
             const int stride = (b == 0 && s > 0) ? 2 : 1;
             B.stage = s;
-            add_conv(p, B.c1, inplanes, widths[s], 3, stride, 1, h, w, false);
-            add_conv(p, B.c2, widths[s], widths[s], 3, 1, 1, B.c1.Hout, B.c1.Wout, false);
-            B.ds = (stride != 1 || inplanes != widths[s]);
-            if (B.ds) add_conv(p, B.cd, inplanes, widths[s], 1, stride, 0, h, w, false);
-            h = B.c1.Hout; w = B.c1.Wout; inplanes = widths[s];
+            if (!bottleneck) {
+                add_conv(p, B.c1, inplanes, widths[s], 3, stride, 1, h, w, false);
+                add_conv(p, B.c2, widths[s], widths[s], 3, 1, 1, B.c1.Hout, B.c1.Wout, false);
+                B.ds = (stride != 1 || inplanes != widths[s]);
+                if (B.ds) add_conv(p, B.cd, inplanes, widths[s], 1, stride, 0, h, w, false);
+                h = B.c1.Hout; w = B.c1.Wout; inplanes = widths[s];
+            } else {
+                // torchvision Bottleneck ("v1.5": the 3x3 carries the stride), state_dict order conv1 bn1 conv2 bn2
+                // conv3 bn3 downsample.0 downsample.1
+                const int width = widths[s] * base_width / 64, outc = widths[s] * 4;
+                add_conv(p, B.c1, inplanes, width, 1, 1, 0, h, w, false);
+                add_conv(p, B.c2, width, width, 3, stride, 1, h, w, false);
+                add_conv(p, B.c3, width, outc, 1, 1, 0, B.c2.Hout, B.c2.Wout, false);
+                B.ds = (stride != 1 || inplanes != outc);
+                if (B.ds) add_conv(p, B.cd, inplanes, outc, 1, stride, 0, h, w, false);
+                h = B.c2.Hout; w = B.c2.Wout; inplanes = outc;
+            }
         }
-        p->stages[s].H = h; p->stages[s].W = w; p->stages[s].C = widths[s];
+        p->stages[s].H = h; p->stages[s].W = w; p->stages[s].C = inplanes;
     }
-    for (auto& B : p->blocks) {     // BN module order: bn1, bn2, downsample.1
+    for (auto& B : p->blocks) {     // BN module order: bn1, bn2, (bn3,) downsample.1
         p->bns.push_back(&B.c1.bn);
         p->bns.push_back(&B.c2.bn);
+        if (bottleneck) p->bns.push_back(&B.c3.bn);
         if (B.ds) p->bns.push_back(&B.cd.bn);
     }
     if (h < 1 || w < 1) { delete p; return fail("image too small for 5 stride-2 stages"); }
     stage_first_tensor_off[4] = p->nparam;
-    p->fc.in = 512; p->fc.out = emb_dim;
-    add_tensor(p, 3, 0, (long long)emb_dim * 512, 2, emb_dim, 512, 0, 0, &p->fc.w_off);
+    p->fc.in = p->feat; p->fc.out = emb_dim;
+    add_tensor(p, 3, 0, (long long)emb_dim * p->feat, 2, emb_dim, p->feat, 0, 0, &p->fc.w_off);
     add_tensor(p, 4, 0, emb_dim, 1, emb_dim, 0, 0, 0, &p->fc.b_off);
     if (p->motion) {
         const int dims[4] = {emb_dim, 128, 128, 2 * emb_dim};
@@ -281,6 +302,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         const int bucket = 3 - B.stage;
         push_desc(B.c1, bucket);
         push_desc(B.c2, bucket);
+        if (bottleneck) push_desc(B.c3, bucket);
         if (B.ds) push_desc(B.cd, bucket);
     }
 
@@ -311,7 +333,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         upd(p->stem);
         for (auto& B : p->blocks) { upd(B.c1); upd(B.c2); if (B.ds) upd(B.cd); }
         (void)mx;   // producers accumulate atomically into VPD_STAT_ROWS rows of [2][C]
-        p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * 512 * 4;
+        p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * p->feat * 4;
         p->partial_off = bp.take(p->partial_bytes);
         p->ticket_off = bp.take(256);
         // measured: the per-block ticket round trip costs more than the 36 tiny finalize launches it saves
@@ -322,13 +344,18 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     p->p0_off = bp.take(padded_elems(NB, p->H1, p->W1, 64, 1) * 2);
     for (auto& B : p->blocks) {
         B.a1_off = bp.take(padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1) * 2);
-        B.out_off = bp.take(padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1) * 2);
+        if (bottleneck) {
+            B.a2_off = bp.take(padded_elems(NB, B.c2.Hout, B.c2.Wout, B.c2.Co, 1) * 2);
+            B.out_off = bp.take(padded_elems(NB, B.c3.Hout, B.c3.Wout, B.c3.Co, 1) * 2);
+        } else {
+            B.out_off = bp.take(padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1) * 2);
+        }
     }
     for (int s = 0; s < 4; ++s) {
         StageInfo& S = p->stages[s];
         S.idn_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
     }
-    p->pooled_off = bp.take((size_t)NB * 512 * 4);
+    p->pooled_off = bp.take((size_t)NB * p->feat * 4);
     p->emb_off = bp.take((size_t)NB * emb_dim * 4);
     p->h1_off = bp.take((size_t)NB * 128 * 4);
     p->h2_off = bp.take((size_t)NB * 128 * 4);
@@ -339,9 +366,15 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         for (auto& B : p->blocks) {
             B.c1.z_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co * 2);
             B.c2.z_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co * 2);
+            if (bottleneck) B.c3.z_off = bp.take((size_t)NB * B.c3.Hout * B.c3.Wout * B.c3.Co * 2);
             if (B.ds) B.cd.z_off = bp.take((size_t)NB * B.cd.Hout * B.cd.Wout * B.cd.Co * 2);
             size_t e = (size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co;
             maxact = e > maxact ? e : maxact;
+            if (bottleneck) {      // gradients w.r.t. the block input / output and both inner activations
+                e = (size_t)NB * B.c1.Hin * B.c1.Win * B.c1.Ci; maxact = e > maxact ? e : maxact;
+                e = (size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co; maxact = e > maxact ? e : maxact;
+                e = (size_t)NB * B.c3.Hout * B.c3.Wout * B.c3.Co; maxact = e > maxact ? e : maxact;
+            }
         }
         for (int s = 0; s < 4; ++s) {
             StageInfo& S = p->stages[s];
@@ -351,6 +384,22 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             }
             S.dzd_off = bp.take(padded_elems(NB, S.H, S.W, S.C, 1) * 2);
         }
+        if (bottleneck) {      // per-stage dz buffers sized for the largest conv output of the stage's blocks
+            for (int s = 0; s < 4; ++s) {
+                size_t m1 = 0, m2 = 0, m3 = 0;
+                for (auto& B : p->blocks) {
+                    if (B.stage != s) continue;
+                    size_t e1 = padded_elems(NB, B.c1.Hout, B.c1.Wout, B.c1.Co, 1), e2 = padded_elems(NB, B.c2.Hout, B.c2.Wout, B.c2.Co, 1),
+                           e3 = padded_elems(NB, B.c3.Hout, B.c3.Wout, B.c3.Co, 1);
+                    m1 = e1 > m1 ? e1 : m1; m2 = e2 > m2 ? e2 : m2; m3 = e3 > m3 ? e3 : m3;
+                }
+                StageInfo& S = p->stages[s];
+                S.dz1_off[0] = S.dz1_off[1] = bp.take(m1 * 2);
+                S.dz2_off[0] = S.dz2_off[1] = bp.take(m2 * 2);
+                S.dz3_off = bp.take(m3 * 2);
+            }
+            for (int i = 0; i < 2; ++i) p->T_off[i] = bp.take(maxact * 2);
+        }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? 2 * p->slab_elems : 1) * 4);      // two slabs, used alternately
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -359,7 +408,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         p->dh2_off = bp.take((size_t)NB * 128 * 4);
         p->dh1_off = bp.take((size_t)NB * 128 * 4);
         p->demb_off = bp.take((size_t)NB * emb_dim * 4);
-        p->dpooled_off = bp.take((size_t)NB * 512 * 4);
+        p->dpooled_off = bp.take((size_t)NB * p->feat * 4);
     }
     p->ws_bytes = bp.cur;
     *out = p;
@@ -639,9 +688,9 @@ int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* 
              float* loss_step, double* loss_accum) {
     vpd_plan* p = c.p;
     const StageInfo& S = p->stages[3];
-    LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, 512, c.n, c.f32(p->pooled_off), c.s));
+    LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.f32(p->pooled_off), c.s));
     float* emb = c.f32(p->emb_off);
-    LCHECK(vpd_launch_sgemm(c.f32(p->pooled_off), c.params + p->fc.w_off, emb, c.params + p->fc.b_off, c.n, p->D, 512,
+    LCHECK(vpd_launch_sgemm(c.f32(p->pooled_off), c.params + p->fc.w_off, emb, c.params + p->fc.b_off, c.n, p->D, p->feat,
                             0, 1, 0, c.s));
     if (emb_out) LCHECK(hipMemcpyAsync(emb_out, emb, (size_t)c.n * p->D * 4, hipMemcpyDeviceToDevice, c.s));
     if (!target) return 0;
@@ -680,6 +729,19 @@ int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, fl
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
         LCHECK(run_conv_fwd(c, B.c1, cur, a1, 1, false, c.bn_escale(B.c1.bn), c.bn_eshift(B.c1.bn), nullptr, 1));
+        if (p->bottleneck) {
+            bf16_t* a2 = c.b16(B.a2_off);
+            LCHECK(run_conv_fwd(c, B.c2, a1, a2, 1, false, c.bn_escale(B.c2.bn), c.bn_eshift(B.c2.bn), nullptr, 1));
+            const bf16_t* idn3 = cur;
+            if (B.ds) {
+                bf16_t* idb = c.b16(p->stages[B.stage].idn_off);
+                LCHECK(run_conv_fwd(c, B.cd, cur, idb, 1, false, c.bn_escale(B.cd.bn), c.bn_eshift(B.cd.bn), nullptr, 0));
+                idn3 = idb;
+            }
+            LCHECK(run_conv_fwd(c, B.c3, a2, outp, 1, false, c.bn_escale(B.c3.bn), c.bn_eshift(B.c3.bn), idn3, 1));
+            cur = outp;
+            continue;
+        }
         const bf16_t* idn = cur;
         if (B.ds) {
             bf16_t* idb = c.b16(p->stages[B.stage].idn_off);
@@ -750,6 +812,23 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
         LCHECK(run_bn_finalize(c, B.c1, bn_running));
         LCHECK(run_bn_apply(c, B.c1, 0, nullptr, nullptr, a1, 1));
+        if (p->bottleneck) {
+            bf16_t* a2 = c.b16(B.a2_off);
+            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+            LCHECK(run_bn_finalize(c, B.c2, bn_running));
+            LCHECK(run_bn_apply(c, B.c2, 0, nullptr, nullptr, a2, 1));
+            LCHECK(run_conv_fwd(c, B.c3, a2, c.b16(B.c3.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+            LCHECK(run_bn_finalize(c, B.c3, bn_running));
+            if (B.ds) {
+                LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+                LCHECK(run_bn_finalize(c, B.cd, bn_running));
+                LCHECK(run_bn_apply(c, B.c3, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+            } else {
+                LCHECK(run_bn_apply(c, B.c3, 1, cur, nullptr, outp, 1));
+            }
+            cur = outp;
+            continue;
+        }
         LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
         LCHECK(run_bn_finalize(c, B.c2, bn_running));
         if (B.ds) {
@@ -791,19 +870,19 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(vpd_launch_sgemm(c.f32(p->dh1_off), params + L[0].w_off, c.f32(p->demb_off), nullptr, n, L[0].in, L[0].out, 0, 0, 0, s));
         demb = c.f32(p->demb_off);
     }
-    LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, 512, n, 1, 0, 0, s));
+    LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, p->feat, n, 1, 0, 0, s));
     LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
-    LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, 512, p->D, 0, 0, 0, s));
+    LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, p->feat, p->D, 0, 0, 0, s));
 
     int gi = 0;      // index of the G buffer holding d(out) of the current block
     bf16_t* G[3] = {c.b16(p->G_off[0]), c.b16(p->G_off[1]), c.b16(p->G_off[2])};
     {
         const StageInfo& S = p->stages[3];
-        LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, 512, n, G[gi], s));
+        LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
     }
     // ---- side stream for the weight gradients ----
     static const bool want_side = getenv("VPD_TWO_STREAMS") && atoi(getenv("VPD_TWO_STREAMS"));
-    const bool fork = p->two_streams || want_side;
+    const bool fork = (p->two_streams || want_side) && !p->bottleneck;     // Bottleneck plans share dz buffers per stage
     if (fork && !p->side) LCHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
     hipStream_t ws_stream = fork ? p->side : s;
     p->ev_next = 0;
@@ -889,6 +968,34 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         bf16_t* dnew = G[(gi + 2) % 3];
         bf16_t* dz2 = c.b16(S.dz2_off[par]);
         bf16_t* dz1 = c.b16(S.dz1_off[par]);
+        if (p->bottleneck) {
+            bf16_t* dz3 = c.b16(S.dz3_off);
+            bf16_t* da2 = c.b16(p->T_off[0]);
+            bf16_t* da1b = c.b16(p->T_off[1]);
+            // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout
+            LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads));
+            LCHECK(fork_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
+            LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
+            LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
+            LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
+            LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
+            LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
+            if (B.ds) {
+                bf16_t* dzd = c.b16(S.dzd_off);
+                LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
+                LCHECK(fork_wgrad(B.cd, dzd, 1, xin));
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // 1x1 stride 1: writes every input pixel
+                LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
+                gi = (gi + 2) % 3;
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
+            }
+            if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
+                if (unpack_bucket(3 - B.stage)) return -1;
+            }
+            continue;
+        }
         // the side stream's readers of this parity's dz buffers (block bi+2 of the same stage) must be done
         if (fork && dz_free[B.stage][par]) LCHECK(hipStreamWaitEvent(s, dz_free[B.stage][par], 0));
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout

@@ -11,17 +11,20 @@ import torch
 
 from ._lib import check, lib
 
-# reference: models/module.py:17-21 (BasicBlock archs; Bottleneck archs are out of scope)
-ENCODER_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+# reference: models/module.py:17-32 (ENCODER_ARCH): BasicBlock archs and the Bottleneck archs
+ENCODER_LAYERS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3),
+                  "resnet101": (3, 4, 23, 3), "wide_resnet50_2": (3, 4, 6, 3), "wide_resnet101_2": (3, 4, 23, 3)}
+BOTTLENECK_ARCHS = ("resnet50", "resnet101", "wide_resnet50_2", "wide_resnet101_2")
 _STAGE_WIDTH = (64, 128, 256, 512)
 
 
 def encoder_param_names(arch):
     """Trainable tensors / BN buffers of the encoder in reference state_dict order."""
     if arch not in ENCODER_LAYERS:
-        raise KeyError("unsupported encoder_arch %r (resnet18 | resnet34)" % (arch,))
+        raise KeyError("unsupported encoder_arch %r (%s)" % (arch, " | ".join(ENCODER_LAYERS)))
     train, bns = ["resnet.conv1.weight", "resnet.bn1.weight", "resnet.bn1.bias"], ["resnet.bn1"]
     inpl = 64
+    exp = 4 if arch in BOTTLENECK_ARCHS else 1
     for li, (nblk, planes) in enumerate(zip(ENCODER_LAYERS[arch], _STAGE_WIDTH), start=1):
         for bi in range(nblk):
             p = "resnet.layer%d.%d" % (li, bi)
@@ -29,10 +32,13 @@ def encoder_param_names(arch):
             train += [p + ".conv1.weight", p + ".bn1.weight", p + ".bn1.bias",
                       p + ".conv2.weight", p + ".bn2.weight", p + ".bn2.bias"]
             bns += [p + ".bn1", p + ".bn2"]
-            if stride != 1 or inpl != planes:
+            if exp == 4:
+                train += [p + ".conv3.weight", p + ".bn3.weight", p + ".bn3.bias"]
+                bns.append(p + ".bn3")
+            if stride != 1 or inpl != planes * exp:
                 train += [p + ".downsample.0.weight", p + ".downsample.1.weight", p + ".downsample.1.bias"]
                 bns.append(p + ".downsample.1")
-            inpl = planes
+            inpl = planes * exp
     train += ["resnet.fc.weight", "resnet.fc.bias"]
     return train, bns
 

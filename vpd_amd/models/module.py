@@ -1,7 +1,7 @@
 """Architecture table and the motion head, mirroring reference models/module.py.
 
-ENCODER_ARCH (reference models/module.py:17-32): only the BasicBlock archs are
-in scope (SURVEY.md 8f lists the Bottleneck ones as "next").
+ENCODER_ARCH (reference models/module.py:17-32): the BasicBlock archs and the Bottleneck archs
+(resnet50/101, wide_resnet50_2/101_2); EfficientNet students are out of scope.
 FCNet (reference models/module.py:133-156) as built at train_vpd_model.py:61-65:
 Linear(D,128)-ReLU-Linear(128,128)-Dropout(0)-ReLU-Linear(128,2D); state_dict
 keys layers.{0,2,5}.{weight,bias}.

@@ -69,7 +69,7 @@ class RGBF_EmbeddingModel(nn.Module):
                 elif kind == 2:
                     p.zero_()
                 else:
-                    bound = 1.0 / math.sqrt(512)
+                    bound = 1.0 / math.sqrt(self.get_parameter("resnet.fc.weight").shape[1])
                     p.copy_((torch.rand(p.shape, device=eng.device, generator=g) * 2 - 1) * bound)
             for bn in eng.bn_names:
                 rm, rv = eng.bn_views(bn)
