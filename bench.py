@@ -201,8 +201,10 @@ def main():
                     "traffic_note": traffic_note,
                     "whole_step_frac": value / world * flop / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12),
                     "kernels": kernels,
-                    "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region; "
-                            "a stride-2 dgrad's parity-class launches are one timed unit" % args.profile_steps}
+                    "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region: the "
+                            "start/stop events ride in each kernel's own dispatch packet (hipExtLaunchKernelGGL), so the "
+                            "figure is the kernel's duration as rocprofv3 --kernel-trace reports it; a weight-gradient "
+                            "launch is timed without its slab reduce" % args.profile_steps}
         out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

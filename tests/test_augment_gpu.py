@@ -145,11 +145,13 @@ def test_trainer_epoch_on_raw_u8_batches():
         opt, scaler = tr.get_optimizer(5e-4)
         ds = SyntheticCrops(24, 5, 64, 32, False, MEAN_STD, seed=3, raw_u8=raw)
         losses.append([tr.epoch(DataLoader(ds, batch_size=8), opt, scaler) for _ in range(2)])
-    assert losses[0] == losses[1], losses
+    # same crops, same bf16 staging values (bit-exact, test_staged_input_equals_fp32_batch_path); the training steps
+    # in between use fp32 atomics in the generic weight-gradient kernel, whose summation order varies run to run
+    assert np.allclose(losses[0], losses[1], rtol=1e-3), losses
     # with augmentation on: runs, finite, and differs from the un-augmented loss
     enc = RGBF_EmbeddingModel("resnet18", 32, True, torch.device("cuda:0"))
     enc.reset_parameters(seed=0)
     tr = ModelTrainer(enc, motion=False, augmenter=A.CropAugmenter("cuda:0", MEAN_STD, 64, True), augment=True)
     opt, scaler = tr.get_optimizer(5e-4)
     la = tr.epoch(DataLoader(SyntheticCrops(24, 5, 64, 32, False, MEAN_STD, seed=3, raw_u8=True), batch_size=8), opt, scaler)
-    assert math.isfinite(la) and la != losses[1][0]
+    assert math.isfinite(la) and abs(la - losses[1][0]) > 1e-3 * losses[1][0]

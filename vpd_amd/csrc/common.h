@@ -1,6 +1,7 @@
 // Shared device helpers for the VPD student kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
@@ -158,3 +159,25 @@ struct WgradParams {
     int chunks_per_block;                       // 128-pixel chunks handled by one block
     TapSet taps;                                // w0 + ir*wrs + ic*wcs indexes the dw slice
 };
+
+// ---------------------------------------------------------------------------
+// Timing hook (bench.py's roofline): while a TimeScope is armed, the NEXT matrix-kernel launch of this thread carries
+// the scope's start / stop events in its own dispatch packet (hipExtLaunchKernelGGL), so their elapsed time is the
+// kernel's duration as a profiler reports it -- an event pair recorded around a launch also contains ~5 us of
+// event-packet processing.  Unarmed (always, outside the instrumented steps) it is a plain launch.
+// ---------------------------------------------------------------------------
+struct VpdLaunchEvents { hipEvent_t start, stop; };
+inline VpdLaunchEvents& vpd_launch_events() {
+    static thread_local VpdLaunchEvents e = {nullptr, nullptr};
+    return e;
+}
+#define VPD_LAUNCH(kernel, grid, block, lds, stream, ...)                                                          \
+    do {                                                                                                          \
+        VpdLaunchEvents& le_ = vpd_launch_events();                                                               \
+        if (le_.start) {                                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, le_.start, le_.stop, 0, __VA_ARGS__);         \
+            le_.start = nullptr;                                                                                  \
+        } else {                                                                                                  \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                    \
+        }                                                                                                         \
+    } while (0)

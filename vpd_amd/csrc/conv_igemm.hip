@@ -607,10 +607,10 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
     ConvParams q = p;
     q.fin.nblocks = grid;
     switch (conv_ep_mode(q)) {
-        case 0: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 1: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 2: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        default: hipLaunchKernelGGL((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 2: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        default: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
     }
     return hipGetLastError();
 }
@@ -756,8 +756,8 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
     ConvParams q = p;
     q.fin.nblocks = grid;
-    if (p.stats) hipLaunchKernelGGL((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
-    else hipLaunchKernelGGL((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
+    if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
+    else VPD_LAUNCH((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
     return hipGetLastError();
 }
 
@@ -768,10 +768,10 @@ static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t 
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
     switch (conv_ep_mode(q)) {
-        case 0: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0>), grid, dim3(512), lds, stream, q, g); break;
-        case 1: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1>), grid, dim3(512), lds, stream, q, g); break;
-        case 2: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2>), grid, dim3(512), lds, stream, q, g); break;
-        default: hipLaunchKernelGGL((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3>), grid, dim3(512), lds, stream, q, g); break;
+        case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0>), grid, dim3(512), lds, stream, q, g); break;
+        case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1>), grid, dim3(512), lds, stream, q, g); break;
+        case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2>), grid, dim3(512), lds, stream, q, g); break;
+        default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3>), grid, dim3(512), lds, stream, q, g); break;
     }
     return hipGetLastError();
 }
@@ -784,7 +784,7 @@ static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_
     if (lds < red) lds = red;
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, q, g);
+    VPD_LAUNCH((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, q, g);
     return hipGetLastError();
 }
 
@@ -818,10 +818,10 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     ConvParams q = p;
     q.fin.nblocks = (int)(grid.x * grid.y);
     switch (conv_ep_mode(q)) {
-        case 0: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
-        case 1: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, q); break;
-        default: hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, stream, q); break;
+        case 0: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
+        case 1: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
+        case 2: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, q); break;
+        default: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, stream, q); break;
     }
     return hipGetLastError();
 }

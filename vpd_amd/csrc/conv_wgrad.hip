@@ -620,7 +620,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         ksplit = (nchunks + cpb - 1) / cpb;
         const size_t lds = (size_t)3 * (64 + 128) * 64 * sizeof(bf16_t);
         const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;
-        hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(1, ksplit), dim3(768), lds, stream, p, tr_stem, cpb, xelems);
+        VPD_LAUNCH(conv_wgrad_stem_kernel, dim3(1, ksplit), dim3(768), lds, stream, p, tr_stem, cpb, xelems);
         const long n4 = (long)7 * 64 * 64 / 4;
         const int groups = ksplit < 16 ? ksplit : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
@@ -633,9 +633,9 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         g.ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, &g.cpb);
         const int npass = (g.NHP + 31) / 32;            // 3..5
         const size_t lds = (size_t)WG_NS * (WG_CH + 32 * npass) * 64 * sizeof(bf16_t);
-        if (npass <= 3) hipLaunchKernelGGL(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
-        else if (npass == 4) hipLaunchKernelGGL(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
-        else hipLaunchKernelGGL(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else VPD_LAUNCH(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
         return vpd_launch_wgrad_reduce(p, stream);
     }
@@ -651,7 +651,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     p.chunks_per_block = cpb;
     dim3 grid(tiles, ksplit);
     const size_t lds = 64 * 1024;     // max(staging 2*2*16 KiB, reduction 64 KiB)
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), lds, stream, p);
+    VPD_LAUNCH(conv_wgrad_kernel, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -500,11 +500,18 @@ struct TimeScope {
             return e;
         };
         vpd_plan::TimedLaunch t{cls, flops, get(), get()};
-        (void)hipEventRecord(t.a, s);
         p->timed.push_back(t);
         idx = (int)p->timed.size() - 1;
+        vpd_launch_events() = {t.a, t.b};       // the scope's first matrix-kernel launch carries them (common.h)
     }
-    ~TimeScope() { if (idx >= 0) (void)hipEventRecord(p->timed[idx].b, s); }
+    ~TimeScope() {
+        if (idx < 0) return;
+        if (vpd_launch_events().start) {        // nothing was launched through VPD_LAUNCH: bracket the scope instead
+            vpd_launch_events().start = nullptr;
+            (void)hipEventRecord(p->timed[idx].a, s);
+            (void)hipEventRecord(p->timed[idx].b, s);
+        }
+    }
 };
 inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real taps and channels
     return 2.0 * n * cv.Hout * cv.Wout * cv.Co * (double)cv.Ci * cv.k * cv.k;
@@ -636,7 +643,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
         if (e != hipSuccess) return e;
         return reduce ? (*reduce)(q) : vpd_launch_wgrad_reduce(q, st);
     }
-    TimeScope ts(c.p, st, vpd_wgrad_overwrites(q) ? 5 : 6, conv_flops(cv, c.n));
+    TimeScope ts(c.p, st, cv.stem ? 7 : (vpd_wgrad_overwrites(q) ? 5 : 6), conv_flops(cv, c.n));      // 7: stem kernels
     return vpd_launch_wgrad(q, st);
 }
 
