@@ -97,6 +97,14 @@ hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                             double eps, double wd, int step, hipStream_t s);
 
+#define ZR_MAX 16
+struct ZeroRanges {                     // 16-byte aligned ranges, lengths in float4
+    float* ptr[ZR_MAX];
+    long n4[ZR_MAX];
+    int count;
+};
+hipError_t vpd_launch_zero_ranges(const ZeroRanges& z, hipStream_t s);
+
 // augment.hip (declared with the public vpd_aug_params of include/vpd_hip.h)
 struct vpd_aug_params;
 hipError_t vpd_launch_augment(const unsigned char* rgb, const unsigned char* flow, const unsigned char* mask,

@@ -145,3 +145,21 @@ hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n
                        (float)(1.0 - b2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
     return hipGetLastError();
 }
+
+// Zero up to ZR_MAX float ranges in ONE launch (accumulator rows of the BN statistics + the fp32 weight-gradient
+// ranges the atomics kernel adds into): hipMemsetAsync costs 5-12 us per call on this runtime.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroRanges z) {
+    float4* p = reinterpret_cast<float4*>(z.ptr[blockIdx.y]);
+    const long n4 = z.n4[blockIdx.y];
+    const float4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) p[i] = zero;
+}
+hipError_t vpd_launch_zero_ranges(const ZeroRanges& z, hipStream_t s) {
+    if (z.count <= 0) return hipSuccess;
+    long mx = 0;
+    for (int i = 0; i < z.count; ++i) mx = z.n4[i] > mx ? z.n4[i] : mx;
+    long gx = (mx + 255) / 256;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), z.count), dim3(256), 0, s, z);
+    return hipGetLastError();
+}

@@ -614,7 +614,8 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
 // `st`, so the caller can move that bandwidth-bound sum to a side stream, beside the next MFMA kernels.
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
                           hipStream_t st, int slab_index = 0,
-                          const std::function<hipError_t(const WgradParams&)>* reduce = nullptr) {
+                          const std::function<hipError_t(const WgradParams&)>* reduce = nullptr,
+                          ZeroRanges* collect_zero = nullptr, bool prezeroed = false) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -629,7 +630,14 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
     if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) return hipErrorInvalidValue;   // plan and launcher must agree
-    if (!vpd_wgrad_overwrites(q)) {      // the generic kernel accumulates with atomics: zero its range first
+    if (collect_zero) {                  // dry run at the start of backward: which ranges need zeroing
+        if (!vpd_wgrad_overwrites(q) && collect_zero->count < ZR_MAX) {
+            collect_zero->ptr[collect_zero->count] = q.dw;
+            collect_zero->n4[collect_zero->count++] = (long)cv.ntaps * cv.Co * cv.Kc / 4;
+        }
+        return hipSuccess;
+    }
+    if (!vpd_wgrad_overwrites(q) && !prezeroed) {      // the generic kernel accumulates with atomics: zero its range first
         hipError_t e = hipMemsetAsync(q.dw, 0, (size_t)cv.ntaps * cv.Co * cv.Kc * 4, st);
         if (e != hipSuccess) return e;
     }
@@ -797,7 +805,12 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
-    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes + 256, s));     // accumulator rows + ticket
+    {
+        ZeroRanges z;
+        memset(&z, 0, sizeof z);
+        z.ptr[0] = c.f32(p->partial_off); z.n4[0] = (long)(p->partial_bytes + 256) / 16; z.count = 1;      // accumulator rows + ticket
+        LCHECK(vpd_launch_zero_ranges(z, s));
+    }
     if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     // stem: conv -> batch stats -> BN+ReLU+maxpool
     LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0,
@@ -857,7 +870,20 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     Ctx c{p, ws, s, params, n};
-    LCHECK(hipMemsetAsync(ws + p->partial_off, 0, p->partial_bytes, s));
+    // one launch zeroes the accumulator rows and every weight-gradient range the atomics kernel will add into
+    ZeroRanges zr;
+    memset(&zr, 0, sizeof zr);
+    zr.ptr[0] = c.f32(p->partial_off); zr.n4[0] = (long)p->partial_bytes / 16; zr.count = 1;
+    bool prezeroed = true;
+    {
+        auto dry = [&](const ConvInfo& cv, int dzpad) {
+            (void)run_conv_wgrad(c, cv, nullptr, dzpad, nullptr, s, 0, nullptr, &zr);
+        };
+        for (auto& B : p->blocks) { dry(B.c1, 1); dry(B.c2, 1); if (p->bottleneck) dry(B.c3, 1); if (B.ds) dry(B.cd, 1); }
+        dry(p->stem, 0);
+        if (zr.count >= ZR_MAX) { zr.count = 1; prezeroed = false; }      // too many ranges (deep Bottleneck nets): memset per conv
+    }
+    LCHECK(vpd_launch_zero_ranges(zr, s));
 
     // ---- head ----
     const float* demb = c.f32(p->dpred_off);
@@ -934,7 +960,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 if (r != hipSuccess) return r;
                 slab_free[slab_turn] = nullptr;
             }
-            return run_conv_wgrad(c, cv, dz, dzpad, x, s, slab_turn, &reduce_on_side);
+            return run_conv_wgrad(c, cv, dz, dzpad, x, s, slab_turn, &reduce_on_side, nullptr, prezeroed);
         }
         if (fork) {
             hipEvent_t e = next_event();
@@ -943,7 +969,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             r = hipStreamWaitEvent(p->side, e, 0);
             if (r != hipSuccess) return r;
         }
-        return run_conv_wgrad(c, cv, dz, dzpad, x, ws_stream);
+        return run_conv_wgrad(c, cv, dz, dzpad, x, ws_stream, 0, nullptr, nullptr, prezeroed);
     };
     // main stream must not overwrite a dz buffer the side stream may still be reading
     hipEvent_t dz_free[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
