@@ -148,6 +148,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    # one-time setup that is not a "step": build the plan / workspace, and bring the RCCL communicator up
+    eng.plan(HW, HW, args.batch, True, False)
+    if world > 1:
+        t = torch.zeros(1, device=device)
+        torch.distributed.all_reduce(t)
+    torch.cuda.synchronize(device)
+
     for _ in range(args.warmup):
         one_step()
     sync()
