@@ -284,3 +284,47 @@ def test_ragged_batches_and_graph():
     enc.engine.launch_eval_graph(pl, 11)
     torch.cuda.synchronize()
     assert np.allclose(out.cpu().numpy(), full, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("cfg", [("resnet18", 96, 5, 3), ("resnet18", 160, 3, 2), ("resnet34", 32, 5, 7), ("resnet18", 224, 5, 1),
+                                 ("resnet50", 96, 5, 2)],
+                         ids=["r18_96px_n3", "r18_160px_rgb_n2", "r34_32px_n7", "r18_224px_n1", "r50_96px_n2"])
+def test_other_image_sizes_and_tiny_batches(cfg):
+    """Image sizes whose feature maps do not fit the halo tilings (96 -> 24/12/6/3 pixel rows, 160 -> 40/20/10/5,
+    224 -> 56/28/14/7, 32 -> 8/4/2/1) take the generic kernels; batches of 1..7 crops leave most tiles ragged.
+    Eval embeddings and the train-mode loss against the fp32 oracle, and the backward pass in the well-conditioned
+    regime of test_backward_in_a_well_conditioned_regime."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    arch, hw, c_in, n = cfg
+    sd = O.reference_init_state_dict(arch, c_in, 32, 11)
+    last = ".bn3.weight" if O.arch_expansion(arch) == 4 else ".bn2.weight"
+    for k in sd:
+        if k.endswith(last):
+            sd[k] = sd[k] * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = sd[k] * 0.5 + 0.25          # non-trivial eval-mode statistics
+    enc = RGBF_EmbeddingModel(arch, 32, c_in == 5, "cuda")
+    enc.load_state_dict(sd)
+    tr = ModelTrainer(enc, False)
+    orc = O.StudentOracle(arch, c_in, 32, False, sd, None)
+    img, tgt = O.synthetic_crops(n, c_in, hw, 5), O.synthetic_targets(n, 32, False, 6)
+    e = enc.embed(img.numpy())
+    e_ref = O.embed(orc.enc, img, arch, c_in == 5)
+    assert per_sample_rel(e, e_ref).max() <= EMB_TOL, per_sample_rel(e, e_ref)
+    if n * (hw // 32) ** 2 < 8:
+        return                                   # train-mode BN over fewer than 8 values per channel in layer4: eval only
+    enc.train()
+    loss = tr._forward_loss(img, tgt, train=True)
+    l_hip = loss.item()
+    loss.backward()
+    torch.cuda.synchronize()
+    l_ref, _, _, grads_ref = orc.forward_loss(img, tgt, train=True, need_grad=True)
+    assert abs(l_hip - l_ref) <= LOSS_TOL * l_ref, (l_hip, l_ref)
+    num = den = nh = 0.0
+    for name, p in enc.named_parameters():
+        r = grads_ref["enc." + name].double().flatten()
+        gh = p.grad.detach().cpu().double().flatten()
+        num += float((gh * r).sum()); den += float((r * r).sum()); nh += float((gh * gh).sum())
+    cos, proj = num / (den * nh) ** 0.5, num / den
+    assert cos >= 0.9 and 0.9 <= proj <= 1.1, (cos, proj)
