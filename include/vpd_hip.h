@@ -36,8 +36,9 @@ int vpd_abi_version(void);
  * Replaces the module construction of RGBF_EmbeddingModel.__init__ (models/rgb.py:46-66),
  * ResNet.__init__/_make_layer (models/module.py:35-110) and, when motion != 0,
  * FCNet(emb_dim,[128,128],2*emb_dim) (train_vpd_model.py:61-65).
- * arch: "resnet18" | "resnet34" (models/module.py:17-21).  train != 0 reserves
- * the activations / gradients a train step needs. */
+ * arch: "resnet18" | "resnet34" (BasicBlock) | "resnet50" | "resnet101" | "wide_resnet50_2" | "wide_resnet101_2"
+ * (Bottleneck) -- the ResNet entries of ENCODER_ARCH (models/module.py:17-32).  train != 0 reserves the
+ * activations / gradients a train step needs. */
 int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
                     int max_batch, int train, vpd_plan_t** out);
 void vpd_plan_destroy(vpd_plan_t* plan);
