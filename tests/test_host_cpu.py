@@ -121,3 +121,41 @@ def test_synthetic_dataset_is_seeded_and_in_range():
     a, b = ds[2], ds[2]
     assert torch.equal(a["img"], b["img"]) and a["img"].shape == (5, 64, 64) and a["emb"].shape == (32,)
     assert float(a["img"][3:].abs().max()) <= 0.5
+
+
+def test_frame_dataset_jitter_views(tmp_path):
+    """apply --jitter: view order [orig, j x jit(orig), j x jit(flip), flip] (reference Appendix B.8), ColorJitter applied
+    to the NORMALISED image exactly as the oracle's restatement of torchvision's ops composes it."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from oracle import augment_oracle as AO
+    from vpd_amd.data import FrameDataset, color_jitter, load_flow, load_rgb
+    rs = np.random.RandomState(0)
+    d = tmp_path / "vid"
+    d.mkdir()
+    Image.fromarray(rs.randint(0, 256, (32, 32, 3)).astype(np.uint8)).save(d / "7.png")
+    Image.fromarray(rs.randint(0, 256, (32, 32, 3)).astype(np.uint8)).save(d / "7.flow.png")
+    mean_std = ((0.34, 0.46, 0.52), (0.16, 0.17, 0.19))
+    base = load_rgb(str(d / "7.png"), 32, mean_std)
+    flow = load_flow(str(d / "7.flow.png"), 32)
+    # color_jitter == the oracle's ops in the sampled order with the sampled factors (same RNG draws)
+    torch.manual_seed(5)
+    got = color_jitter(base)
+    torch.manual_seed(5)
+    order, f = AO.color_jitter_params()
+    exp = base
+    for op in order:
+        exp = AO._OPS[op](exp, f[op])
+    assert torch.allclose(got, exp, atol=1e-6) and float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    ds = FrameDataset([(0, 7, str(d / "7"))], 32, mean_std, augment_jitter=2, augment_flip=True, flow_img_name="flow")
+    item = ds[0]
+    v = item["img"]
+    assert v.shape == (6, 5, 32, 32) and item["frame"] == 7
+    assert torch.equal(v[0, :3], base) and torch.equal(v[0, 3:], flow)
+    assert torch.equal(v[5, :3], torch.flip(base, (2,)))                       # the plain flip is LAST
+    assert torch.equal(v[5, 3], -torch.flip(flow[0], (1,))) and torch.equal(v[5, 4], torch.flip(flow[1], (1,)))
+    for k in (1, 2, 3, 4):                                                     # jittered views: clamped to [0, 1], unflipped flow
+        assert float(v[k, :3].min()) >= 0.0 and float(v[k, :3].max()) <= 1.0 and torch.equal(v[k, 3:], flow)
+    plain = FrameDataset([(0, 7, str(d / "7"))], 32, mean_std, augment_flip=False)[0]["img"]
+    assert plain.shape == (1, 3, 32, 32)

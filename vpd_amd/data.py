@@ -150,12 +150,68 @@ class TeacherEmbDataset(torch.utils.data.Dataset):
         return mk(train_data, target_len), mk(val_data, int(target_len * 0.2)), emb_dim
 
 
+def _blend(a, b, ratio):
+    return (ratio * a + (1.0 - ratio) * b).clamp(0, 1.0)
+
+
+def _grey(img):
+    r, g, b = img.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(dim=-3)
+
+
+def _adjust_hue(img, f):
+    """torchvision's adjust_hue for float CHW tensors (RGB -> HSV, h = (h + f) mod 1, HSV -> RGB)."""
+    r, g, b = img.unbind(dim=-3)
+    maxc, minc = torch.max(img, dim=-3).values, torch.min(img, dim=-3).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    div = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+    h = (maxc == r) * (bc - gc) + ((maxc == g) & (maxc != r)) * (2.0 + rc - bc) + \
+        ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = (torch.fmod(h / 6.0 + 1.0, 1.0) + f) % 1.0
+    v = maxc
+    i = torch.floor(h * 6.0)
+    fr = h * 6.0 - i
+    i = i.to(torch.int32) % 6
+    p = torch.clamp(v * (1.0 - s), 0.0, 1.0)
+    q = torch.clamp(v * (1.0 - s * fr), 0.0, 1.0)
+    t = torch.clamp(v * (1.0 - s * (1.0 - fr)), 0.0, 1.0)
+    mask = i.unsqueeze(dim=-3) == torch.arange(6).view(-1, 1, 1)
+    a4 = torch.stack((torch.stack((v, q, p, p, t, v), dim=-3), torch.stack((t, v, v, q, p, p), dim=-3),
+                      torch.stack((p, p, t, v, v, q), dim=-3)), dim=-4)
+    return torch.einsum("...ijk, ...xijk -> ...xjk", mask.to(img.dtype), a4)
+
+
+def color_jitter(img, brightness=0.2, contrast=0.2, saturation=0.05, hue=0.05):
+    """transforms.ColorJitter(**JITTER_KWARGS) (vpd_dataset/common.py:11-12) on a float CHW tensor: the four ops in a
+    random order with factors drawn as ColorJitter.get_params does.  The inference views of the reference apply it to
+    the NORMALISED image (vpd_dataset/single_frame.py:366-379), whose values outside [0, 1] the
+    ops clamp -- reproduced as is."""
+    order = torch.randperm(4).tolist()
+    u = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi))
+    fb, fc, fs, fh = u(1 - brightness, 1 + brightness), u(1 - contrast, 1 + contrast), \
+        u(1 - saturation, 1 + saturation), u(-hue, hue)
+    for op in order:
+        if op == 0:
+            img = _blend(img, torch.zeros_like(img), fb)
+        elif op == 1:
+            img = _blend(img, torch.mean(_grey(img), dim=(-3, -2, -1), keepdim=True), fc)
+        elif op == 2:
+            img = _blend(img, _grey(img), fs)
+        else:
+            img = _adjust_hue(img, fh)
+    return img
+
+
 class FrameDataset(torch.utils.data.Dataset):
-    """Inference items {'video', 'frame', 'img': [k, C, H, W]} with k = 1 (+1 h-flip view)."""
+    """Inference items {'video', 'frame', 'img': [k, C, H, W]}: views [orig, j x jitter(orig), j x jitter(flip), flip]
+    (reference vpd_dataset/single_frame.py:361-403, order of Appendix B.8)."""
 
     def __init__(self, tasks, img_dim, rgb_mean_std, augment_jitter=0, augment_flip=False, flow_img_name=None):
-        if augment_jitter:
-            raise NotImplementedError('--jitter views need ColorJitter (next row f1)')
+        self.jitter_count = int(augment_jitter or 0)
         self.tasks, self.img_dim, self.rgb_mean_std = tasks, img_dim, rgb_mean_std
         self.flip, self.flow_img_name = augment_flip, flow_img_name
 
@@ -165,8 +221,12 @@ class FrameDataset(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         video, frame_num, prefix = self.tasks[idx]
         img = load_rgb('{}.png'.format(prefix), self.img_dim, self.rgb_mean_std)
-        imgs = [img]
-        flips = [torch.flip(img, (2,))] if self.flip else []
+        imgs = [img] + [color_jitter(img) for _ in range(self.jitter_count)]
+        flips = []
+        if self.flip:
+            flip_img = torch.flip(img, (2,))
+            flips = [flip_img]
+            imgs += [color_jitter(flip_img) for _ in range(self.jitter_count)]      # jittered flips join `imgs` (B.8)
         if self.flow_img_name is not None:
             flow = load_flow('{}.{}.png'.format(prefix, self.flow_img_name), self.img_dim)
             imgs = [torch.cat((x, flow)) for x in imgs]
