@@ -8,7 +8,7 @@ from torch.utils.data import DataLoader
 
 from vpd_amd import paths as dataset_paths
 from vpd_amd.apply import StreamingWriter, apply_batch_size, embed_dataset
-from vpd_amd.data import FrameDataset, list_crop_dir
+from vpd_amd.data import FrameDataset, list_crop_dir, list_tennis_crops
 from vpd_amd.io import load_json
 from vpd_amd.models.rgb import RGBF_EmbeddingModel
 
@@ -45,8 +45,9 @@ def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
     print('RGB mean & std:', rgb_mean_std)
 
     if dataset == 'tennis':
-        raise NotImplementedError('tennis uses per-player crop naming (apply_vpd_model.py:36-66): not yet mirrored')
-    videos, tasks = list_crop_dir(dataset_paths.CROPS[dataset])
+        videos, tasks = list_tennis_crops(dataset_paths.TENNIS_VIDEO_DIR, dataset_paths.TENNIS_CROP_DIR)
+    else:
+        videos, tasks = list_crop_dir(dataset_paths.CROPS[dataset])
     ds = FrameDataset(tasks, img_dim, rgb_mean_std, augment_jitter=jitter or 0, augment_flip=not no_flip,
                       flow_img_name=flow_img)
 

@@ -159,3 +159,22 @@ def test_frame_dataset_jitter_views(tmp_path):
         assert float(v[k, :3].min()) >= 0.0 and float(v[k, :3].max()) <= 1.0 and torch.equal(v[k, 3:], flow)
     plain = FrameDataset([(0, 7, str(d / "7"))], 32, mean_std, augment_flip=False)[0]["img"]
     assert plain.shape == (1, 3, 32, 32)
+
+
+def test_tennis_crop_listing(tmp_path):
+    """apply_vpd_model.get_tennis_dataset: two pseudo-videos per clip, frame numbers relative to the clip start."""
+    from vpd_amd.data import list_tennis_crops
+    vd, cd = tmp_path / "videos", tmp_path / "crops"
+    vd.mkdir()
+    (vd / "match_a_100_103.mp4").write_bytes(b"")
+    (vd / "notes.txt").write_bytes(b"")
+    for player, frames in (("front", (100, 102, 103)), ("back", ())):
+        d = cd / "match_a" / player
+        d.mkdir(parents=True)
+        for f in frames:
+            (d / ("%d.png" % f)).write_bytes(b"")
+        (d / "999.png").write_bytes(b"")            # outside the clip
+    videos, tasks = list_tennis_crops(str(vd), str(cd))
+    assert videos == ["front__match_a_100_103", "back__match_a_100_103"]
+    assert [(v, f) for v, f, _ in tasks] == [(0, 0), (0, 2), (0, 3)]
+    assert tasks[1][2].endswith("match_a/front/102")

@@ -254,6 +254,31 @@ def list_crop_dir(crop_dir):
     return videos, tasks
 
 
+def list_tennis_crops(video_dir, crop_dir):
+    """apply_vpd_model.get_tennis_dataset (:36-66): every <name>_<start>_<end>.mp4 yields two "videos",
+    front__<clip> and back__<clip>, whose crops live in <crop_dir>/<name>/<player>/<absolute frame>.png; the frame
+    number stored in the pickle is relative to the clip's start."""
+    tasks, videos = [], []
+    for video_file in sorted(os.listdir(video_dir)):
+        if not video_file.endswith('.mp4'):
+            continue
+        clip = os.path.splitext(video_file)[0]
+        src_name, start, end = clip.rsplit('_', 2)
+        start, end = int(start), int(end)
+        for player in ('front', 'back'):
+            vid = len(videos)
+            videos.append('{}__{}'.format(player, clip))
+            count = 0
+            for fr in range(start, end + 1):
+                prefix = os.path.join(crop_dir, src_name, player, str(fr))
+                if os.path.isfile(prefix + '.png'):
+                    tasks.append((vid, fr - start, prefix))
+                    count += 1
+            if count == 0:
+                print('{} has no crops'.format(videos[-1]))
+    return videos, tasks
+
+
 class SyntheticCrops(torch.utils.data.Dataset):
     """Seeded synthetic crops + teacher targets in the reference's value ranges (no files)."""
 
