@@ -178,3 +178,25 @@ def test_tennis_crop_listing(tmp_path):
     assert videos == ["front__match_a_100_103", "back__match_a_100_103"]
     assert [(v, f) for v, f, _ in tasks] == [(0, 0), (0, 2), (0, 3)]
     assert tasks[1][2].endswith("match_a/front/102")
+
+
+def test_tennis_teacher_ingestion(tmp_path):
+    """TennisDataset.load_default: <player>__<video>_<start>_<end>.emb.pkl -> items addressing
+    <video>/<player>/<start + frame>.png, pose-score filter (dp_score before kp_score), embed_time pairing."""
+    import numpy as np
+    from vpd_amd.data import load_tennis_default
+    from vpd_amd.io import store_pickle
+    emb_dir = tmp_path / "embs"
+    emb_dir.mkdir()
+    rs = np.random.RandomState(0)
+    for clip in range(5):
+        embs = [(f, rs.randn(2, 8).astype(np.float32), {"kp_score": 0.9, "dp_score": (0.1 if f == 2 else 0.8)})
+                for f in (0, 1, 2, 3, 5)]
+        store_pickle(str(emb_dir / ("front__m%d_100_105.emb.pkl" % clip)), embs)
+    tr, va, d = load_tennis_default(str(emb_dir), "/crops", 128, True, 1000, ((0,) * 3, (1,) * 3), flow_img_name="flow")
+    assert d == 8 and len(tr) == 1000 and len(va) == 200
+    items = tr.data + va.data
+    assert len(items) == 5 * 2                                  # per clip: frames 1 and 3 (0 first, 2 filtered, 5 no predecessor)
+    assert {it[1] for it in items} == {101, 103} and all(it[0].endswith("/front") for it in items)
+    assert all(it[2].shape == (2, 16) for it in items)          # [emb, emb - prev] along the feature axis
+    assert len({it[0] for it in tr.data} & {it[0] for it in va.data}) == 0      # split over clips

@@ -10,7 +10,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from vpd_amd import paths as dataset_paths
-from vpd_amd.data import RGB_MEAN_STD, SyntheticCrops, TeacherEmbDataset
+from vpd_amd.data import RGB_MEAN_STD, SyntheticCrops, TeacherEmbDataset, load_tennis_default
 from vpd_amd.io import store_json
 from vpd_amd.models.rgb import RGBF_EmbeddingModel
 from vpd_amd.trainer import ModelTrainer
@@ -57,6 +57,8 @@ def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
         raise NotImplementedError('--no_test_video needs the reference action_dataset split lists (out of scope)')
     if emb_dir is None:
         emb_dir = os.path.join(dataset_paths.ROOT[dataset], 'embs')
+    if dataset == 'tennis':          # per-player crop directories, split over clips (train_vpd_model.py:121-128)
+        return load_tennis_default(emb_dir, dataset_paths.CROPS[dataset], **dataset_kwargs)
     return TeacherEmbDataset.load_default(emb_dir, dataset_paths.CROPS[dataset], **dataset_kwargs)
 
 

@@ -64,7 +64,13 @@ def load_flow(path, img_dim):
 
 
 def _pose_score(meta):
-    return meta.get('kp_score', 1.) if isinstance(meta, dict) else 1.
+    """_get_pose_score (vpd_dataset/single_frame.py:33-44): dp_score, else kp_score; student pickles carry neither."""
+    if not isinstance(meta, dict):
+        return 1.
+    for k in ('dp_score', 'kp_score'):
+        if meta.get(k) is not None:
+            return meta[k]
+    return 1.
 
 
 class TeacherEmbDataset(torch.utils.data.Dataset):
@@ -204,6 +210,51 @@ def color_jitter(img, brightness=0.2, contrast=0.2, saturation=0.05, hue=0.05):
         else:
             img = _adjust_hue(img, fh)
     return img
+
+
+def load_tennis_default(emb_dir, img_dir, img_dim, embed_time, target_len, rgb_mean_std, flow_img_name=None,
+                        min_pose_score=None, exclude_prefixes=None):
+    """TennisDataset.load_default (vpd_dataset/single_frame.py:88-162): teacher pickles are named
+    <player>__<video>_<start>_<end>.emb.pkl with clip-relative frame numbers, crops live in
+    <img_dir>/<video>/<player>/<start + frame>.png, and the 80/20 split is over CLIPS, not frames."""
+    thresh = DEFAULT_MIN_POSE_SCORE if min_pose_score is None else min_pose_score
+    clips, emb_dim = [], None
+    for emb_file in sorted(os.listdir(emb_dir)):
+        if not emb_file.endswith(EMB_FILE_SUFFIX):
+            continue
+        name = emb_file.split(EMB_FILE_SUFFIX)[0]
+        if exclude_prefixes is not None and name.startswith(tuple(exclude_prefixes)):
+            print('Excluded:', name)
+            continue
+        video_embs = load_pickle(os.path.join(emb_dir, emb_file))
+        clips.append((name, video_embs))
+        if emb_dim is None:
+            emb_dim = video_embs[0][1].shape[-1]
+        assert emb_dim == video_embs[0][1].shape[-1]
+
+    def items(clip_list):
+        out = []
+        for name, video_embs in clip_list:
+            player, rest = name.split('__', 1)
+            video_name, start_frame, _ = rest.rsplit('_', 2)
+            for i, (frame_num, emb_target, emb_meta) in enumerate(video_embs):
+                if _pose_score(emb_meta) < thresh:
+                    continue
+                if embed_time:
+                    if i == 0 or video_embs[i - 1][0] != frame_num - 1:
+                        continue
+                    emb_target = np.concatenate([emb_target, emb_target - video_embs[i - 1][1]],
+                                                axis=0 if len(emb_target.shape) == 1 else 1)
+                out.append((os.path.join(video_name, player), int(start_frame) + frame_num, emb_target, emb_meta))
+        return out
+
+    print('Videos:', len(clips))
+    random.shuffle(clips)                            # unseeded, like train_test_split(videos, test_size=0.2)
+    n_val = int(round(0.2 * len(clips)))
+    val, train = items(clips[:n_val]), items(clips[n_val:])
+    key = lambda x: x[:2]
+    mk = lambda d, n: TeacherEmbDataset(sorted(d, key=key), img_dir, img_dim, rgb_mean_std, n, flow_img_name=flow_img_name)
+    return mk(train, target_len), mk(val, int(target_len * 0.2)), emb_dim
 
 
 class FrameDataset(torch.utils.data.Dataset):
