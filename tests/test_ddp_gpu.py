@@ -44,3 +44,74 @@ def test_bucket_reducer_world1_matches_plain_run():
         assert np.allclose(res[0][1], res[1][1], rtol=1e-3)
     finally:
         dist.destroy_process_group()
+
+
+def _rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    from vpd_amd.ddp import shard_slice
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves the CUDA buckets through the host
+    try:
+        torch.cuda.set_device(0)
+        sd = O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 2)
+        img = O.synthetic_crops(10, 5, 64, 3)
+        tgt = O.synthetic_targets(10, 32, False, 4)
+        sl = shard_slice(10, rank, world)
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+        enc.load_state_dict(sd)
+        tr = ModelTrainer(enc, False, process_group=dist.group.WORLD)
+        opt, sc = tr.get_optimizer(5e-4)
+        enc.train()
+        loss = tr._forward_loss(img[sl], tgt[sl], train=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = enc.engine.grads.clone().cpu().numpy()
+        ep = tr.epoch([{"img": img[sl], "emb": tgt[sl]}], optimizer=opt, scaler=sc)      # all-reduced loss / count
+        w = enc.engine.params.clone().cpu().numpy()
+        q.put((rank, g, ep, w))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
+    """world_size 2 (two processes, both on this GPU, gloo transport): after the bucketed all-reduce every rank holds
+    the SUM of the two shards' gradients (per-shard BatchNorm statistics, as SURVEY 8e), the epoch value is the
+    global sum-MSE per crop, and both ranks take the same AdamW step."""
+    import torch.multiprocessing as mp
+    from vpd_amd.ddp import shard_slice
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29547, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, ep0, w0), (_, g1, ep1, w1) = res
+    assert np.array_equal(g0, g1) and ep0 == ep1
+    assert np.allclose(w0, w1, rtol=0, atol=1e-7)
+    # single-process emulation: each shard alone (its own batch statistics), gradients summed
+    sd = O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 2)
+    img, tgt = O.synthetic_crops(10, 5, 64, 3), O.synthetic_targets(10, 32, False, 4)
+    total, loss_sum = None, 0.0
+    for r in range(2):
+        sl = shard_slice(10, r, 2)
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+        enc.load_state_dict(sd)
+        tr = ModelTrainer(enc, False)
+        enc.train()
+        loss = tr._forward_loss(img[sl], tgt[sl], train=True)
+        loss_sum += loss.item()
+        loss.backward()
+        torch.cuda.synchronize()
+        g = enc.engine.grads.clone().cpu().numpy()
+        total = g if total is None else total + g
+    rel = np.linalg.norm(g0 - total) / np.linalg.norm(total)
+    assert rel < 1e-3, rel                      # fp32 atomics: order of summation varies run to run (measured ~1e-6)
+    assert abs(ep0 - loss_sum / 10) <= 1e-4 * abs(ep0)
