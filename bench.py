@@ -123,7 +123,11 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("VPD_DIST_BACKEND", "nccl")      # "nccl" is RCCL; gloo only for single-GPU dry runs of this path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
     from vpd_amd.trainer import ModelTrainer
@@ -169,20 +173,25 @@ def main():
         dt = float(t.item())
     loss_now = float(eng.loss_step.item())
 
+    # ---- instrumented steps for the roofline: EVERY rank runs them (they contain the gradient all-reduce; a rank that
+    # ran them alone would wait for its peers forever), rank 0 arms the per-kernel dispatch events and reads them ----
+    pl = eng.plan(HW, HW, args.batch, True, False)
+    if rank == 0:
+        eng.set_timing(pl, True)
+    for _ in range(args.profile_steps):
+        one_step()
+    sync()
+    cls = {}
+    if rank == 0:
+        cls = eng.read_timing(pl) if args.profile_steps > 0 else {}
+        eng.set_timing(pl, False)
+
     out = None
     if rank == 0:
         crops = args.batch * world * args.steps
         value = crops / dt
         flop = train_flop_per_crop(args.arch, C_IN, HW, EMB_DIM)
         assert (args.arch, C_IN) not in TRAIN_FLOP_PER_CROP or flop == TRAIN_FLOP_PER_CROP[(args.arch, C_IN)]
-        # ---- roofline of the dominant kernel class: HIP events around each conv launch, on its stream ----
-        pl = eng.plan(HW, HW, args.batch, True, False)
-        eng.set_timing(pl, True)
-        for _ in range(args.profile_steps):
-            one_step()
-        torch.cuda.synchronize(device)
-        cls = eng.read_timing(pl) if args.profile_steps > 0 else {}
-        eng.set_timing(pl, False)
         kernels = {}
         for k, v in cls.items():
             if v["launches"] > 0:
