@@ -70,7 +70,7 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
         rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        torch.distributed.init_process_group('nccl')
+        torch.distributed.init_process_group(os.environ.get('VPD_DIST_BACKEND', 'nccl'))      # 'nccl' = RCCL
     rgb_mean_std = RGB_MEAN_STD['resnet' if pretrained else dataset]
 
     if synthetic is not None:
