@@ -15,6 +15,7 @@
 // element.
 #include <stdlib.h>
 
+#include <string.h>
 #include "common.h"
 
 static __device__ __forceinline__ int wg_swz(int r, int c16) {
@@ -201,7 +202,7 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
 // MFMA-wave body of conv_wgrad_halo_kernel for taps [T0, T1): ci columns 16*ctile .. +15, all 64 co.
 template <int T0, int T1>
 static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, const WgHaloGeom& g, const bf16_t* ring,
-                                                       int STAGE, int nch, int ctile, int lane) {
+                                                       int STAGE, int nch, int ctile, int lane, int bx, int by) {
     constexpr int NT = T1 - T0;
     const int W = p.Ws, H = p.Hs, Wp = W + 2;
     f32x4 acc[NT][4];
@@ -275,9 +276,9 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
     // acc[t][a][j] = partial dW[tap T0+t][co0 + a*16 + 4*gq + j][ci0 + 16*ctile + i16]
     if (VPD_ABL(p, 8)) return;
     const int kct = p.Kc >> 6;
-    const int co0 = (blockIdx.x / kct) * 64;
-    const int ci0 = (blockIdx.x % kct) * 64;
-    float* slab = p.slab + (size_t)blockIdx.y * 9 * p.Co * p.Kc;
+    const int co0 = (bx / kct) * 64;
+    const int ci0 = (bx % kct) * 64;
+    float* slab = p.slab + (size_t)by * 9 * p.Co * p.Kc;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tt = T0 + t;
@@ -293,9 +294,9 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #define WG_CH 64           // pixels per chunk = two MFMA K-steps (vpd_wgrad_split assumes 64)
 #define WG_NS 3            // ring stages
 
-// NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS)
+// NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS).  (bx, by) = (output tile, pixel split) of this block.
 template <int NPASS>
-__global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
+static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, const WgHaloGeom& g, int bx, int by) {
     constexpr int HROWS = 32 * NPASS;
     constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile then halo
     constexpr int PER_CHUNK = 2 + NPASS;                          // LDS-DMA instructions per loader wave per chunk
@@ -309,10 +310,10 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.Ws, H = p.Hs, Wp = W + 2;
     const int kct = p.Kc >> 6;
-    const int co0 = (blockIdx.x / kct) * 64;
-    const int ci0 = (blockIdx.x % kct) * 64;
+    const int co0 = (bx / kct) * 64;
+    const int ci0 = (bx % kct) * 64;
     const int nchunks_total = (p.M + WG_CH - 1) / WG_CH;
-    const int chunk_begin = blockIdx.y * g.cpb;
+    const int chunk_begin = by * g.cpb;
     int chunk_end = chunk_begin + g.cpb;
     chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
     const int nch = chunk_end - chunk_begin;                      // >= 1 by construction of ksplit
@@ -375,9 +376,74 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
 
     // ------------------------- MFMA waves -------------------------
     const int ctile = wave & 3;
-    if (wave < 4) wgrad_mfma_half<0, 5>(p, g, ring, STAGE, nch, ctile, lane);
-    else wgrad_mfma_half<5, 9>(p, g, ring, STAGE, nch, ctile, lane);
+    if (wave < 4) wgrad_mfma_half<0, 5>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
+    else wgrad_mfma_half<5, 9>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
 }
+
+template <int NPASS>
+__global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
+    wgrad_halo_body<NPASS>(p, g, blockIdx.x, blockIdx.y);
+}
+
+// Grouped launch: the weight gradients of SEVERAL convolutions of one ResNet stage in one grid.  A weight gradient
+// only needs dz and the saved activation, so it can wait until the stage's backward is done; one launch then
+// carries 6-12 problems, which (1) pays the ~10 us fixed cost of a launch once instead of per layer, (2) gives the
+// chip thousands of blocks, so each block can take 4x more pixels and the split-K slab shrinks 4x (layer4 needs none:
+// its blocks write the gradient itself), and (3) leaves no one-block-per-CU tail between layers.
+#define WG_GROUP_MAX 12
+struct WgGroup {
+    int nprob;
+    int task_begin[WG_GROUP_MAX + 1];          // first grid block of each problem
+    int tiles[WG_GROUP_MAX];
+    WgradParams p[WG_GROUP_MAX];
+    WgHaloGeom g[WG_GROUP_MAX];
+};
+template <int NPASS>
+__global__ __launch_bounds__(768) void conv_wgrad_halo_grouped_kernel(const WgGroup grp) {
+    const int t = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < grp.nprob; ++i)
+        if (t >= grp.task_begin[i]) pi = i;
+    const int local = t - grp.task_begin[pi];
+    const int tiles = grp.tiles[pi];
+    wgrad_halo_body<NPASS>(grp.p[pi], grp.g[pi], local % tiles, local / tiles);
+}
+
+// slab sums of a group in one launch: blockIdx.y = problem (problems whose blocks wrote the gradient directly have ksplit 1
+// and are skipped by the launcher)
+struct WgReduceGroup {
+    int nprob;
+    const float4* slab[WG_GROUP_MAX];
+    float4* dw[WG_GROUP_MAX];
+    long n4[WG_GROUP_MAX];
+    int ksplit[WG_GROUP_MAX];
+};
+__global__ __launch_bounds__(1024) void wgrad_slab_reduce_group_kernel(const WgReduceGroup r, int groups) {
+    __shared__ float4 sh[16][64];
+    const int pi = blockIdx.y;
+    const long n4 = r.n4[pi];
+    const int ksplit = r.ksplit[pi];
+    const float4* slab = r.slab[pi];
+    const int o = threadIdx.x & 63, gi = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + o;
+    if ((long)blockIdx.x * 64 >= n4) return;                      // block-uniform
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int s2 = gi; s2 < ksplit; s2 += groups) {
+            const float4 v = slab[(long)s2 * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    sh[gi][o] = a;
+    __syncthreads();
+    if (gi == 0 && i < n4) {
+        for (int k = 1; k < groups; ++k) {
+            const float4 v = sh[k][o];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        r.dw[pi][i] = a;
+    }
+}
+
 
 // ---------------------------------------------------------------------------
 // Stem weight gradient (7x7 stride 2, 8-channel border-3 input, 64 output channels):
@@ -604,6 +670,77 @@ hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
     const int groups = ksplit < 16 ? ksplit : 16;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
                        (const float4*)p.slab, (float4*)p.dw, n4, ksplit, groups);
+    return hipGetLastError();
+}
+
+// ---- grouped launch (see WgGroup) ----
+// chunks per block: 4x the per-layer kernel's 16, i.e. 64 pixel chunks of 64 pixels (VPD_WG_GROUP_CPB overrides)
+static int wg_group_cpb() {
+    static const int v = getenv("VPD_WG_GROUP_CPB") ? atoi(getenv("VPD_WG_GROUP_CPB")) : 64;
+    return v < 1 ? 1 : v;
+}
+int vpd_wgrad_group_ksplit(int M) {
+    const int nchunks = (M + WG_CH - 1) / WG_CH;
+    const int cpb = wg_group_cpb();
+    return (nchunks + cpb - 1) / cpb;
+}
+// slab floats a problem needs in a grouped launch (0: its blocks write dw directly)
+size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc) {
+    const int ks = vpd_wgrad_group_ksplit(M);
+    return ks <= 1 ? 0 : (size_t)ks * 9 * Co * Kc;
+}
+bool vpd_wgrad_group_eligible(const WgradParams& p) {
+    WgHaloGeom g;
+    WgradParams q = p;
+    if (!q.slab) q.slab = reinterpret_cast<float*>(16);          // eligibility does not depend on the slab address
+    return vpd_wgrad_overwrites(q) && wg_halo_geom(q, &g);
+}
+// ps[i].slab must point to vpd_wgrad_group_slab_floats() floats of its own (ignored when that is 0)
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream) {
+    if (n < 1 || n > WG_GROUP_MAX) return hipErrorInvalidValue;
+    static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+    WgGroup grp = {};
+    WgReduceGroup red = {};
+    grp.nprob = n;
+    int tasks = 0, npass = 0, max_ks = 1;
+    long max_n4 = 0;
+    for (int i = 0; i < n; ++i) {
+        WgradParams p = ps[i];
+        p.ablate = ablate;
+        WgHaloGeom g;
+        if (!wg_halo_geom(p, &g)) return hipErrorInvalidValue;
+        const int np = (g.NHP + 31) / 32;
+        if (npass == 0) npass = np;
+        if (np != npass) return hipErrorInvalidValue;             // one stage: one geometry
+        const int nchunks = (p.M + WG_CH - 1) / WG_CH;
+        g.cpb = wg_group_cpb();
+        g.ksplit = (nchunks + g.cpb - 1) / g.cpb;
+        if (g.ksplit <= 1) p.slab = p.dw;                         // split 0 of a 1-split problem IS the gradient
+        else {
+            red.slab[red.nprob] = reinterpret_cast<const float4*>(p.slab);
+            red.dw[red.nprob] = reinterpret_cast<float4*>(p.dw);
+            red.n4[red.nprob] = (long)9 * p.Co * p.Kc / 4;
+            red.ksplit[red.nprob] = g.ksplit;
+            max_n4 = red.n4[red.nprob] > max_n4 ? red.n4[red.nprob] : max_n4;
+            max_ks = g.ksplit > max_ks ? g.ksplit : max_ks;
+            ++red.nprob;
+        }
+        grp.tiles[i] = (p.Co / 64) * (p.Kc / 64);
+        grp.task_begin[i] = tasks;
+        tasks += grp.tiles[i] * g.ksplit;
+        grp.p[i] = p;
+        grp.g[i] = g;
+    }
+    grp.task_begin[n] = tasks;
+    const size_t lds = (size_t)WG_NS * (WG_CH + 32 * (npass <= 3 ? 3 : npass)) * 64 * sizeof(bf16_t);
+    if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<3>, dim3(tasks), dim3(768), lds, stream, grp);
+    else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<4>, dim3(tasks), dim3(768), lds, stream, grp);
+    else VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<5>, dim3(tasks), dim3(768), lds, stream, grp);
+    if (red.nprob > 0 && !(ablate & 16)) {
+        const int groups = max_ks < 16 ? max_ks : 16;
+        hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),
+                           0, stream, red, groups);
+    }
     return hipGetLastError();
 }
 

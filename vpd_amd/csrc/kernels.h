@@ -58,6 +58,10 @@ hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
 size_t vpd_wgrad_slab_bytes();
+// grouped (per-stage, deferred) weight gradients: see WgGroup in conv_wgrad.hip
+bool vpd_wgrad_group_eligible(const WgradParams& p);
+size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc);
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
 bool vpd_wgrad_overwrites(const WgradParams& p);
 bool vpd_wgrad_halo_shape_ok(int Hout, int Wout);
 

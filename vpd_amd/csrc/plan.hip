@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <functional>
 #include <vector>
 
@@ -53,6 +54,8 @@ struct ConvInfo {
     long long fwd_off = 0, dgr_off = -1; // bf16 element offsets in the weight arena
     long long wg_off = 0;                // fp32 element offset in the wgrad scratch
     long long slab_off = -1;             // fp32 element offset of this conv's split slabs (3x3 s1 convs) or -1
+    size_t dz_own_off = 0;               // grouped weight gradients: this conv's own padded dz buffer (kept until the stage's launch)
+    long long gslab_off = 0;             // ... and its slab inside the stage's grouped slab (floats)
     BnInfo bn;
     size_t z_off = 0;                    // dense bf16 conv output (train)
 };
@@ -116,6 +119,8 @@ struct vpd_plan {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_pool2;          // fork/join events, reused every step
     size_t ev_next = 0;
+    bool wg_group = true;       // per-stage grouped weight gradients (VPD_WG_GROUP=0: one launch per conv)
+    size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest stage
     bool two_streams = false;   // measured: no gain (conv kernels fill every CU's VGPR/LDS, nothing co-resides); VPD_TWO_STREAMS=1
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
     bool timing = false;
@@ -399,6 +404,22 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                 S.dz3_off = bp.take(m3 * 2);
             }
             for (int i = 0; i < 2; ++i) p->T_off[i] = bp.take(maxact * 2);
+        }
+        // grouped weight gradients (BasicBlock students): every eligible 3x3 stride-1 conv keeps its own dz until the
+        // stage's grouped launch; the stage's slab holds every problem's splits at once
+        p->wg_group = !bottleneck && !(getenv("VPD_WG_GROUP") && !atoi(getenv("VPD_WG_GROUP")));
+        if (p->wg_group) {
+            size_t stage_slab[4] = {0, 0, 0, 0};
+            for (auto& B : p->blocks)
+                for (ConvInfo* cv : {&B.c1, &B.c2}) {
+                    if (cv->slab_off < 0) continue;
+                    cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
+                    cv->gslab_off = (long long)stage_slab[B.stage];
+                    stage_slab[B.stage] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
+                }
+            size_t mx = 16;
+            for (int s2 = 0; s2 < 4; ++s2) mx = stage_slab[s2] > mx ? stage_slab[s2] : mx;
+            p->gslab_off = bp.take(mx * 4);
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? 2 * p->slab_elems : 1) * 4);      // two slabs, used alternately
@@ -951,8 +972,49 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         side_used = true;
         return r;
     };
+    // grouped mode: eligible convs are queued and launched together when the stage's backward is done
+    const bool grouped = p->wg_group && !fork && !sred;
+    struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
+    std::vector<Pending> pending;
+    auto flush_group = [&]() -> hipError_t {
+        if (pending.empty()) return hipSuccess;
+        WgradParams qs[12];
+        double flops = 0.0;
+        size_t done = 0;
+        hipError_t r = hipSuccess;
+        while (done < pending.size() && r == hipSuccess) {
+            const int cnt = (int)std::min<size_t>(12, pending.size() - done);
+            flops = 0.0;
+            for (int i = 0; i < cnt; ++i) {
+                const Pending& pd = pending[done + i];
+                const ConvInfo& cv = *pd.cv;
+                WgradParams q;
+                memset(&q, 0, sizeof q);
+                q.dz = pd.dz; q.dzHp = cv.Hout + 2; q.dzWp = cv.Wout + 2; q.dzC = cv.Co; q.dzpad = 1;
+                q.x = pd.x; q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci;
+                q.dw = c.f32(p->wg_off) + cv.wg_off;
+                q.slab = c.f32(p->gslab_off) + cv.gslab_off;
+                q.N = n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
+                q.M = n * cv.Hout * cv.Wout;
+                q.taps = conv_taps_fwd(cv);
+                qs[i] = q;
+                flops += conv_flops(cv, n);
+            }
+            {
+                TimeScope ts(p, s, 5, flops);
+                r = vpd_launch_wgrad_group(qs, cnt, s);
+            }
+            done += cnt;
+        }
+        pending.clear();
+        return r;
+    };
     // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
     auto fork_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
+        if (grouped && cv.dz_own_off && dz == c.b16(cv.dz_own_off)) {
+            pending.push_back({&cv, dz, x});
+            return hipSuccess;
+        }
         if (sred && !cv.stem) {
             slab_turn ^= 1;
             if (slab_free[slab_turn]) {      // the sum that last read this slab
@@ -999,8 +1061,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         bf16_t* dout = G[gi];
         bf16_t* da1 = G[(gi + 1) % 3];
         bf16_t* dnew = G[(gi + 2) % 3];
-        bf16_t* dz2 = c.b16(S.dz2_off[par]);
-        bf16_t* dz1 = c.b16(S.dz1_off[par]);
+        bf16_t* dz2 = c.b16(grouped && B.c2.dz_own_off ? B.c2.dz_own_off : S.dz2_off[par]);
+        bf16_t* dz1 = c.b16(grouped && B.c1.dz_own_off ? B.c1.dz_own_off : S.dz1_off[par]);
         if (p->bottleneck) {
             bf16_t* dz3 = c.b16(S.dz3_off);
             bf16_t* da2 = c.b16(p->T_off[0]);
@@ -1054,6 +1116,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(hipEventRecord(e, p->side));
             dz_free[B.stage][par] = e;
         }
+        if (bi == 0 || p->blocks[bi - 1].stage != B.stage) LCHECK(flush_group());      // the stage's weight gradients
         if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
             if (unpack_bucket(3 - B.stage)) return -1;
         }
