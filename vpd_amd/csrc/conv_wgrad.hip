@@ -674,20 +674,64 @@ hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
 }
 
 // ---- grouped launch (see WgGroup) ----
-// chunks per block: 4x the per-layer kernel's 16, i.e. 64 pixel chunks of 64 pixels (VPD_WG_GROUP_CPB overrides)
-static int wg_group_cpb() {
-    static const int v = getenv("VPD_WG_GROUP_CPB") ? atoi(getenv("VPD_WG_GROUP_CPB")) : 64;
-    return v < 1 ? 1 : v;
+// Split policy.  A problem's K (its 64-pixel chunks) is cut into `ksplit` tasks per output tile; every task beyond the
+// first costs a 9*64*64 fp32 partial written to the slab and read back.  Tasks run in rounds of one per CU, so the cost
+// of a choice is  rounds * (chunks_per_task * t_chunk + t_fixed) + slab bytes * 2 / bandwidth (+ the reduce launch),
+// with the measured t_chunk 0.62 us (1152 MFMA cycles per SIMD), t_fixed 5 us, 4.5 TB/s.  Candidates: task sizes that
+// fill r = 1..6 whole rounds of the 256 CUs, and fixed sizes; VPD_WG_GROUP_CPB pins the size instead.
+static int wg_group_cpb_env() {
+    static const int v = getenv("VPD_WG_GROUP_CPB") ? atoi(getenv("VPD_WG_GROUP_CPB")) : 0;
+    return v;
 }
-int vpd_wgrad_group_ksplit(int M) {
-    const int nchunks = (M + WG_CH - 1) / WG_CH;
-    const int cpb = wg_group_cpb();
-    return (nchunks + cpb - 1) / cpb;
+// splits a problem may use at most: its slab share is capped at 16 MB (plan-time allocation)
+int vpd_wgrad_group_max_splits(int Co, int Kc) {
+    const size_t per = (size_t)9 * Co * Kc * 4;
+    size_t cap = ((size_t)16 << 20) / per;
+    if (cap > 64) cap = 64;
+    return cap < 2 ? 1 : (int)cap;
 }
-// slab floats a problem needs in a grouped launch (0: its blocks write dw directly)
 size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc) {
-    const int ks = vpd_wgrad_group_ksplit(M);
-    return ks <= 1 ? 0 : (size_t)ks * 9 * Co * Kc;
+    (void)M;
+    const int cap = vpd_wgrad_group_max_splits(Co, Kc);
+    return cap <= 1 ? 0 : (size_t)cap * 9 * Co * Kc;
+}
+static void wg_group_choose(const WgradParams* ps, int n, int* ksplit) {
+    int nch[WG_GROUP_MAX], tiles[WG_GROUP_MAX], cap[WG_GROUP_MAX];
+    double work = 0.0;
+    for (int i = 0; i < n; ++i) {
+        nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
+        tiles[i] = (ps[i].Co / 64) * (ps[i].Kc / 64);
+        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc);
+        if (cap[i] > nch[i]) cap[i] = nch[i];
+        work += (double)nch[i] * tiles[i];
+    }
+    const double t_chunk = 0.62, t_fixed = 5.0, bw = 4.5e6;      // us, us, bytes per us
+    double best = 1e30;
+    auto eval = [&](double target) {
+        int ks[WG_GROUP_MAX];
+        long tasks = 0;
+        int max_cpb = 0;
+        double slab = 0.0;
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            int k = (int)(nch[i] / target + 0.5);
+            k = k < 1 ? 1 : (k > cap[i] ? cap[i] : k);
+            const int cpb = (nch[i] + k - 1) / k;
+            k = (nch[i] + cpb - 1) / cpb;
+            ks[i] = k;
+            tasks += (long)tiles[i] * k;
+            max_cpb = cpb > max_cpb ? cpb : max_cpb;
+            if (k > 1) { slab += (double)k * 9 * ps[i].Co * ps[i].Kc * 4; any = true; }
+        }
+        const double cost = (double)((tasks + 255) / 256) * (max_cpb * t_chunk + t_fixed) + 2.0 * slab / bw + (any ? 3.0 : 0.0);
+        if (cost < best) {
+            best = cost;
+            for (int i = 0; i < n; ++i) ksplit[i] = ks[i];
+        }
+    };
+    if (wg_group_cpb_env() > 0) { eval((double)wg_group_cpb_env()); return; }
+    for (int r = 1; r <= 6; ++r) eval(work / (256.0 * r));
+    for (int cpb = 16; cpb <= 512; cpb *= 2) eval((double)cpb);
 }
 bool vpd_wgrad_group_eligible(const WgradParams& p) {
     WgHaloGeom g;
@@ -702,6 +746,8 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
     WgGroup grp = {};
     WgReduceGroup red = {};
     grp.nprob = n;
+    int ks[WG_GROUP_MAX];
+    wg_group_choose(ps, n, ks);
     int tasks = 0, npass = 0, max_ks = 1;
     long max_n4 = 0;
     for (int i = 0; i < n; ++i) {
@@ -713,8 +759,8 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
         if (npass == 0) npass = np;
         if (np != npass) return hipErrorInvalidValue;             // one stage: one geometry
         const int nchunks = (p.M + WG_CH - 1) / WG_CH;
-        g.cpb = wg_group_cpb();
-        g.ksplit = (nchunks + g.cpb - 1) / g.cpb;
+        g.ksplit = ks[i];
+        g.cpb = (nchunks + g.ksplit - 1) / g.ksplit;
         if (g.ksplit <= 1) p.slab = p.dw;                         // split 0 of a 1-split problem IS the gradient
         else {
             red.slab[red.nprob] = reinterpret_cast<const float4*>(p.slab);
