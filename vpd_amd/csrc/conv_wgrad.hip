@@ -393,14 +393,21 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
 #define WG_GROUP_MAX 12
 struct WgGroup {
     int nprob;
-    int task_begin[WG_GROUP_MAX + 1];          // first grid block of each problem
+    int xcd_remap;                             // 1: blocks of one XCD take CONSECUTIVE tasks (see the kernel)
+    int task_begin[WG_GROUP_MAX + 1];          // first task of each problem
     int tiles[WG_GROUP_MAX];
     WgradParams p[WG_GROUP_MAX];
     WgHaloGeom g[WG_GROUP_MAX];
 };
 template <int NPASS>
 __global__ __launch_bounds__(768) void conv_wgrad_halo_grouped_kernel(const WgGroup grp) {
-    const int t = blockIdx.x;
+    // Tasks are ordered tile-fastest, so consecutive tasks are the output tiles of ONE pixel range: they read the same
+    // dz / x chunks (different channel slices).  Workgroups go to the 8 XCDs round-robin (block b -> XCD b % 8, each
+    // with its own L2), so block b takes task (b % 8) * (grid / 8) + b / 8: the tiles that share pixels then run on
+    // one XCD at the same time and their operands come from its L2 instead of 4-8 separate trips to HBM.
+    int t = blockIdx.x;
+    if (grp.xcd_remap) t = (t & 7) * (gridDim.x >> 3) + (t >> 3);
+    if (t >= grp.task_begin[grp.nprob]) return;                   // grid padded to a multiple of 8
     int pi = 0;
     for (int i = 1; i < grp.nprob; ++i)
         if (t >= grp.task_begin[i]) pi = i;
@@ -778,10 +785,13 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
         grp.g[i] = g;
     }
     grp.task_begin[n] = tasks;
+    static const int remap = !(getenv("VPD_WG_XCD") && !atoi(getenv("VPD_WG_XCD")));
+    grp.xcd_remap = remap;
+    const int grid = remap ? ((tasks + 7) / 8) * 8 : tasks;
     const size_t lds = (size_t)WG_NS * (WG_CH + 32 * (npass <= 3 ? 3 : npass)) * 64 * sizeof(bf16_t);
-    if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<3>, dim3(tasks), dim3(768), lds, stream, grp);
-    else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<4>, dim3(tasks), dim3(768), lds, stream, grp);
-    else VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<5>, dim3(tasks), dim3(768), lds, stream, grp);
+    if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<3>, dim3(grid), dim3(768), lds, stream, grp);
+    else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<4>, dim3(grid), dim3(768), lds, stream, grp);
+    else VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<5>, dim3(grid), dim3(768), lds, stream, grp);
     if (red.nprob > 0 && !(ablate & 16)) {
         const int groups = max_ks < 16 ? max_ks : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),
