@@ -684,8 +684,8 @@ hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
 // Split policy.  A problem's K (its 64-pixel chunks) is cut into `ksplit` tasks per output tile; every task beyond the
 // first costs a 9*64*64 fp32 partial written to the slab and read back.  Tasks run in rounds of one per CU, so the cost
 // of a choice is  rounds * (chunks_per_task * t_chunk + t_fixed) + slab bytes * 2 / bandwidth (+ the reduce launch),
-// with the measured t_chunk 0.62 us (1152 MFMA cycles per SIMD), t_fixed 5 us, 4.5 TB/s.  Candidates: task sizes that
-// fill r = 1..6 whole rounds of the 256 CUs, and fixed sizes; VPD_WG_GROUP_CPB pins the size instead.
+// with the measured t_chunk 1.0 us (grouped launches: 124-242 us for 252 x 114 ... 176 x 256 chunk tasks), t_fixed 4 us,
+// 4.5 TB/s.  Every task size from 8 to 512 chunks is tried; VPD_WG_GROUP_CPB pins the size instead.
 static int wg_group_cpb_env() {
     static const int v = getenv("VPD_WG_GROUP_CPB") ? atoi(getenv("VPD_WG_GROUP_CPB")) : 0;
     return v;
@@ -712,7 +712,7 @@ static void wg_group_choose(const WgradParams* ps, int n, int* ksplit) {
         if (cap[i] > nch[i]) cap[i] = nch[i];
         work += (double)nch[i] * tiles[i];
     }
-    const double t_chunk = 0.62, t_fixed = 5.0, bw = 4.5e6;      // us, us, bytes per us
+    const double t_chunk = 1.0, t_fixed = 4.0, bw = 4.5e6;       // us, us, bytes per us
     double best = 1e30;
     auto eval = [&](double target) {
         int ks[WG_GROUP_MAX];
@@ -737,8 +737,8 @@ static void wg_group_choose(const WgradParams* ps, int n, int* ksplit) {
         }
     };
     if (wg_group_cpb_env() > 0) { eval((double)wg_group_cpb_env()); return; }
-    for (int r = 1; r <= 6; ++r) eval(work / (256.0 * r));
-    for (int cpb = 16; cpb <= 512; cpb *= 2) eval((double)cpb);
+    (void)work;
+    for (int cpb = 8; cpb <= 512; cpb += (cpb < 128 ? 1 : 4)) eval((double)cpb);
 }
 bool vpd_wgrad_group_eligible(const WgradParams& p) {
     WgHaloGeom g;
