@@ -205,7 +205,7 @@ def main():
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-            rows = [v for k, v in pmc["kernels"].items() if dom.split("<")[0] in k]
+            rows = [v for k, v in pmc["kernels"].items() if dom.split("<")[0].split(" ")[0] in k]
             n = sum(r["launches"] for r in rows)
             traffic = sum(r["launches"] * (2 * r["fetch_KB_per_launch"] + r["write_KB_per_launch"]) for r in rows) / n * 1024
             traffic_note = pmc["note"]
@@ -219,8 +219,8 @@ def main():
                     "kernels": kernels,
                     "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region: the "
                             "start/stop events ride in each kernel's own dispatch packet (hipExtLaunchKernelGGL), so the "
-                            "figure is the kernel's duration as rocprofv3 --kernel-trace reports it; a weight-gradient "
-                            "launch is timed without its slab reduce" % args.profile_steps}
+                            "figure is the kernel's duration as rocprofv3 --kernel-trace reports it; a grouped weight-gradient "
+                            "launch (all 3x3 stride-1 convs of one ResNet stage) is timed without its slab reduce" % args.profile_steps}
         out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
