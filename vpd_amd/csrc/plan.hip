@@ -405,9 +405,9 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             }
             for (int i = 0; i < 2; ++i) p->T_off[i] = bp.take(maxact * 2);
         }
-        // grouped weight gradients (BasicBlock students): every eligible 3x3 stride-1 conv keeps its own dz until the
+        // grouped weight gradients: every eligible 3x3 stride-1 conv keeps its own dz until the
         // stage's grouped launch; the stage's slab holds every problem's splits at once
-        p->wg_group = !bottleneck && !(getenv("VPD_WG_GROUP") && !atoi(getenv("VPD_WG_GROUP")));
+        p->wg_group = !(getenv("VPD_WG_GROUP") && !atoi(getenv("VPD_WG_GROUP")));
         if (p->wg_group) {
             size_t stage_slab[4] = {0, 0, 0, 0};
             for (auto& B : p->blocks)
@@ -1086,6 +1086,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             } else {
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
             }
+            if (bi == 0 || p->blocks[bi - 1].stage != B.stage) LCHECK(flush_group());      // the stage's weight gradients
             if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
                 if (unpack_bucket(3 - B.stage)) return -1;
             }
