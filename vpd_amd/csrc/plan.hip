@@ -902,7 +902,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         };
         for (auto& B : p->blocks) { dry(B.c1, 1); dry(B.c2, 1); if (p->bottleneck) dry(B.c3, 1); if (B.ds) dry(B.cd, 1); }
         dry(p->stem, 0);
-        if (zr.count >= ZR_MAX) { zr.count = 1; prezeroed = false; }      // too many ranges (deep Bottleneck nets): memset per conv
+        if (zr.count >= ZR_MAX) {      // too many ranges (Bottleneck nets: 30-100 1x1 convs): zero the whole scratch in one range
+            zr.ptr[1] = c.f32(p->wg_off); zr.n4[1] = (long)(p->wg_elems + 3) / 4; zr.count = 2;
+        }
     }
     LCHECK(vpd_launch_zero_ranges(zr, s));
 
