@@ -84,18 +84,6 @@ struct TapSet {
     int w0, wrs, wcs;
 };
 
-// Optional fused BatchNorm finalize: the LAST block of the producing kernel (ticket counter) turns the
-// statistics accumulator rows into mean / rstd / scale / shift and updates the running statistics,
-// instead of a separate dependent launch.  counter == null disables it.
-struct BnFin {
-    unsigned* counter;                          // zero between launches (the last block resets it)
-    const float* gamma; const float* beta;
-    float* running_mean; float* running_var;    // may be null
-    float* mean; float* rstd; float* scale; float* shift;
-    float count, momentum, eps;
-    int nblocks;
-};
-
 // Output sub-grid of one launch (or of one parity class of a merged stride-2 data-gradient launch).
 struct ConvGeo {
     int Hs, Ws, M, oph, opw;
@@ -125,7 +113,6 @@ struct ConvParams {
     int accumulate;                             // y += result
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
-    BnFin fin;                                  // fused finalize of `stats` (forward, train mode)
     // gather kernel only: extra parity classes of a stride-2 data gradient, selected by blockIdx.z (class 0 is
     // described by the fields above); ncls == 0 or 1 means a single class
     int ncls;

@@ -137,70 +137,3 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
     }
 }
 
-static __device__ __forceinline__ float ld_agent(const float* p) {
-    // L1-bypassing load: the accumulator rows were written by other CUs' memory-side atomics
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Shared by every producer of BN statistics: mean/var from the VPD_STAT_ROWS accumulator rows of channel c
-// (which are re-zeroed), in double.
-static __device__ __forceinline__ void stat_rows_sum(float* rows, int C, int c, double* s1, double* s2) {
-    float v1[VPD_STAT_ROWS], v2[VPD_STAT_ROWS];
-#pragma unroll
-    for (int t = 0; t < VPD_STAT_ROWS; ++t) {
-        v1[t] = ld_agent(rows + ((size_t)t * 2) * C + c);
-        v2[t] = ld_agent(rows + ((size_t)t * 2 + 1) * C + c);
-    }
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int t = 0; t < VPD_STAT_ROWS; ++t) {
-        a += (double)v1[t]; b += (double)v2[t];
-        rows[((size_t)t * 2) * C + c] = 0.f;
-        rows[((size_t)t * 2 + 1) * C + c] = 0.f;
-    }
-    *s1 = a; *s2 = b;
-}
-
-// Ticket: true in exactly one block per launch -- the one that arrives after every other block's
-// atomics have been acknowledged by memory.  Called by ALL threads of the block.
-static __device__ __forceinline__ bool last_block_arrives(unsigned* counter, int nblocks, unsigned char* smem) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's atomics have been performed
-    __syncthreads();
-    volatile int* flag = reinterpret_cast<volatile int*>(smem);
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned t = atomicAdd(counter, 1u);
-        *flag = (t == (unsigned)(nblocks - 1)) ? 1 : 0;
-    }
-    __syncthreads();
-    const bool last = *flag != 0;
-    if (last) __threadfence();                              // acquire: drop this CU's stale L1 lines
-    return last;
-}
-
-// Forward BN finalize by the last block (nn.BatchNorm2d train semantics; same math as bn_finalize_kernel).
-static __device__ __forceinline__ void conv_finalize_tail(const ConvParams& p, unsigned char* smem) {
-    const BnFin& f = p.fin;
-    if (!f.counter) return;
-    if (!last_block_arrives(f.counter, f.nblocks, smem)) return;
-    for (int c = threadIdx.x; c < p.Co; c += blockDim.x) {
-        double s1, s2;
-        stat_rows_sum(p.stats, p.Co, c, &s1, &s2);
-        const double mu = s1 / (double)f.count;
-        double var = s2 / (double)f.count - mu * mu;
-        var = var > 0.0 ? var : 0.0;
-        const float r = (float)(1.0 / sqrt(var + (double)f.eps));
-        f.mean[c] = (float)mu;
-        f.rstd[c] = r;
-        const float sc = f.gamma[c] * r;
-        f.scale[c] = sc;
-        f.shift[c] = f.beta[c] - (float)mu * sc;
-        if (f.running_mean) {
-            const double unb = f.count > 1.f ? var * (double)f.count / ((double)f.count - 1.0) : var;
-            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
-            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
-        }
-    }
-    if (threadIdx.x == 0) *f.counter = 0u;
-}

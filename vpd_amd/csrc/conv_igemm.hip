@@ -147,7 +147,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
-    conv_finalize_tail(p, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -302,7 +301,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     conv_epilogue<BM, BN, WM, WN>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
-    conv_finalize_tail(p, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -402,7 +400,6 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
         __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
         if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_epilogue
-        conv_finalize_tail(p, smem);                              // barriers inside: all 8 waves take part
         return;
     }
 
@@ -465,7 +462,6 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
-    conv_finalize_tail(p, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -535,7 +531,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
         if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
-        conv_finalize_tail(p, red);
         return;
     }
 
@@ -596,7 +591,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
-    conv_finalize_tail(p, red);
 }
 
 template <int HROWS>
@@ -605,7 +599,6 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
     const int grid = ntiles < 256 ? ntiles : 256;
     const size_t lds = ((size_t)9 * 64 + 2 * HROWS) * 64 * sizeof(bf16_t) + 2048;
     ConvParams q = p;
-    q.fin.nblocks = grid;
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
         case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
@@ -679,7 +672,6 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
         if (EPM == 1) __builtin_amdgcn_s_barrier();               // matches the barrier inside conv_stats_flush
-        conv_finalize_tail(p, red);
         return;
     }
 
@@ -734,7 +726,6 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (EPM == 1) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
-    conv_finalize_tail(p, red);
 }
 
 // stem shape test + launch; returns false when the generic gather kernel has to take it
@@ -755,7 +746,6 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048;
     const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
     ConvParams q = p;
-    q.fin.nblocks = grid;
     if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
     else VPD_LAUNCH((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
     return hipGetLastError();
@@ -766,7 +756,6 @@ static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t 
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
     const size_t lds = ((size_t)HB * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
-    q.fin.nblocks = (int)(grid.x * grid.y);
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0>), grid, dim3(512), lds, stream, q, g); break;
         case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1>), grid, dim3(512), lds, stream, q, g); break;
@@ -783,7 +772,6 @@ static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_
     const size_t red = (size_t)2 * 2 * BN * sizeof(float);
     if (lds < red) lds = red;
     ConvParams q = p;
-    q.fin.nblocks = (int)(grid.x * grid.y);
     VPD_LAUNCH((conv3x3_halo_kernel<BM, BN, HROWS, HALO2>), grid, dim3(256), lds, stream, q, g);
     return hipGetLastError();
 }
@@ -816,7 +804,6 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     dim3 grid((maxM + BM - 1) / BM, p.Co / BN, p.ncls > 1 ? p.ncls : 1);
     const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
-    q.fin.nblocks = (int)(grid.x * grid.y);
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
         case 1: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;

@@ -99,8 +99,7 @@ struct vpd_plan {
     // workspace offsets (bytes)
     size_t ws_bytes = 0;
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
-    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, T_off[2] = {0, 0}, slab_off = 0, ticket_off = 0;
-    bool fused_fin = true;
+    size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, T_off[2] = {0, 0}, slab_off = 0;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
@@ -115,13 +114,8 @@ struct vpd_plan {
     struct Graph { int n; hipGraph_t g; hipGraphExec_t e; };
     std::vector<Graph> graphs;
     void* bound_ws = nullptr;
-    // backward runs the weight-gradient kernels on a side stream (they are off the dgrad critical path)
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev_pool2;          // fork/join events, reused every step
-    size_t ev_next = 0;
     bool wg_group = true;       // per-stage grouped weight gradients (VPD_WG_GROUP=0: one launch per conv)
     size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest stage
-    bool two_streams = false;   // measured: no gain (conv kernels fill every CU's VGPR/LDS, nothing co-resides); VPD_TWO_STREAMS=1
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
     bool timing = false;
     struct TimedLaunch { int cls; double flops; hipEvent_t a, b; };
@@ -340,10 +334,6 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         (void)mx;   // producers accumulate atomically into VPD_STAT_ROWS rows of [2][C]
         p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * p->feat * 4;
         p->partial_off = bp.take(p->partial_bytes);
-        p->ticket_off = bp.take(256);
-        // measured: the per-block ticket round trip costs more than the 36 tiny finalize launches it saves
-        // (38.3k vs 44.7k crops/s), so the fused form is opt-in
-        p->fused_fin = getenv("VPD_FUSED_FIN") && atoi(getenv("VPD_FUSED_FIN"));
     }
     p->z0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
     p->p0_off = bp.take(padded_elems(NB, p->H1, p->W1, 64, 1) * 2);
@@ -422,7 +412,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             p->gslab_off = bp.take(mx * 4);
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
-        p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? 2 * p->slab_elems : 1) * 4);      // two slabs, used alternately
+        p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
@@ -442,8 +432,6 @@ extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
         (void)hipGraphExecDestroy(g.e);
         (void)hipGraphDestroy(g.g);
     }
-    for (auto e : p->ev_pool2) (void)hipEventDestroy(e);
-    if (p->side) (void)hipStreamDestroy(p->side);
     for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
@@ -540,8 +528,7 @@ inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real 
 
 // forward convolution launch; input padded activation `x` (border 1; stem: xin), output `y`
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
-                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
-                        float* bn_running = nullptr, bool fuse_finalize = false) {
+                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -555,22 +542,12 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
-    if (stats && fuse_finalize) {
-        q.fin.counter = reinterpret_cast<unsigned*>(c.ws + c.p->ticket_off);
-        q.fin.gamma = c.params + cv.bn.w_off; q.fin.beta = c.params + cv.bn.b_off;
-        q.fin.running_mean = bn_running ? bn_running + cv.bn.rm_off : nullptr;
-        q.fin.running_var = bn_running ? bn_running + cv.bn.rv_off : nullptr;
-        q.fin.mean = c.bn_mean(cv.bn); q.fin.rstd = c.bn_rstd(cv.bn);
-        q.fin.scale = c.bn_scale(cv.bn); q.fin.shift = c.bn_shift(cv.bn);
-        q.fin.count = (float)q.M; q.fin.momentum = kBnMomentum; q.fin.eps = kBnEps;
-    }
     const int kc = vpd_conv_kernel_class(q);
     TimeScope ts(c.p, c.s, kc == 5 ? 7 : kc, conv_flops(cv, c.n));      // slot 7: stem kernel (5, 6 are the wgrads)
     return vpd_launch_conv(q, c.s);
 }
 
 hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) {
-    if (c.p->fused_fin) return hipSuccess;      // done by the conv kernel's last block
     const int M = c.n * cv.Hout * cv.Wout;
     const int bm = vpd_conv_bm(M, cv.Co);
     (void)bm;
@@ -631,12 +608,8 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     return vpd_launch_conv(q, c.s);
 }
 
-// The halo kernel leaves split partials in a slab; `reduce` (may be null) is called instead of summing the slab on
-// `st`, so the caller can move that bandwidth-bound sum to a side stream, beside the next MFMA kernels.
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
-                          hipStream_t st, int slab_index = 0,
-                          const std::function<hipError_t(const WgradParams&)>* reduce = nullptr,
-                          ZeroRanges* collect_zero = nullptr, bool prezeroed = false) {
+                          hipStream_t st, ZeroRanges* collect_zero = nullptr, bool prezeroed = false) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -644,7 +617,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (cv.stem) { q.xHp = c.p->xHp; q.xWp = c.p->xWp; q.xC = 8; }
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.dw = c.f32(c.p->wg_off) + cv.wg_off;
-    float* slab = c.f32(c.p->slab_off) + (size_t)slab_index * c.p->slab_elems;
+    float* slab = c.f32(c.p->slab_off);
     q.slab = cv.slab_off >= 0 ? slab + cv.slab_off : (cv.stem ? slab : nullptr);
     q.defer_reduce = 0;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
@@ -670,7 +643,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
             e = vpd_launch_wgrad(q, st);
         }
         if (e != hipSuccess) return e;
-        return reduce ? (*reduce)(q) : vpd_launch_wgrad_reduce(q, st);
+        return vpd_launch_wgrad_reduce(q, st);
     }
     TimeScope ts(c.p, st, cv.stem ? 7 : (vpd_wgrad_overwrites(q) ? 5 : 6), conv_flops(cv, c.n));      // 7: stem kernels
     return vpd_launch_wgrad(q, st);
@@ -829,13 +802,12 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     {
         ZeroRanges z;
         memset(&z, 0, sizeof z);
-        z.ptr[0] = c.f32(p->partial_off); z.n4[0] = (long)(p->partial_bytes + 256) / 16; z.count = 1;      // accumulator rows + ticket
+        z.ptr[0] = c.f32(p->partial_off); z.n4[0] = (long)p->partial_bytes / 16; z.count = 1;      // accumulator rows
         LCHECK(vpd_launch_zero_ranges(z, s));
     }
     if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
     // stem: conv -> batch stats -> BN+ReLU+maxpool
-    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0,
-                        bn_running, p->fused_fin));
+    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, true, nullptr, nullptr, nullptr, 0));
     LCHECK(run_bn_finalize(c, p->stem, bn_running));
     {
         StemPoolParams sp;
@@ -850,18 +822,18 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     for (auto& B : p->blocks) {
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
-        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0));
         LCHECK(run_bn_finalize(c, B.c1, bn_running));
         LCHECK(run_bn_apply(c, B.c1, 0, nullptr, nullptr, a1, 1));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
-            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
             LCHECK(run_bn_finalize(c, B.c2, bn_running));
             LCHECK(run_bn_apply(c, B.c2, 0, nullptr, nullptr, a2, 1));
-            LCHECK(run_conv_fwd(c, B.c3, a2, c.b16(B.c3.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+            LCHECK(run_conv_fwd(c, B.c3, a2, c.b16(B.c3.z_off), 0, true, nullptr, nullptr, nullptr, 0));
             LCHECK(run_bn_finalize(c, B.c3, bn_running));
             if (B.ds) {
-                LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+                LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
                 LCHECK(run_bn_finalize(c, B.cd, bn_running));
                 LCHECK(run_bn_apply(c, B.c3, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
             } else {
@@ -870,10 +842,10 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             cur = outp;
             continue;
         }
-        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
         LCHECK(run_bn_finalize(c, B.c2, bn_running));
         if (B.ds) {
-            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0, bn_running, p->fused_fin));
+            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
             LCHECK(run_bn_finalize(c, B.cd, bn_running));
             LCHECK(run_bn_apply(c, B.c2, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
         } else {
@@ -898,7 +870,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     bool prezeroed = true;
     {
         auto dry = [&](const ConvInfo& cv, int dzpad) {
-            (void)run_conv_wgrad(c, cv, nullptr, dzpad, nullptr, s, 0, nullptr, &zr);
+            (void)run_conv_wgrad(c, cv, nullptr, dzpad, nullptr, s, &zr);
         };
         for (auto& B : p->blocks) { dry(B.c1, 1); dry(B.c2, 1); if (p->bottleneck) dry(B.c3, 1); if (B.ds) dry(B.cd, 1); }
         dry(p->stem, 0);
@@ -936,46 +908,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         const StageInfo& S = p->stages[3];
         LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
     }
-    // ---- side stream for the weight gradients ----
-    static const bool want_side = getenv("VPD_TWO_STREAMS") && atoi(getenv("VPD_TWO_STREAMS"));
-    const bool fork = (p->two_streams || want_side) && !p->bottleneck;     // Bottleneck plans share dz buffers per stage
-    if (fork && !p->side) LCHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    hipStream_t ws_stream = fork ? p->side : s;
-    p->ev_next = 0;
-    auto next_event = [&]() -> hipEvent_t {
-        if (p->ev_next == p->ev_pool2.size()) {
-            hipEvent_t e = nullptr;
-            (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            p->ev_pool2.push_back(e);
-        }
-        return p->ev_pool2[p->ev_next++];
-    };
-    // VPD_SIDE_REDUCE=1 (experiment, measured 6 % SLOWER: 49.4k vs 52.5k crops/s on the same box): the 38 MB slab
-    // of each weight-gradient kernel is summed on `side` while the main stream goes on with the data gradient; two
-    // slabs alternate, so the next weight-gradient kernel only waits for the sum before last.  Like the two-stream
-    // backward, cross-stream hand-offs cost more than the overlap returns on this part.
-    static const bool side_reduce = getenv("VPD_SIDE_REDUCE") && atoi(getenv("VPD_SIDE_REDUCE"));
-    const bool sred = side_reduce && !fork;
-    if (sred && !p->side) LCHECK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    int slab_turn = 0;
-    hipEvent_t slab_free[2] = {nullptr, nullptr};
-    bool side_used = false;
-    const std::function<hipError_t(const WgradParams&)> reduce_on_side = [&](const WgradParams& q) -> hipError_t {
-        hipEvent_t e = next_event();
-        hipError_t r = hipEventRecord(e, s);
-        if (r != hipSuccess) return r;
-        r = hipStreamWaitEvent(p->side, e, 0);
-        if (r != hipSuccess) return r;
-        r = vpd_launch_wgrad_reduce(q, p->side);
-        if (r != hipSuccess) return r;
-        hipEvent_t f = next_event();
-        r = hipEventRecord(f, p->side);
-        slab_free[slab_turn] = f;
-        side_used = true;
-        return r;
-    };
     // grouped mode: eligible convs are queued and launched together when the stage's backward is done
-    const bool grouped = p->wg_group && !fork && !sred;
+    // (running weight gradients or their slab sums on a second stream was measured 6 % slower: DESIGN.md)
+    const bool grouped = p->wg_group;
     struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
     std::vector<Pending> pending;
     auto flush_group = [&]() -> hipError_t {
@@ -1012,40 +947,14 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         return r;
     };
     // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
-    auto fork_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
+    auto queue_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
         if (grouped && cv.dz_own_off && dz == c.b16(cv.dz_own_off)) {
             pending.push_back({&cv, dz, x});
             return hipSuccess;
         }
-        if (sred && !cv.stem) {
-            slab_turn ^= 1;
-            if (slab_free[slab_turn]) {      // the sum that last read this slab
-                hipError_t r = hipStreamWaitEvent(s, slab_free[slab_turn], 0);
-                if (r != hipSuccess) return r;
-                slab_free[slab_turn] = nullptr;
-            }
-            return run_conv_wgrad(c, cv, dz, dzpad, x, s, slab_turn, &reduce_on_side, nullptr, prezeroed);
-        }
-        if (fork) {
-            hipEvent_t e = next_event();
-            hipError_t r = hipEventRecord(e, s);
-            if (r != hipSuccess) return r;
-            r = hipStreamWaitEvent(p->side, e, 0);
-            if (r != hipSuccess) return r;
-        }
-        return run_conv_wgrad(c, cv, dz, dzpad, x, ws_stream, 0, nullptr, nullptr, prezeroed);
-    };
-    // main stream must not overwrite a dz buffer the side stream may still be reading
-    hipEvent_t dz_free[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-    auto join_side = [&]() -> hipError_t {      // main waits for everything enqueued on the side stream so far
-        if (!fork && !(sred && side_used)) return hipSuccess;
-        hipEvent_t e = next_event();
-        hipError_t r = hipEventRecord(e, p->side);
-        if (r != hipSuccess) return r;
-        return hipStreamWaitEvent(s, e, 0);
+        return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed);
     };
     auto unpack_bucket = [&](int b) -> int {
-        LCHECK(join_side());
         const int nb = (int)p->bmap_unpack[b].size() / 2;
         if (nb > 0)
             LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
@@ -1071,17 +980,17 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             bf16_t* da1b = c.b16(p->T_off[1]);
             // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout
             LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads));
-            LCHECK(fork_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
+            LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
             LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
             LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
-            LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
+            LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
             LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
             LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
-            LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
+            LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
                 bf16_t* dzd = c.b16(S.dzd_off);
                 LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
-                LCHECK(fork_wgrad(B.cd, dzd, 1, xin));
+                LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // 1x1 stride 1: writes every input pixel
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
                 gi = (gi + 2) % 3;
@@ -1094,30 +1003,23 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             }
             continue;
         }
-        // the side stream's readers of this parity's dz buffers (block bi+2 of the same stage) must be done
-        if (fork && dz_free[B.stage][par]) LCHECK(hipStreamWaitEvent(s, dz_free[B.stage][par], 0));
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
         LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
-        LCHECK(fork_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
+        LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         // (a variant that fused bn1's backward reduction into this dgrad's epilogue was measured 6 % SLOWER end to
         //  end -- the extra epilogue code bloats every conv kernel -- and was removed)
         LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
         LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
-        LCHECK(fork_wgrad(B.c1, dz1, 1, xin));
+        LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
             LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
-            LCHECK(fork_wgrad(B.cd, dzd, 1, xin));
+            LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
             LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
             gi = (gi + 2) % 3;
         } else {
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
-        }
-        if (fork) {      // everything the side stream has been given so far covers this block's dz readers
-            hipEvent_t e = next_event();
-            LCHECK(hipEventRecord(e, p->side));
-            dz_free[B.stage][par] = e;
         }
         if (bi == 0 || p->blocks[bi - 1].stage != B.stage) LCHECK(flush_group());      // the stage's weight gradients
         if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
@@ -1135,8 +1037,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
         LCHECK(vpd_launch_stem_pool_bwd(sb, (float)sb.M, params + p->stem.bn.w_off, grads + p->stem.bn.w_off,
                                         grads + p->stem.bn.b_off, c.bn_coef(p->stem.bn), c.b16(p->dz0_off), s));
-        LCHECK(join_side());      // the stem's kernel sums its own slab (slab 0) on the main stream
-        LCHECK(fork_wgrad(p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
+        LCHECK(queue_wgrad(p->stem, c.b16(p->dz0_off), 0, c.b16(p->xin_off)));
     }
     return unpack_bucket(3);
 }
