@@ -101,8 +101,8 @@ def test_device_noise_statistics_and_determinism():
 
 
 def test_staged_input_equals_fp32_batch_path():
-    """vpd_plan_stage_crops + forward(x = NULL) == vpd_augment_crops -> fp32 batch -> forward(x): same embeddings
-    bit for bit (both round the same fp32 values to bf16 once)."""
+    """vpd_plan_stage_crops + forward(x = NULL) == vpd_augment_crops -> fp32 batch -> forward(x): same embeddings,
+    bit for bit in eval mode (both round the same fp32 values to bf16 once)."""
     from vpd_amd import augment as A
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
     n, h = 6, 128
@@ -125,7 +125,8 @@ def test_staged_input_equals_fp32_batch_path():
     l1 = float(eng.loss_step.item())
     staged = aug.stage(eng, dv[0], dv[1], dv[2], params, train=True, noise=nz)
     t2 = eng.forward_train(None, tgt, accumulate_loss=False, staged=staged).clone()
-    assert torch.equal(t1, t2) and l1 == float(eng.loss_step.item())
+    # train mode: the batch statistics are accumulated with fp32 atomics, whose order varies from launch to launch
+    assert torch.allclose(t1, t2, rtol=1e-3, atol=1e-4) and abs(l1 - float(eng.loss_step.item())) <= 1e-3 * l1
 
 
 def test_trainer_epoch_on_raw_u8_batches():
