@@ -331,9 +331,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
 }
 
 int vpd_bn_bwd_blocks(int M, int C, int* ppb_out) {
+    // pixels per block: enough blocks to hide the load latency (the small layers were latency-bound at one block per
+    // CU with the earlier 8 iterations / 1024 blocks: +1.5 % end to end), at least four pixel iterations per thread so
+    // that the per-block LDS reduce + 2C atomics stay amortised
+    static const int min_iter = getenv("VPD_BN_MINITER") ? atoi(getenv("VPD_BN_MINITER")) : 4;
+    static const int max_blocks = getenv("VPD_BN_MAXBLK") ? atoi(getenv("VPD_BN_MAXBLK")) : 2048;
     const int ppi = 256 / (C / 8);
-    int ppb = (M + 1023) / 1024;                  // at most ~1024 blocks
-    if (ppb < ppi * 8) ppb = ppi * 8;
+    int ppb = (M + max_blocks - 1) / max_blocks;
+    if (ppb < ppi * min_iter) ppb = ppi * min_iter;
     ppb = ((ppb + ppi - 1) / ppi) * ppi;
     if (ppb_out) *ppb_out = ppb;
     return (M + ppb - 1) / ppb;
