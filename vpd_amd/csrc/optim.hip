@@ -3,9 +3,35 @@
 #include "common.h"
 #include "kernels.h"
 
-// f32 [N][C][H][W] -> bf16 [N][Hp][Wp][Cp] interior (zero border is pre-set and never written)
+// f32 [N][C][H][W] -> bf16 [N][Hp][Wp][Cp] interior (zero border is pre-set and never written).
+// A thread converts 4 consecutive pixels of a row: one float4 per channel plane in, four 16-byte pixels out.
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* x, int N, int C, int H, int W, bf16_t* out,
                                                          int Hp, int Wp, int pad, int Cp) {
+    const int W4 = W >> 2;
+    const long total = (long)N * H * W4;
+    const long plane = (long)H * W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(it / ((long)H * W4));
+        const long r4 = it - (long)b * H * W4;
+        const int y = (int)(r4 / W4);
+        const int x0 = (int)(r4 - (long)y * W4) << 2;
+        float v[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[q][c] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float4 f = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * plane + (size_t)y * W + x0);
+            v[0][c] = f.x; v[1][c] = f.y; v[2][c] = f.z; v[3][c] = f.w;
+        }
+        bf16_t* dst = out + ((size_t)(b * Hp + y + pad) * Wp + x0 + pad) * Cp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(dst + q * Cp) = pack8(v[q]);
+    }
+}
+// widths that are not a multiple of 4: one pixel per thread
+__global__ __launch_bounds__(256) void pack_input_px_kernel(const float* x, int N, int C, int H, int W, bf16_t* out,
+                                                            int Hp, int Wp, int pad, int Cp) {
     const long total = (long)N * H * W;
     const long plane = (long)H * W;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -21,9 +47,14 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* x, int N, 
 hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
                                  int Cp, hipStream_t s) {
     if (Cp != 8 || C > 8) return hipErrorInvalidValue;
-    long items = (long)N * H * W;
+    const bool quad = (W & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+    long items = quad ? (long)N * H * (W / 4) : (long)N * H * W;
     long g = (items + 255) / 256;
     if (g > 8192) g = 8192;
+    if (!quad) {
+        hipLaunchKernelGGL(pack_input_px_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pack_input_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
     return hipGetLastError();
 }
