@@ -450,6 +450,62 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
     }
 }
 
+// BatchNorm-backward sums of the stem from the pooled side.  The gradient of a pooling window goes to its arg-max pixel
+// only, and survives the ReLU iff the pooled value is positive; there a = gamma * xhat + beta, so
+//   sum g = sum_windows d [a > 0],   sum g * xhat = sum_windows d [a > 0] (a - beta) / gamma
+// needs dpool and the pooled activation only (67 MB) instead of a pass over z with its 2.25 windows per pixel
+// (260 MB, 90 us).  a is the stored bf16 activation: xhat differs from the z-based value by its rounding (2^-9
+// relative, zero mean), far below the bf16 noise of the gradients themselves.
+__global__ __launch_bounds__(256) void stem_pool_bwd_sums_kernel(const StemPoolBwdParams p) {
+    __shared__ float sh[256][17];
+    const int cv = p.C >> 3;
+    const int ppi = 256 / cv;
+    const int c8 = threadIdx.x % cv;
+    const int pl = threadIdx.x / cv;
+    const int c = c8 << 3;
+    const int HWo = p.Ho * p.Wo;
+    const int Mo = p.M / (p.Hz * p.Wz) * HWo;                      // pooled pixels of the batch
+    float ig[8], be[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float gm = p.gamma_p[c + j];
+        ig[j] = fabsf(gm) > 1e-20f ? 1.f / gm : 0.f;
+        be[j] = p.beta_p[c + j];
+        a1[j] = 0.f; a2[j] = 0.f;
+    }
+    const int pHp = p.Ho + 2 * p.ppad, pWp = p.Wo + 2 * p.ppad;
+    const int mbeg = blockIdx.x * p.ppb;
+    int mend = mbeg + p.ppb;
+    mend = mend < Mo ? mend : Mo;
+    if (pl < ppi)
+        for (int m = mbeg + pl; m < mend; m += ppi) {
+            const int b = m / HWo;
+            const int r = m - b * HWo;
+            const int oy = r / p.Wo;
+            const int ox = r - oy * p.Wo;
+            float d[8], a[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.dpool + (size_t)m * p.C + c), d);
+            unpack8(*reinterpret_cast<const uint4*>(p.pooled + ((size_t)(b * pHp + oy + p.ppad) * pWp + ox + p.ppad) * p.C + c), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float g = a[j] > 0.f ? d[j] : 0.f;
+                a1[j] += g;
+                a2[j] += g * ((a[j] - be[j]) * ig[j]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sh[threadIdx.x][j] = a1[j]; sh[threadIdx.x][8 + j] = a2[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * p.C; t += 256) {
+        const int which = t / p.C;
+        const int ch = t - which * p.C;
+        const int q8 = ch >> 3, j = ch & 7;
+        float tot = 0.f;
+        for (int gI = 0; gI < ppi; ++gI) tot += sh[gI * cv + q8][which * 8 + j];
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
+    }
+}
+
 hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, const float* gamma, float* dgamma,
                                     float* dbeta, float* coef, bf16_t* dz, hipStream_t s) {
     // Two passes over (d_pool, argmax, z): pass 1 = the BN-backward sums of g (max-pool routing + ReLU mask, never
@@ -458,7 +514,15 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
     if (p.C % 8 || 256 % (p.C / 8)) return hipErrorInvalidValue;
     const int T = vpd_bn_bwd_blocks(p.M, p.C, &p.ppb);
     p.pass = 1; p.coef = coef; p.dz = dz;
-    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
+    static const bool pooled_sums = !(getenv("VPD_STEM_POOLSUMS") && !atoi(getenv("VPD_STEM_POOLSUMS")));
+    if (pooled_sums && p.pooled) {
+        StemPoolBwdParams q = p;
+        const int Mo = p.M / (p.Hz * p.Wz) * p.Ho * p.Wo;
+        const int To = vpd_bn_bwd_blocks(Mo, p.C, &q.ppb);
+        hipLaunchKernelGGL(stem_pool_bwd_sums_kernel, dim3(To), dim3(256), 0, s, q);
+    } else {
+        hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, s, p.partials,
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, coef);

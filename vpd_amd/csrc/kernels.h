@@ -42,6 +42,9 @@ struct StemPoolBwdParams {
     float* partials;
     int M, Hz, Wz, Ho, Wo, C, ppb;
     int pass; const float* coef; bf16_t* dz;    // filled by the launcher
+    // pooled post-ReLU activation (padded NHWC, border ppad) and the BN affine parameters: the backward sums are taken
+    // over the POOLED positions (4x fewer than z pixels), where xhat of the arg-max pixel is (a - beta) / gamma
+    const bf16_t* pooled; int ppad; const float* gamma_p; const float* beta_p;
 };
 
 struct PackDesc {                       // one convolution's weight tensors

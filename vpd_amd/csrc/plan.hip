@@ -1034,6 +1034,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         sb.mean = c.bn_mean(p->stem.bn); sb.rstd = c.bn_rstd(p->stem.bn);
         sb.scale = c.bn_scale(p->stem.bn); sb.shift = c.bn_shift(p->stem.bn);
         sb.g = c.b16(p->g0_off); sb.partials = c.f32(p->partial_off);
+        sb.pooled = c.b16(p->p0_off); sb.ppad = 1;
+        sb.gamma_p = params + p->stem.bn.w_off; sb.beta_p = params + p->stem.bn.b_off;
         sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
         LCHECK(vpd_launch_stem_pool_bwd(sb, (float)sb.M, params + p->stem.bn.w_off, grads + p->stem.bn.w_off,
                                         grads + p->stem.bn.b_off, c.bn_coef(p->stem.bn), c.b16(p->dz0_off), s));
