@@ -233,6 +233,68 @@ def test_backward_in_a_well_conditioned_regime(arch):
     assert all(c >= 0.93 and 0.9 <= b <= 1.1 for c, b in res.values()), res
 
 
+@pytest.mark.parametrize("motion", [False, True])
+def test_training_trajectory_tracks_fp32_oracle(motion):
+    """Twelve real AdamW steps (3 epochs x 4 batches of 16 crops, ResNet-18, the well-conditioned initialisation of the
+    test above) through ModelTrainer.epoch, against the fp32 oracle taking the same steps on the CPU: per-epoch train
+    loss within 1 %, the eval-mode loss afterwards (running statistics after 12 updates) within 1 %.  Adam's first
+    steps are sign-like (m/sqrt(v) = +-1), so rounding noise in near-zero gradient coordinates moves those weights by a
+    full +-lr: the trained weights and the held-out embeddings are therefore gated against what the oracle's own bf16
+    emulation (same algorithm, same rounding points, CPU) shows for the same 12 steps --
+    err_hip <= 1.5 * err_emulation + 1e-2 for both."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    D = 32
+    sd = O.reference_init_state_dict("resnet18", 5, D, 11)
+    for k in sd:
+        if k.endswith(".bn2.weight"):
+            sd[k] = sd[k] * 0.1
+    dec_sd = O.procedural_state_dict(O.decoder_schema(D), 12) if motion else None
+    enc = RGBF_EmbeddingModel("resnet18", D, True, "cuda")
+    enc.load_state_dict(sd)
+    tr = ModelTrainer(enc, motion)
+    if motion:
+        tr.fcn_time.load_state_dict(dec_sd)
+    orc = O.StudentOracle("resnet18", 5, D, motion, sd, dec_sd)
+    batches = [{"img": O.synthetic_crops(16, 5, 64, 20 + i), "emb": O.synthetic_targets(16, D, motion, 40 + i)}
+               for i in range(4)]
+    held = [{"img": O.synthetic_crops(16, 5, 64, 77), "emb": O.synthetic_targets(16, D, motion, 78)}]
+    opt, sc = tr.get_optimizer(5e-4)
+    orc.get_optimizer(5e-4)
+    emu = O.StudentOracle("resnet18", 5, D, motion, sd, dec_sd)
+    emu.get_optimizer(5e-4)
+    got, ref = [], []
+    for _ in range(3):
+        got.append(tr.epoch(batches, optimizer=opt, scaler=sc))
+        ref.append(orc.epoch(batches, train=True))
+        for b in batches:
+            _, _, _, g = emu.forward_loss(b["img"], b["emb"], train=True, need_grad=True, emulate_bf16=True)
+            O.adamw_update(emu.params(), g, emu.opt, 5e-4)
+    got.append(tr.epoch(held))
+    ref.append(orc.epoch(held, train=False))
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, ref)]
+    e_ref = O.embed(orc.enc, held[0]["img"], "resnet18", True)
+    with torch.no_grad():
+        e_emu = O.encoder_forward(emu.enc, held[0]["img"], "resnet18", False, None, True).numpy()
+    emb_hip = float(per_sample_rel(enc.embed(held[0]["img"]), e_ref).max())
+    emb_emu = float(per_sample_rel(e_emu, e_ref).max())
+
+    def weight_err(get):
+        num = den = 0.0
+        for name in orc.enc_keys:
+            r = orc.enc[name].double()
+            num += float(((get(name).double() - r) ** 2).sum())
+            den += float((r ** 2).sum())
+        return (num / den) ** 0.5
+    w_hip = weight_err(lambda n: enc.get_parameter(n).detach().cpu())
+    w_emu = weight_err(lambda n: emu.enc[n])
+    print("trajectory", dict(motion=motion, hip=got, ref=ref, rel=rel, emb=(emb_hip, emb_emu), w=(w_hip, w_emu)))
+    assert ref[2] < ref[0]                                       # the oracle itself is learning on these batches
+    assert max(rel) <= 1e-2, (got, ref)
+    assert emb_hip <= 1.5 * emb_emu + 1e-2, (emb_hip, emb_emu)
+    assert w_hip <= 1.5 * w_emu + 1e-2, (w_hip, w_emu)
+
+
 def test_adamw_kernel_injected_grads():
     """Fused AdamW kernel vs torch.optim.AdamW on identical injected gradients (golden from torch)."""
     import ctypes as C
