@@ -103,6 +103,14 @@ int vpd_backward(vpd_plan_t* plan, const float* params, float* grads, int n, voi
 int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
                    double lr, double beta1, double beta2, double eps, double weight_decay, int step, void* stream);
 
+/* The same optimizer.step(), fused with the refresh of `plan`'s packed bf16 weights (what vpd_pack_weights would do on
+ * the next forward): one pass over params / grads / adam_m / adam_v (16-byte aligned, numel >= the plan's
+ * vpd_plan_param_numel; tensors beyond the plan's are updated too).  After it `plan` needs no vpd_pack_weights until
+ * the parameters are written by someone else; other plans over the same parameters (the eval plan) still do. */
+int vpd_plan_adamw_step(vpd_plan_t* plan, float* params, const float* grads, float* adam_m, float* adam_v,
+                        long long numel, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int step, void* workspace, void* stream);
+
 /* hipGraph-captured eval forward for a fixed batch size (apply_vpd_model.py:152-168 inner
  * loop at BATCH_SIZE crops per call).  Capture binds the pointers given here. */
 /* ---- train-time input pipeline on the device (the step right before the hot path) ----
@@ -152,9 +160,9 @@ int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
 /* One implicit-GEMM conv launch on padded-NHWC bf16 tensors (forward conv or data-gradient conv).
  * tapset9 = {nr, nc, dy0, dys, dx0, dxs, w0, wrs, wcs}: tap (ir,ic) gathers input pixel
  * (y*istr + dy0 + ir*dys, x*istr + dx0 + ic*dxs) in padded coordinates and uses weight slice
- * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional, pre-zeroed): [16][2][Co] accumulator
- * rows (block b adds its per-channel sum / sum of squares into row b % 16). */
-int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, float* stats, int n, int xHp, int xWp,
+ * w0 + ir*wrs + ic*wcs of w_bf16 [slice][Co][Kc].  stats (optional, pre-zeroed): f64 [16][2][Co] accumulator
+ * rows (block b adds its per-channel sum / sum of squares into row b % 16 with fp64 atomics). */
+int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, double* stats, int n, int xHp, int xWp,
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);
 int vpd_op_conv_bm(int M, int Co);

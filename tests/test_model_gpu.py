@@ -295,6 +295,53 @@ def test_training_trajectory_tracks_fp32_oracle(motion):
     assert w_hip <= 1.5 * w_emu + 1e-2, (w_hip, w_emu)
 
 
+@pytest.mark.parametrize("arch,motion", [("resnet18", True), ("resnet50", False)])
+def test_fused_adamw_repack_equals_separate_kernels(arch, motion):
+    """optimizer.step() of the train loop is ONE kernel (AdamW + refresh of the plan's packed bf16 weights,
+    vpd_plan_adamw_step); it must leave the parameters, both moments and the NEXT forward exactly as the flat AdamW
+    kernel followed by vpd_pack_weights does."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    D = 32
+    sd = O.reference_init_state_dict(arch, 5, D, 21)
+    last = ".bn3.weight" if O.arch_expansion(arch) == 4 else ".bn2.weight"
+    for k in sd:                   # well-conditioned regime (see above): the BN statistics' fp32 atomics make an untrained
+        if k.endswith(last):       # ResNet-50's loss bimodal at the 2 % level, which would hide a stale weight
+            sd[k] = sd[k] * 0.1
+    dec_sd = O.procedural_state_dict(O.decoder_schema(D), 22) if motion else None
+    img, tgt = O.synthetic_crops(6, 5, 64, 23), O.synthetic_targets(6, D, motion, 24)
+    out, g0 = [], None
+    for fused in (True, False):
+        enc = RGBF_EmbeddingModel(arch, D, True, "cuda")
+        enc.load_state_dict(sd)
+        tr = ModelTrainer(enc, motion)
+        if motion:
+            tr.fcn_time.load_state_dict(dec_sd)
+        opt, _ = tr.get_optimizer(5e-4)
+        eng = enc.engine
+        enc.train()
+        losses = []
+        for it in range(3):
+            loss = tr._forward_loss(img, tgt, train=True)
+            losses.append(loss.item())
+            loss.backward()
+            if g0 is None:
+                g0 = eng.grads.clone()
+            eng.grads.copy_(g0)                  # identical gradients in both runs (BN statistics use fp32 atomics)
+            assert eng._step_plan is not None
+            if not fused:
+                eng._step_plan = None
+            opt.step()
+        torch.cuda.synchronize()
+        out.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), losses))
+    (p1, m1, v1, l1), (p0, m0, v0, l0) = out
+    for name, a, b in (("m", m1, m0), ("v", v1, v0), ("p", p1, p0)):
+        bad = (a != b).nonzero().flatten()
+        assert bad.numel() == 0, (name, int(bad.numel()), bad[:8].tolist(), float((a - b).abs().max()))
+    assert np.allclose(l1, l0, rtol=2e-3), (l1, l0)          # the next forwards ran on the same packed weights
+    assert abs(l1[1] - l1[0]) > 0.01 * l1[0]                  # ... and one step moves the loss far more than that
+
+
 def test_adamw_kernel_injected_grads():
     """Fused AdamW kernel vs torch.optim.AdamW on identical injected gradients (golden from torch)."""
     import ctypes as C

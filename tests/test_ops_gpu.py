@@ -72,7 +72,7 @@ def run_conv(xp, wp, n, xHp, xWp, xC, yH, yW, ypad, Hs, Ws, osub, oph, opw, istr
         y = torch.zeros(n * yHp * yWp * yC, dtype=torch.bfloat16, device="cuda")
     stats = None
     if want_stats:
-        stats = torch.zeros(16, 2, Co, dtype=torch.float32, device="cuda")     # VPD_STAT_ROWS accumulator rows
+        stats = torch.zeros(16, 2, Co, dtype=torch.float64, device="cuda")     # VPD_STAT_ROWS accumulator rows
     _check(L.vpd_op_conv2d(ptr(xp), ptr(wp), ptr(y), ptr(stats) if stats is not None else None, n, xHp, xWp, xC,
                            yHp, yWp, yC, ypad, Hs, Ws, osub, oph, opw, istr, Kc, Co, taps, accumulate, stream()))
     torch.cuda.synchronize()

@@ -38,7 +38,7 @@ for name, ci, co, hw in LAYERS:
     w = (torch.randn(9 * co * ci, device="cuda") * 0.05).to(torch.bfloat16)
     y = torch.zeros(B * hw * hw * co, device="cuda", dtype=torch.bfloat16)
     dzp = torch.randn(B * (hw + 2) * (hw + 2) * co, device="cuda").to(torch.bfloat16)
-    stats = torch.zeros(64 * 2 * co, device="cuda")
+    stats = torch.zeros(64 * 2 * co, dtype=torch.float64, device="cuda")
     dw = torch.zeros(9 * co * ci, device="cuda")
     slab = torch.empty(L.vpd_op_wgrad_slab_bytes() // 4, device="cuda")
     flops = 2.0 * B * hw * hw * co * ci * 9

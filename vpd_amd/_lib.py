@@ -38,6 +38,8 @@ SIGNATURES = {
     "vpd_backward": (C.c_int, [vp, vp, vp, C.c_int, C.POINTER(vp), vp, vp]),
     "vpd_adamw_step": (C.c_int, [vp, vp, vp, vp, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_double, C.c_int, vp]),
+    "vpd_plan_adamw_step": (C.c_int, [vp, vp, vp, vp, vp, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_int, vp, vp]),
     "vpd_augment_crops": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                     C.c_float, vp, vp, vp]),
     "vpd_plan_stage_crops": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),

@@ -1,7 +1,9 @@
 // BatchNorm (train + eval), ReLU, residual add, stem max-pool and their
 // backward passes.  All HBM-bound: 16-byte (8 x bf16) accesses per lane,
-// per-channel reductions done as per-block partials (deterministic) that a
-// tiny finalize kernel sums in double precision.
+// per-channel reductions done as per-block fp32 partials (fixed order inside a
+// block) added with fp64 atomics into 16 accumulator rows that a tiny finalize
+// kernel sums in double precision: the arrival order of the blocks moves a sum
+// by ~1e-16 relative, which does not survive the fp32 rounding of the results.
 #include "common.h"
 #include "kernels.h"
 
@@ -11,8 +13,8 @@
 // ---------------------------------------------------------------------------
 // One wave per 64 channels, one channel per lane: the 2*VPD_STAT_ROWS loads are independent and go out
 // back to back, so the kernel costs one memory round trip (it is latency, not bandwidth, bound).
-static __device__ __forceinline__ void stat_rows_take(float* partials, int C, int c, double* s1, double* s2) {
-    float v1[VPD_STAT_ROWS], v2[VPD_STAT_ROWS];
+static __device__ __forceinline__ void stat_rows_take(double* partials, int C, int c, double* s1, double* s2) {
+    double v1[VPD_STAT_ROWS], v2[VPD_STAT_ROWS];
 #pragma unroll
     for (int t = 0; t < VPD_STAT_ROWS; ++t) {
         v1[t] = partials[((size_t)t * 2) * C + c];
@@ -21,15 +23,15 @@ static __device__ __forceinline__ void stat_rows_take(float* partials, int C, in
     double a = 0.0, b = 0.0;
 #pragma unroll
     for (int t = 0; t < VPD_STAT_ROWS; ++t) {
-        a += (double)v1[t]; b += (double)v2[t];
-        partials[((size_t)t * 2) * C + c] = 0.f;          // leave the accumulator rows zeroed for the next producer
-        partials[((size_t)t * 2 + 1) * C + c] = 0.f;
+        a += v1[t]; b += v2[t];
+        partials[((size_t)t * 2) * C + c] = 0.0;          // leave the accumulator rows zeroed for the next producer
+        partials[((size_t)t * 2 + 1) * C + c] = 0.0;
     }
     *s1 = a; *s2 = b;
 }
 
 __global__ __launch_bounds__(64) void bn_finalize_kernel(
-    float* partials, int T, int C, float count,
+    double* partials, int T, int C, float count,
     const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, float momentum, float eps,
     float* mean, float* rstd, float* scale, float* shift) {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
     }
 }
 
-hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
+hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, T, C, count, gamma,
@@ -265,13 +267,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p)
         const int q8 = ch >> 3, j = ch & 7;
         float tot = 0.f;
         for (int g = 0; g < ppi; ++g) tot += sh[g * cv + q8][which * 8 + j];
-        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], (double)tot);
     }
 }
 
 // pass 1b: partials -> dgamma, dbeta (fp32 grads) and the apply coefficients
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
-    float* partials, int T, int C, float count, const float* __restrict__ gamma,
+    double* partials, int T, int C, float count, const float* __restrict__ gamma,
     const float* __restrict__ rstd, float* dgamma, float* dbeta, float* coef) {
     (void)T;
     const int c = blockIdx.x * 64 + threadIdx.x;
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
         const int q8 = ch >> 3, j = ch & 7;
         float tot = 0.f;
         for (int gI = 0; gI < ppi; ++gI) tot += sh[gI * cv + q8][which * 8 + j];
-        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], (double)tot);
     }
 }
 
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_sums_kernel(const StemPoolB
         const int q8 = ch >> 3, j = ch & 7;
         float tot = 0.f;
         for (int gI = 0; gI < ppi; ++gI) tot += sh[gI * cv + q8][which * 8 + j];
-        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], tot);
+        atomicAdd(&p.partials[((size_t)(blockIdx.x & (VPD_STAT_ROWS - 1)) * 2 + which) * p.C + ch], (double)tot);
     }
 }
 

@@ -103,7 +103,7 @@ struct ConvParams {
     const bf16_t* x; int xHp, xWp, xC;          // padded dims, pixel stride (elements)
     const bf16_t* w;                            // [tap][Co][Kc] bf16
     bf16_t* y; int yHp, yWp, yC, ypad;
-    float* stats;                               // [mtiles][2][Co] partial sum / sumsq, or null
+    double* stats;                              // [VPD_STAT_ROWS][2][Co] accumulators of sum / sum of squares (fp64 atomics), or null
     const float* ep_scale; const float* ep_shift;   // eval epilogue: y = relu?(scale*acc+shift(+res))
     const bf16_t* res; int rHp, rWp, rC, rpad;  // residual for the eval epilogue (padded act) or null
     int ep_relu;

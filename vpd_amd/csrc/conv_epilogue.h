@@ -131,8 +131,10 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + c];
-            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them
-            atomicAdd(&p.stats[((size_t)(row & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], t);
+            // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them.  The rows
+            // are fp64: the order in which blocks arrive then perturbs a sum at the 1e-16 level, far below the fp32
+            // rounding of mean / rstd, so the statistics (and with them the whole step) repeat run to run
+            atomicAdd(&p.stats[((size_t)(row & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], (double)t);
         }
     }
 }

@@ -27,7 +27,7 @@ struct BnBwdParams {
     const bf16_t* act; int aHp, aWp, apad;   // padded post-ReLU activation (mask) or null
     const float* mean; const float* rstd;
     float* coef;                        // [3][C] scratch
-    float* partials;                    // [T][2][C] scratch
+    double* partials;                   // [VPD_STAT_ROWS][2][C] fp64 accumulator rows
     bf16_t* dz; int dzHp, dzWp, dzpad;  // output (padded or dense)
     int M, H, W, C, write_g, ppb;
     const float* mscale; const float* mshift;   // when act == null and these are set: ReLU mask = (mscale*z + mshift > 0)
@@ -39,7 +39,7 @@ struct StemPoolBwdParams {
     const bf16_t* z;                    // dense [N][Hz][Wz][C]
     const float* mean; const float* rstd; const float* scale; const float* shift;
     bf16_t* g;                          // unused (g is recomputed, never stored)
-    float* partials;
+    double* partials;
     int M, Hz, Wz, Ho, Wo, C, ppb;
     int pass; const float* coef; bf16_t* dz;    // filled by the launcher
     // pooled post-ReLU activation (padded NHWC, border ppad) and the BN affine parameters: the backward sums are taken
@@ -52,8 +52,10 @@ struct PackDesc {                       // one convolution's weight tensors
     long long fwd_off;                  // bf16 [ntaps][Co][Kc] offset in the packed-weight arena
     long long dgr_off;                  // bf16 [kh*kw][Ci][Co] offset (dgrad layout) or -1
     long long wg_off;                   // fp32 [ntaps][Co][Kc] offset in the wgrad scratch
-    int Co, Ci, kh, kw, Kc, ntaps, stem;
+    int Co, Ci, kh, kw, Kc, ntaps, stem;   // stem: 1 = 7x7 row-tap packing; 2 = not a conv: plain range (AdamW only)
+    long long numel;                    // stem == 2: length of the range at src_off
 };
+struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
@@ -68,7 +70,7 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
 bool vpd_wgrad_overwrites(const WgradParams& p);
 bool vpd_wgrad_halo_shape_ok(int Hout, int Wout);
 
-hipError_t vpd_launch_bn_finalize(float* partials, int T, int C, float count, const float* gamma,
+hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,
                                   float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
 hipError_t vpd_launch_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -99,6 +101,9 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
                                  int Cp, hipStream_t s);
 hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* master, bf16_t* arena, hipStream_t s);
+hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
+                                 float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
+                                 int step, hipStream_t s);
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* wg, float* grads, hipStream_t s);
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,

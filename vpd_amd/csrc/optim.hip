@@ -91,21 +91,36 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackDesc* descs
     const int tci = d.Ci >> 5;
     const int co0 = (chunk / tci) * 32, ci0 = (chunk % tci) * 32;
     const int run = 32 * khw;                      // contiguous floats per co row of the tile
-    for (int i = threadIdx.x; i < 32 * run; i += 256) {
-        const int r = i / run, k = i - r * run;
-        tile[r][k] = src[((size_t)(co0 + r) * d.Ci + ci0) * khw + k];
+    if ((reinterpret_cast<size_t>(src) & 15) == 0) {   // 16-byte loads (run and the row starts are multiples of 4 floats)
+        const int run4 = run >> 2;
+        for (int i = threadIdx.x; i < 32 * run4; i += 256) {
+            const int r = i / run4, k = (i - r * run4) << 2;
+            const float4 f = *reinterpret_cast<const float4*>(src + ((size_t)(co0 + r) * d.Ci + ci0) * khw + k);
+            tile[r][k] = f.x; tile[r][k + 1] = f.y; tile[r][k + 2] = f.z; tile[r][k + 3] = f.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 32 * run; i += 256) {
+            const int r = i / run, k = i - r * run;
+            tile[r][k] = src[((size_t)(co0 + r) * d.Ci + ci0) * khw + k];
+        }
     }
     __syncthreads();
-    // forward: dst[(tap*Co + co)*Ci + ci]; lanes run along ci
-    for (int i = threadIdx.x; i < 32 * run; i += 256) {
-        const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
-        arena[d.fwd_off + ((size_t)tap * d.Co + co0 + co) * d.Ci + ci0 + ci] = (bf16_t)tile[co][ci * khw + tap];
+    // forward: dst[(tap*Co + co)*Ci + ci]: a lane converts 8 consecutive ci -> one 16-byte store, 4 lanes per 64-byte run
+    for (int i = threadIdx.x; i < 128 * khw; i += 256) {
+        const int q = i & 3, co = (i >> 2) & 31, tap = i >> 7;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = tile[co][(q * 8 + j) * khw + tap];
+        *reinterpret_cast<uint4*>(arena + d.fwd_off + ((size_t)tap * d.Co + co0 + co) * d.Ci + ci0 + q * 8) = pack8(f);
     }
-    // dgrad: dst[(tap*Ci + ci)*Co + co]; lanes run along co
+    // dgrad: dst[(tap*Ci + ci)*Co + co]: 8 consecutive co per lane
     if (d.dgr_off >= 0)
-        for (int i = threadIdx.x; i < 32 * run; i += 256) {
-            const int co = i & 31, ci = (i >> 5) & 31, tap = i >> 10;
-            arena[d.dgr_off + ((size_t)tap * d.Ci + ci0 + ci) * d.Co + co0 + co] = (bf16_t)tile[co][ci * khw + tap];
+        for (int i = threadIdx.x; i < 128 * khw; i += 256) {
+            const int q = i & 3, ci = (i >> 2) & 31, tap = i >> 7;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = tile[q * 8 + j][ci * khw + tap];
+            *reinterpret_cast<uint4*>(arena + d.dgr_off + ((size_t)tap * d.Ci + ci0 + ci) * d.Co + co0 + q * 8) = pack8(f);
         }
 }
 hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
@@ -116,7 +131,8 @@ hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int
 }
 
 // Gradient of every conv of a bucket -> flat gradient buffer in the reference's OIHW order, one launch.
-// Every conv's weight gradient sits in the wgrad scratch as [tap][Co][Kc] fp32: gather into OIHW.
+// Every conv's weight gradient sits in the wgrad scratch as [tap][Co][Kc] fp32: gather into OIHW (element-wise: the
+// strided 4-byte reads are absorbed by L2; an LDS-tiled transpose like pack_weights_kernel measured 48 % slower).
 __global__ __launch_bounds__(256) void unpack_grads_kernel(const PackDesc* descs, const int* blockmap, const float* wg,
                                                            float* grads) {
     const PackDesc d = descs[blockmap[2 * blockIdx.x]];
@@ -148,32 +164,114 @@ hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int
 
 // Fused AdamW over the whole flat parameter buffer (every tensor shares the
 // hyper-parameters: train_vpd_model.py:104 uses one param group, wd on all).
+// (explicit fma placement: the flat kernel and the fused AdamW + repack kernel must round identically)
+static __device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, const AdamHyper& h) {
+#pragma clang fp contract(off)
+    p *= h.decay;
+    m = fmaf(g - m, h.omb1, m);
+    v = fmaf(h.omb2 * g, g, v * h.b2);
+    const float den = fmaf(sqrtf(v), h.inv_sqrt_bc2, h.eps);
+    p = fmaf(-h.step_size, m / den, p);
+}
+static __device__ __forceinline__ void adamw4(float4& pp, const float4& gg, float4& mm, float4& vv, const AdamHyper& h) {
+    adamw1(pp.x, gg.x, mm.x, vv.x, h); adamw1(pp.y, gg.y, mm.y, vv.y, h);
+    adamw1(pp.z, gg.z, mm.z, vv.z, h); adamw1(pp.w, gg.w, mm.w, vv.w, h);
+}
+static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int step) {
+    const double bc1 = 1.0 - pow(b1, step);
+    const double bc2 = 1.0 - pow(b2, step);
+    return AdamHyper{(float)(1.0 - lr * wd), (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), (float)eps};
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, float4* m, float4* v, long n4,
-                                                    float decay, float omb1, float b2, float omb2, float step_size,
-                                                    float inv_sqrt_bc2, float eps) {
+                                                    const AdamHyper h) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
-#define ADAMW1(f)                                                         \
-        pp.f *= decay;                                                    \
-        mm.f += (gg.f - mm.f) * omb1;                                     \
-        vv.f = vv.f * b2 + omb2 * gg.f * gg.f;                            \
-        pp.f -= step_size * (mm.f / (sqrtf(vv.f) * inv_sqrt_bc2 + eps));
-        ADAMW1(x) ADAMW1(y) ADAMW1(z) ADAMW1(w)
-#undef ADAMW1
+        adamw4(pp, gg, mm, vv, h);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
 }
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                             double eps, double wd, int step, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
-    const double bc1 = 1.0 - pow(b1, step);
-    const double bc2 = 1.0 - pow(b2, step);
     const long n4 = n / 4;
     long gsz = (n4 + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3(gsz < 1 ? 1 : (int)gsz), dim3(256), 0, s, (float4*)p, (const float4*)g,
-                       (float4*)m, (float4*)v, n4, (float)(1.0 - lr * wd), (float)(1.0 - b1), (float)b2,
-                       (float)(1.0 - b2), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps);
+                       (float4*)m, (float4*)v, n4, adam_hyper(lr, b1, b2, eps, wd, step));
+    return hipGetLastError();
+}
+
+// AdamW and the repack of the bf16 weight layouts in ONE pass over the parameters (the train step's optimizer):
+// a block updates a 32(co) x 32(ci) x taps tile of a conv weight in place (p, m, v: 16-byte accesses of the OIHW
+// runs), keeps the new values in LDS and writes both bf16 layouts from there -- pack_weights_kernel's tile without
+// re-reading the 85 MB of master weights.  Ranges that are not conv weights (BatchNorm, fc, motion head) are
+// `stem == 2` descriptors updated element-wise; so is the stem conv, whose row-tap packing gathers across the whole
+// tensor and is done by a 28-block pack_weights_kernel launch afterwards.
+#define ADAM_PLAIN_CHUNK 2048
+__global__ __launch_bounds__(256) void adamw_pack_kernel(const PackDesc* descs, const int* blockmap, float* p,
+                                                         const float* g, float* m, float* v, bf16_t* arena,
+                                                         const AdamHyper h) {
+    __shared__ unsigned short tile[32][32 * 9 + 2];      // the new weights, already rounded to bf16 (18 KB: 8 blocks per CU)
+    const PackDesc d = descs[blockmap[2 * blockIdx.x]];
+    const int chunk = blockmap[2 * blockIdx.x + 1];
+    const int khw = d.kh * d.kw;
+    if (d.stem == 2) {
+        const long e0 = d.src_off + (long)chunk * ADAM_PLAIN_CHUNK;
+        const long e1 = d.src_off + d.numel;
+        for (long e = e0 + threadIdx.x; e < e0 + ADAM_PLAIN_CHUNK && e < e1; e += 256) {
+            float pp = p[e], mm = m[e], vv = v[e];
+            adamw1(pp, g[e], mm, vv, h);
+            p[e] = pp; m[e] = mm; v[e] = vv;
+        }
+        return;
+    }
+    const int tci = d.Ci >> 5;
+    const int co0 = (chunk / tci) * 32, ci0 = (chunk % tci) * 32;
+    const int run4 = (32 * khw) >> 2;
+    for (int i = threadIdx.x; i < 32 * run4; i += 256) {
+        const int r = i / run4, k = (i - r * run4) << 2;
+        const size_t e = d.src_off + ((size_t)(co0 + r) * d.Ci + ci0) * khw + k;
+        float4 pp = *reinterpret_cast<const float4*>(p + e);
+        float4 mm = *reinterpret_cast<const float4*>(m + e);
+        float4 vv = *reinterpret_cast<const float4*>(v + e);
+        adamw4(pp, *reinterpret_cast<const float4*>(g + e), mm, vv, h);
+        *reinterpret_cast<float4*>(p + e) = pp;
+        *reinterpret_cast<float4*>(m + e) = mm;
+        *reinterpret_cast<float4*>(v + e) = vv;
+        tile[r][k] = __builtin_bit_cast(unsigned short, (bf16_t)pp.x);
+        tile[r][k + 1] = __builtin_bit_cast(unsigned short, (bf16_t)pp.y);
+        tile[r][k + 2] = __builtin_bit_cast(unsigned short, (bf16_t)pp.z);
+        tile[r][k + 3] = __builtin_bit_cast(unsigned short, (bf16_t)pp.w);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * khw; i += 256) {
+        const int q = i & 3, co = (i >> 2) & 31, tap = i >> 7;
+        unsigned int w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (unsigned int)tile[co][(q * 8 + 2 * j) * khw + tap] | ((unsigned int)tile[co][(q * 8 + 2 * j + 1) * khw + tap] << 16);
+        *reinterpret_cast<uint4*>(arena + d.fwd_off + ((size_t)tap * d.Co + co0 + co) * d.Ci + ci0 + q * 8) = uint4{w[0], w[1], w[2], w[3]};
+    }
+    if (d.dgr_off >= 0)
+        for (int i = threadIdx.x; i < 128 * khw; i += 256) {
+            const int q = i & 3, ci = (i >> 2) & 31, tap = i >> 7;
+            unsigned int w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                w[j] = (unsigned int)tile[q * 8 + 2 * j][ci * khw + tap] | ((unsigned int)tile[q * 8 + 2 * j + 1][ci * khw + tap] << 16);
+            *reinterpret_cast<uint4*>(arena + d.dgr_off + ((size_t)tap * d.Ci + ci0 + ci) * d.Co + co0 + q * 8) = uint4{w[0], w[1], w[2], w[3]};
+        }
+}
+hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
+                                 float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
+                                 int step, hipStream_t s) {
+    if ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) |
+         reinterpret_cast<size_t>(v)) & 15)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adamw_pack_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, p, g, m, v, arena,
+                       adam_hyper(lr, b1, b2, eps, wd, step));
     return hipGetLastError();
 }
 

@@ -108,6 +108,9 @@ struct vpd_plan {
     // descriptor tables (host copies, uploaded by init_workspace)
     std::vector<PackDesc> descs;
     std::vector<int> bmap_pack;
+    std::vector<int> bmap_adam;            // fused AdamW + repack: conv tiles, the stem (one block), plain ranges
+    size_t bmap_adam_off = 0;
+    int nstem_pack_blocks = 0;             // leading entries of bmap_pack that belong to the stem
     std::vector<int> bmap_unpack[4];
     size_t partial_bytes = 0;
     // captured eval graphs keyed by batch size
@@ -282,6 +285,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         PackDesc d;
         d.src_off = c.w_off; d.fwd_off = c.fwd_off; d.dgr_off = c.dgr_off; d.wg_off = c.wg_off;
         d.Co = c.Co; d.Ci = c.Ci; d.kh = c.k; d.kw = c.k; d.Kc = c.Kc; d.ntaps = c.ntaps; d.stem = c.stem ? 1 : 0;
+        d.numel = 0;
         const int id = (int)p->descs.size();
         p->descs.push_back(d);
         const long long nf = (long long)c.ntaps * c.Co * c.Kc;
@@ -304,6 +308,30 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         if (bottleneck) push_desc(B.c3, bucket);
         if (B.ds) push_desc(B.cd, bucket);
     }
+    {
+        // block map of vpd_plan_adamw_step: every conv tile as in the pack map (not the stem), then the ranges
+        // of [0, nparam_padded) that are not conv weights, in 2048-float chunks (ADAM_PLAIN_CHUNK of optim.hip)
+        const int nconv = (int)p->descs.size();
+        for (size_t i = 0; i + 1 < p->bmap_pack.size(); i += 2) {             // descs[0] is the stem: a plain range here
+            if (p->bmap_pack[i] == 0) { p->nstem_pack_blocks++; continue; }
+            p->bmap_adam.push_back(p->bmap_pack[i]); p->bmap_adam.push_back(p->bmap_pack[i + 1]);
+        }
+        std::vector<std::pair<long long, long long>> convs;                   // (offset, numel), ascending
+        for (int i = 1; i < nconv; ++i)
+            convs.push_back({p->descs[i].src_off, (long long)p->descs[i].Co * p->descs[i].Ci * p->descs[i].kh * p->descs[i].kw});
+        std::sort(convs.begin(), convs.end());
+        long long pos = 0;
+        auto plain = [&](long long a, long long b) {
+            if (b <= a) return;
+            PackDesc d = {};
+            d.src_off = a; d.numel = b - a; d.stem = 2; d.kh = d.kw = 1; d.dgr_off = -1;
+            const int id = (int)p->descs.size();
+            p->descs.push_back(d);
+            for (long long ch = 0; ch * 2048 < b - a; ++ch) { p->bmap_adam.push_back(id); p->bmap_adam.push_back((int)ch); }
+        };
+        for (auto& cv : convs) { plain(pos, cv.first); pos = cv.first + cv.second; }
+        plain(pos, p->nparam_padded);
+    }
 
     // ---- workspace layout ----
     Bump bp;
@@ -315,6 +343,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     for (BnInfo* b : p->bns) b->fl_off = bp.take((size_t)9 * b->C * 4);
     p->desc_off = bp.take(p->descs.size() * sizeof(PackDesc));
     p->bmap_pack_off = bp.take(p->bmap_pack.size() * sizeof(int));
+    p->bmap_adam_off = bp.take(p->bmap_adam.size() * sizeof(int));
     for (int i = 0; i < 4; ++i) p->bmap_unpack_off[i] = bp.take(p->bmap_unpack[i].size() * sizeof(int) + 16);
     // statistics partials: max over layers of T*2*C floats
     {
@@ -332,7 +361,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         upd(p->stem);
         for (auto& B : p->blocks) { upd(B.c1); upd(B.c2); if (B.ds) upd(B.cd); }
         (void)mx;   // producers accumulate atomically into VPD_STAT_ROWS rows of [2][C]
-        p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * p->feat * 4;
+        p->partial_bytes = (size_t)VPD_STAT_ROWS * 2 * p->feat * sizeof(double);
         p->partial_off = bp.take(p->partial_bytes);
     }
     p->z0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -468,6 +497,7 @@ extern "C" int vpd_plan_init_workspace(vpd_plan_t* p, void* ws, void* stream) {
     HCHECK(hipMemsetAsync(ws, 0, p->ws_bytes, s));
     HCHECK(hipMemcpyAsync(w + p->desc_off, p->descs.data(), p->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s));
     HCHECK(hipMemcpyAsync(w + p->bmap_pack_off, p->bmap_pack.data(), p->bmap_pack.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HCHECK(hipMemcpyAsync(w + p->bmap_adam_off, p->bmap_adam.data(), p->bmap_adam.size() * sizeof(int), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 4; ++i)
         if (!p->bmap_unpack[i].empty())
             HCHECK(hipMemcpyAsync(w + p->bmap_unpack_off[i], p->bmap_unpack[i].data(),
@@ -488,6 +518,7 @@ struct Ctx {
     int n;
     bf16_t* b16(size_t off) const { return reinterpret_cast<bf16_t*>(ws + off); }
     float* f32(size_t off) const { return reinterpret_cast<float*>(ws + off); }
+    double* stat_rows() const { return reinterpret_cast<double*>(ws + p->partial_off); }
     float* bn_mean(const BnInfo& b) const { return f32(b.fl_off); }
     float* bn_rstd(const BnInfo& b) const { return f32(b.fl_off) + b.C; }
     float* bn_scale(const BnInfo& b) const { return f32(b.fl_off) + 2 * b.C; }
@@ -536,7 +567,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.w = c.b16(c.p->arena_off) + cv.fwd_off;
     q.y = y; q.yHp = cv.Hout + 2 * ypad; q.yWp = cv.Wout + 2 * ypad; q.yC = cv.Co; q.ypad = ypad;
-    q.stats = stats ? c.f32(c.p->partial_off) : nullptr;
+    q.stats = stats ? c.stat_rows() : nullptr;
     q.ep_scale = ep_scale; q.ep_shift = ep_shift; q.res = res; q.ep_relu = ep_relu;
     q.rHp = cv.Hout + 2; q.rWp = cv.Wout + 2; q.rC = cv.Co; q.rpad = 1;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
@@ -552,7 +583,7 @@ hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) 
     const int bm = vpd_conv_bm(M, cv.Co);
     (void)bm;
     const int T = VPD_STAT_ROWS;     // unused accumulator rows are zero; the producer's tile size is its own business
-    return vpd_launch_bn_finalize(c.f32(c.p->partial_off), T, cv.Co, (float)M, c.params + cv.bn.w_off,
+    return vpd_launch_bn_finalize(c.stat_rows(), T, cv.Co, (float)M, c.params + cv.bn.w_off,
                                   c.params + cv.bn.b_off, bn_running ? bn_running + cv.bn.rm_off : nullptr,
                                   bn_running ? bn_running + cv.bn.rv_off : nullptr, kBnMomentum, kBnEps,
                                   c.bn_mean(cv.bn), c.bn_rstd(cv.bn), c.bn_scale(cv.bn), c.bn_shift(cv.bn), c.s);
@@ -670,7 +701,7 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
     b.act = act; b.aHp = cv.Hout + 2; b.aWp = cv.Wout + 2; b.apad = 1;
     b.mean = c.bn_mean(cv.bn); b.rstd = c.bn_rstd(cv.bn); b.coef = c.bn_coef(cv.bn);
-    b.partials = c.f32(c.p->partial_off);
+    b.partials = c.stat_rows();
     b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
     if (relu_from_z && !reduce_done) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
@@ -1033,7 +1064,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         sb.dpool = G[gi]; sb.idx = reinterpret_cast<const unsigned char*>(ws + p->idx_off); sb.z = c.b16(p->z0_off);
         sb.mean = c.bn_mean(p->stem.bn); sb.rstd = c.bn_rstd(p->stem.bn);
         sb.scale = c.bn_scale(p->stem.bn); sb.shift = c.bn_shift(p->stem.bn);
-        sb.g = c.b16(p->g0_off); sb.partials = c.f32(p->partial_off);
+        sb.g = c.b16(p->g0_off); sb.partials = c.stat_rows();
         sb.pooled = c.b16(p->p0_off); sb.ppad = 1;
         sb.gamma_p = params + p->stem.bn.w_off; sb.beta_p = params + p->stem.bn.b_off;
         sb.M = n * p->H0 * p->W0; sb.Hz = p->H0; sb.Wz = p->W0; sb.Ho = p->H1; sb.Wo = p->W1; sb.C = 64;
@@ -1078,6 +1109,29 @@ extern "C" int vpd_adamw_step(float* params, const float* grads, float* adam_m, 
     if (step < 1) return fail("step is 1-based");
     LCHECK(vpd_launch_adamw(params, grads, adam_m, adam_v, (long)numel, lr, beta1, beta2, eps, weight_decay, step,
                             (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* grads, float* adam_m, float* adam_v,
+                                   long long numel, double lr, double beta1, double beta2, double eps,
+                                   double weight_decay, int step, void* workspace, void* stream) {
+    if (!p || !params || !grads || !adam_m || !adam_v || !workspace) return fail("null argument");
+    if (p->bound_ws != workspace) return fail("workspace not initialised with vpd_plan_init_workspace");
+    if (numel % 4 || numel < p->nparam_padded) return fail("numel must be a multiple of 4 and cover the plan's parameters");
+    if (step < 1) return fail("step is 1-based");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    LCHECK(vpd_launch_adamw_pack(reinterpret_cast<const PackDesc*>(ws + p->desc_off),
+                                 reinterpret_cast<const int*>(ws + p->bmap_adam_off), (int)p->bmap_adam.size() / 2, params,
+                                 grads, adam_m, adam_v, reinterpret_cast<bf16_t*>(ws + p->arena_off), lr, beta1, beta2,
+                                 eps, weight_decay, step, s));
+    LCHECK(vpd_launch_pack_weights(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
+                                   reinterpret_cast<const int*>(ws + p->bmap_pack_off), p->nstem_pack_blocks, params,
+                                   reinterpret_cast<bf16_t*>(ws + p->arena_off), s));
+    if (numel > p->nparam_padded)      // tensors the plan does not use (a motion head on a plan built without it)
+        LCHECK(vpd_launch_adamw(params + p->nparam_padded, grads + p->nparam_padded, adam_m + p->nparam_padded,
+                                adam_v + p->nparam_padded, (long)(numel - p->nparam_padded), lr, beta1, beta2, eps,
+                                weight_decay, step, s));
     return 0;
 }
 
@@ -1148,7 +1202,7 @@ static TapSet tapset_from(const int* t) {
     return ts;
 }
 
-extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, float* stats, int n, int xHp, int xWp, int xC,
+extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, double* stats, int n, int xHp, int xWp, int xC,
                              int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                              int Kc, int Co, const int* tapset9, int accumulate, void* stream) {
     ConvParams q;

@@ -5,6 +5,7 @@ only; every arithmetic step of the hot path is a hand-written HIP kernel behind
 the C ABI (include/vpd_hip.h).  There is no fallback path.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -140,6 +141,7 @@ class StudentEngine:
         self._plans = {}
         self._hip_version = 0          # bumped when a HIP kernel (AdamW) rewrites params behind torch's back
         self._last = None              # (plan, n) of the last train forward, consumed by backward
+        self._step_plan = None         # plan of the last backward: its packed weights are refreshed by adamw_step
         self.bucket_events = None
 
     # -- helpers -------------------------------------------------------------
@@ -162,6 +164,8 @@ class StudentEngine:
         pl = self._plans.get(key)
         if pl is None or pl.max_batch < n:
             if pl is not None:
+                if self._step_plan is pl:
+                    self._step_plan = None
                 pl.close()
             pl = _Plan(self, h, w, max(n, pl.max_batch if pl else 0), train, motion)
             assert pl.param_numel <= self.param_numel      # plans without the motion head omit its tensors
@@ -240,6 +244,7 @@ class StudentEngine:
             raise RuntimeError("backward() without a preceding train-mode forward with a target")
         pl, n = self._last
         self._last = None
+        self._step_plan = pl
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
@@ -252,10 +257,20 @@ class StudentEngine:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
         self.adam_step += 1
-        check(lib().vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
-                                   self.param_numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
-                                   self._stream()), "vpd_adamw_step")
-        self._hip_version += 1
+        pl = self._step_plan
+        if pl is not None and pl.packed_version == self.weights_version() and os.environ.get("VPD_FUSED_ADAMW", "1") != "0":
+            # the train plan of the last backward: AdamW + refresh of its packed bf16 weights in one pass
+            check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                            _ptr(self.adam_v), self.param_numel, lr, betas[0], betas[1], eps,
+                                            weight_decay, self.adam_step, _ptr(pl.workspace), self._stream()),
+                  "vpd_plan_adamw_step")
+            self._hip_version += 1
+            pl.packed_version = self.weights_version()
+        else:
+            check(lib().vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                                       self.param_numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
+                                       self._stream()), "vpd_adamw_step")
+            self._hip_version += 1
 
     def capture_eval_graph(self, x, out):
         """hipGraph of the eval forward for this batch size, bound to x / out (capture needs a
