@@ -257,6 +257,28 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
         __builtin_amdgcn_s_barrier();                             // READY_c
         if (VPD_ABL(p, 2)) continue;
         const bf16_t* st = ring + (c % 3) * STAGE;
+        if constexpr (NT == 4) {
+            // the 4-tap wave of a SIMD reads BOTH k-steps up front and then issues its 32 MFMAs in one run, so that
+            // the 5-tap wave's second read phase falls into this wave's MFMAs instead of coinciding with a read
+            // phase of its own (the two waves leave the barrier together)
+            bf16x8 az[2][4], bx[2][NT];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) az[ks][a] = frag(st + ks * 32 * 64, offA[a][0], offA[a][1]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bx[ks][t] = frag(st, offB[ks][t][0], offB[ks][t][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][t], acc[t][a], 0, 0, 0);
+            continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 az[4], bx[NT];
