@@ -108,13 +108,15 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
                             pin_memory=True)
 
     encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, flow_img is not None, device, pretrained=pretrained)
-    if world > 1:      # same initial weights on every rank
-        torch.distributed.broadcast(encoder.engine.params, 0)
     augmenter = None
     if gpu_augment:
         from vpd_amd.augment import CropAugmenter
         augmenter = CropAugmenter(encoder.device, rgb_mean_std, img_dim, flow_img is not None)
     trainer = ModelTrainer(encoder, motion, augmenter=augmenter)
+    if world > 1:      # same initial weights on every rank (after the trainer: the motion head is initialised there)
+        torch.distributed.broadcast(encoder.engine.params, 0)
+        torch.distributed.broadcast(encoder.engine.bn_running, 0)
+        encoder.engine.mark_weights_changed()
     optimizer, scaler = trainer.get_optimizer(learning_rate)
 
     if rank == 0:

@@ -159,6 +159,11 @@ class StudentEngine:
     def weights_version(self):
         return (self.params._version, self.bn_running._version, self._hip_version)
 
+    def mark_weights_changed(self):
+        """Call after writing `params` / `bn_running` by a path torch's version counters do not see (a collective, a
+        raw pointer): every plan repacks its bf16 weights before its next forward."""
+        self._hip_version += 1
+
     def plan(self, h, w, n, train, motion):
         key = (h, w, bool(train), bool(motion))
         pl = self._plans.get(key)
