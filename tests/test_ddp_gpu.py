@@ -116,3 +116,22 @@ def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
     rel = np.linalg.norm(g0 - total) / np.linalg.norm(total)
     assert rel < 1e-3, rel                      # fp32 atomics: order of summation varies run to run (measured ~1e-6)
     assert abs(ep0 - loss_sum / 10) <= 1e-4 * abs(ep0)
+
+
+def test_train_cli_two_ranks_keep_identical_replicas(tmp_path):
+    """train_vpd_model.py under two ranks (both on this GPU, gloo) with the motion head: the CLI broadcasts rank 0's
+    initial weights (encoder AND motion head), all-reduces the gradients, and at the end compares a parameter checksum
+    across ranks -- a diverged replica makes the run fail."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "run")
+    env = dict(os.environ, VPD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29623", WORLD_SIZE="2",
+               LOCAL_RANK="0")
+    args = [sys.executable, os.path.join(root, "train_vpd_model.py"), "diving48", "--save_dir", out, "--flow_img", "flow",
+            "--synthetic", "64", "--num_epochs", "2", "--batch_size", "16", "--motion", "--encoder_arch", "resnet18"]
+    procs = [subprocess.Popen(args, env=dict(env, RANK=str(r)), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert os.path.exists(os.path.join(out, "epoch0002.encoder.pt")) and os.path.exists(os.path.join(out, "epoch0002.decoder.pt"))

@@ -153,6 +153,14 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
         trainer.save_model(save_dir, 'epoch{:04d}'.format(epoch))
         print('Done!')
     if world > 1:
+        # replicas must hold identical weights (same initial broadcast, same summed gradients, same AdamW): verify
+        chk = torch.stack([encoder.engine.params.double().sum(), encoder.engine.params.double().square().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError('data-parallel replicas diverged: parameter checksums {} .. {}'.format(
+                lo.tolist(), hi.tolist()))
         torch.distributed.destroy_process_group()
 
 
