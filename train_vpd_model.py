@@ -158,7 +158,9 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
         lo, hi = chk.clone(), chk.clone()
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
+        # (a one-shot all-reduce may sum in a rank-dependent order: ulp-level drift is tolerated, a missed
+        # broadcast or a skipped bucket is not)
+        if bool(((hi - lo).abs() > 1e-4 * hi.abs().clamp_min(1e-30)).any()):
             raise RuntimeError('data-parallel replicas diverged: parameter checksums {} .. {}'.format(
                 lo.tolist(), hi.tolist()))
         torch.distributed.destroy_process_group()
