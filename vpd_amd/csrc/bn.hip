@@ -194,8 +194,76 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolParams p) 
         }
     }
 }
+// The same for a horizontal PAIR of outputs per thread (even Wo): their windows share a column, so 15 z pixels are
+// loaded -- all up front, independent of each other -- instead of 2 x 9 behind boundary tests.
+__global__ __launch_bounds__(256) void stem_pool_pair_kernel(const StemPoolParams p) {
+    const int cv = p.C >> 3;
+    const int Ho = p.Ho, Wo = p.Wo, Wk = p.Wo >> 1;
+    const long total = (long)p.N * Ho * Wk * cv;
+    const int c = (int)(threadIdx.x % cv) << 3;            // blockDim is a multiple of cv: fixed per thread
+    float sc[8], sh[8];
+    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(p.scale + c);
+    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(p.scale + c + 4);
+    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + c);
+    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(p.shift + c + 4);
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        long t = it / cv;
+        const int kx = (int)(t % Wk); t /= Wk;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        uint4 zr[3][5];
+        bool ok[3][5];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int y = 2 * oy - 1 + r, x = 4 * kx - 1 + q;
+                ok[r][q] = y >= 0 && y < p.Hz && x >= 0 && x < p.Wz;
+                const int yc = y < 0 ? 0 : (y >= p.Hz ? p.Hz - 1 : y), xc = x < 0 ? 0 : (x >= p.Wz ? p.Wz - 1 : x);
+                zr[r][q] = *reinterpret_cast<const uint4*>(p.z + ((size_t)(b * p.Hz + yc) * p.Wz + xc) * p.C + c);
+            }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float best[8];
+            int bi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) {
+                    if (!ok[r][2 * o + tt]) continue;
+                    float v[8];
+                    unpack8(zr[r][2 * o + tt], v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float a = v[j] * sc[j] + sh[j];
+                        a = a > 0.f ? a : 0.f;
+                        a = bf2f(f2bf(a));
+                        if (a > best[j]) { best[j] = a; bi[j] = r * 3 + tt; }
+                    }
+                }
+            const int ox = 2 * kx + o;
+            const size_t oo = ((size_t)(b * (Ho + 2 * p.opad) + oy + p.opad) * (Wo + 2 * p.opad) + ox + p.opad) * p.C + c;
+            *reinterpret_cast<uint4*>(p.out + oo) = pack8(best);
+            if (p.idx) {
+                uint2 iv;
+                iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+                iv.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+                *reinterpret_cast<uint2*>(p.idx + ((size_t)(b * Ho + oy) * Wo + ox) * p.C + c) = iv;
+            }
+        }
+    }
+}
 hipError_t vpd_launch_stem_pool(const StemPoolParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(ew_grid((long)p.N * p.Ho * p.Wo * (p.C / 8))), dim3(256), 0, s, p);
+    static const bool pair = !(getenv("VPD_STEM_PAIR") && !atoi(getenv("VPD_STEM_PAIR")));
+    const int cv = p.C / 8;
+    if (pair && !(p.Wo & 1) && 256 % cv == 0) {
+        // the grid-stride loop must keep a thread's channel slice fixed: total stride a multiple of cv (256 is)
+        hipLaunchKernelGGL(stem_pool_pair_kernel, dim3(ew_grid((long)p.N * p.Ho * (p.Wo / 2) * cv)), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(ew_grid((long)p.N * p.Ho * p.Wo * cv)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -452,6 +520,85 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_kernel(const StemPoolBwdPar
     }
 }
 
+// Pass 2 of the stem backward over 2x2 blocks of z pixels (even Hz, Wz; 3x3 stride-2 pad-1 pooling, Ho = Hz/2):
+// the block (2ky..2ky+1, 2kx..2kx+1) lies in the windows (ky..ky+1, kx..kx+1) only, so a thread loads four windows
+// (dpool + arg-max bytes) and four z pixels ONCE -- all eight loads independent -- instead of the 9 window visits a
+// pixel-at-a-time pass makes for the same four pixels, each behind its own z load.
+__global__ __launch_bounds__(256) void stem_pool_bwd_quad_kernel(const StemPoolBwdParams p, long items) {
+    const int cv = p.C >> 3;
+    const int c8 = threadIdx.x % cv;
+    const int c = c8 << 3;
+    const int per = 256 / cv;                       // items per block iteration
+    const int Hk = p.Hz >> 1, Wk = p.Wz >> 1;
+    float mu[8], rs[8], sc[8], shf[8], c1[8], c2[8], c3[8];
+#define LD8(dst, src) \
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
+    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+    LD8(mu, p.mean + c) LD8(rs, p.rstd + c) LD8(sc, p.scale + c) LD8(shf, p.shift + c)
+    LD8(c1, p.coef + c) LD8(c2, p.coef + p.C + c) LD8(c3, p.coef + 2 * p.C + c)
+#undef LD8
+    for (long it = (long)blockIdx.x * per + threadIdx.x / cv; it < items; it += (long)gridDim.x * per) {
+        const int kx = (int)(it % Wk);
+        const long q = it / Wk;
+        const int ky = (int)(q % Hk);
+        const int b = (int)(q / Hk);
+        // windows w[wy][wx] = (ky + wy, kx + wx); the far ones may fall off the pooled map
+        uint4 dw[2][2];
+        uint2 iw[2][2];
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = ky + wy, ox = kx + wx;
+                dw[wy][wx] = uint4{0u, 0u, 0u, 0u};
+                iw[wy][wx] = uint2{0xffffffffu, 0xffffffffu};                 // matches no tap
+                if (oy < p.Ho && ox < p.Wo) {
+                    const size_t po = ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.C + c;
+                    dw[wy][wx] = *reinterpret_cast<const uint4*>(p.dpool + po);
+                    iw[wy][wx] = *reinterpret_cast<const uint2*>(p.idx + po);
+                }
+            }
+        uint4 zr[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                zr[dy][dx] = *reinterpret_cast<const uint4*>(
+                    p.z + ((size_t)(b * p.Hz + 2 * ky + dy) * p.Wz + 2 * kx + dx) * p.C + c);
+        float d[2][2][8];
+#pragma unroll
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) unpack8(dw[wy][wx], d[wy][wx]);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float z[8], o[8];
+                unpack8(zr[dy][dx], z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float g = 0.f;
+                    // pixel row 2ky+dy is tap row dy+1 of window row ky and, for dy = 1, tap row 0 of window row ky+1
+#pragma unroll
+                    for (int wy = 0; wy <= dy; ++wy)
+#pragma unroll
+                        for (int wx = 0; wx <= dx; ++wx) {
+                            const unsigned want = (unsigned)((dy + 1 - 2 * wy) * 3 + (dx + 1 - 2 * wx));
+                            const unsigned word = j < 4 ? iw[wy][wx].x : iw[wy][wx].y;
+                            const unsigned sel = (word >> (8 * (j & 3))) & 0xffu;
+                            g += sel == want ? d[wy][wx][j] : 0.f;
+                        }
+                    const float a = z[j] * sc[j] + shf[j];
+                    g = a > 0.f ? g : 0.f;
+                    const float xh = (z[j] - mu[j]) * rs[j];
+                    o[j] = c1[j] * (g - c2[j] - xh * c3[j]);
+                }
+                *reinterpret_cast<uint4*>(p.dz + ((size_t)(b * p.Hz + 2 * ky + dy) * p.Wz + 2 * kx + dx) * p.C + c) = pack8(o);
+            }
+    }
+}
+
 // BatchNorm-backward sums of the stem from the pooled side.  The gradient of a pooling window goes to its arg-max pixel
 // only, and survives the ReLU iff the pooled value is positive; there a = gamma * xhat + beta, so
 //   sum g = sum_windows d [a > 0],   sum g * xhat = sum_windows d [a > 0] (a - beta) / gamma
@@ -529,6 +676,15 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
                        VPD_STAT_ROWS, p.C, count,
                        gamma, p.rstd, dgamma, dbeta, coef);
     p.pass = 2;
-    hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
+    static const bool quad = !(getenv("VPD_STEM_QUAD") && !atoi(getenv("VPD_STEM_QUAD")));
+    if (quad && !(p.Hz & 1) && !(p.Wz & 1) && p.Ho == p.Hz / 2 && p.Wo == p.Wz / 2) {
+        const int per = 256 / (p.C / 8);
+        const long items = (long)(p.M / (p.Hz * p.Wz)) * (p.Hz / 2) * (p.Wz / 2);
+        long blocks = (items + per - 1) / per;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(stem_pool_bwd_quad_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3(256), 0, s, p, items);
+    } else {
+        hipLaunchKernelGGL(stem_pool_bwd_kernel, dim3(T), dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
