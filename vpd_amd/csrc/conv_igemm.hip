@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     // parity class of a merged stride-2 data gradient (blockIdx.z); class 0 lives in the top-level fields
     ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     TapSet taps = p.taps;
-    switch (blockIdx.z) {
+    // heaviest class first: the classes come in ascending tap count (1, 2, 2, 4 taps for a 3x3 kernel) and blocks are
+    // dispatched z-slowest, so walking them backwards keeps the 4-tap blocks out of the tail of the launch
+    switch ((int)gridDim.z - 1 - (int)blockIdx.z) {
         case 1: geo = p.cls[0].geo; taps = p.cls[0].taps; break;
         case 2: geo = p.cls[1].geo; taps = p.cls[1].taps; break;
         case 3: geo = p.cls[2].geo; taps = p.cls[2].taps; break;
