@@ -7,7 +7,10 @@ Workload (BASELINE.json configs[1]): ResNet-34 student, 5-channel 128x128 crops 
 emb_dim 128, batch 256 per GPU, bf16 operands / fp32 accumulation, weak scaling over GPUs.
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches this file under torch.distributed.run (one rank per GPU).
+One rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank; started
+from a bare shell with --gpus N > 1 it spawns the N ranks itself (before anything touches the GPU) and relays rank 0's
+line.  W warm-up steps, then `--repeats` timed regions of EXACTLY K steps each, every one bracketed by barrier +
+synchronize with the MAX over ranks; the reported value is the MEDIAN region, all of them are listed.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -26,6 +29,7 @@ import torch
 ARCH, C_IN, EMB_DIM, HW, BATCH_PER_GPU = "resnet34", 5, 128, 128, 256
 # algorithmic work per crop: fwd + dgrad (no stem dgrad) + wgrad
 TRAIN_FLOP_PER_CROP = {("resnet34", 5): 7203061760, ("resnet34", 3): 7100301312, ("resnet18", 5): 3579183104}
+FWD_FLOP_PER_CROP = 2443837440               # ResNet-34, 5x128x128, D=128
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md
 DIVING48_MEAN_STD = ((0.3411329922282787, 0.46349889258964044, 0.5162481674015696),
                      (0.16302619019820488, 0.17092395707914718, 0.19266662199338647))
@@ -102,28 +106,87 @@ def cpu_baseline(sample_batch=32, budget_s=20.0, max_steps=40):
                       "%d schedulable cores, warm-up %.1f s)" % (steps, sample_batch, dt, cores, warm)}
 
 
+def spawn_ranks(n, argv):
+    """--gpus N from a bare shell: start the N ranks as CHILD processes (this parent never initialises the GPU, and
+    nothing is exec'ed from a process that has), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    ngpu = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    procs = []
+    for r in range(n):
+        # fewer devices than ranks (a 1-GPU box driving the 2-rank path over gloo): ranks share device r % ngpu
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r % max(ngpu, 1)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode(errors="replace")
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
+
+
+def apply_block(enc, device, batches=12, warmup=3):
+    """Inference twin (BASELINE configs[4]): 1,000-crop batches (500 frames x 2 views, apply_vpd_model.py:15) of the
+    eval forward as ONE hipGraph launch per batch, inputs resident; the timed region is `batches` launches."""
+    frames, k = 500, 2
+    n = frames * k
+    eng = enc.engine
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn((n, C_IN, HW, HW), generator=g, device=device)
+    out = torch.empty((n, EMB_DIM), dtype=torch.float32, device=device)
+    enc.eval()
+    pl = eng.capture_eval_graph(x, out)
+    for _ in range(warmup):
+        eng.launch_eval_graph(pl, n)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        eng.launch_eval_graph(pl, n)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    enc.train()
+    return {"tflops": batches * n / dt * FWD_FLOP_PER_CROP / 1e12,
+            "frac_of_mfma_peak": batches * n / dt * FWD_FLOP_PER_CROP / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
+            "workload": "configs[4]-shaped: %d hipGraph launches of %d frames x %d views (1000 crops), eval forward, "
+                        "inputs resident" % (batches, frames, k),
+            "value": batches * n / dt, "unit": "crops/s", "ms_per_batch": 1e3 * dt / batches,
+            "finite": bool(torch.isfinite(out).all())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="crops per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-apply", action="store_true", help="skip the inference-twin block")
     ap.add_argument("--arch", default=ARCH, help="student architecture (default: the BASELINE config, resnet34)")
     ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("VPD_DIST_BACKEND", "nccl")      # "nccl" is RCCL; gloo only for single-GPU dry runs of this path
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("RCCL needs one GPU per rank (%d visible, %d ranks); VPD_DIST_BACKEND=gloo runs the ranks "
+                             "on shared devices" % (torch.cuda.device_count(), world))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -161,16 +224,20 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    region_s = []
+    for _ in range(max(args.repeats, 1)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        region_s.append(dt)
+    dt = sorted(region_s)[len(region_s) // 2]            # median timed region of exactly --steps steps
     loss_now = float(eng.loss_step.item())
 
     # ---- instrumented steps for the roofline: EVERY rank runs them (they contain the gradient all-reduce; a rank that
@@ -202,6 +269,8 @@ def main():
         if not kernels:      # --profile-steps 0 (used under rocprofv3): no event timing, no roofline object
             kernels = {"(not timed)": {"ms_per_step": 0.0, "tflops": 0.0}}
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        mat_ms = sum(v["ms"] for v in cls.values()) / max(args.profile_steps, 1)
+        mat_flops = sum(v["flops"] for v in cls.values()) / max(args.profile_steps, 1)
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
@@ -216,6 +285,10 @@ def main():
                     "frac": kernels[dom]["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note,
                     "whole_step_frac": value / world * flop / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12),
+                    # FLOP-weighted over ALL matrix-kernel classes (= their FLOPs / their summed time); `frac` above
+                    # is the single class that takes the most time
+                    "matrix_kernels_frac": (mat_flops / (mat_ms * 1e-3) / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS) if mat_ms > 0 else None,
+                    "matrix_kernels_ms_per_step": mat_ms,
                     "kernels": kernels,
                     "note": "per-class HIP-event timing from %d instrumented steps run right after the timed region: the "
                             "start/stop events ride in each kernel's own dispatch packet (hipExtLaunchKernelGGL), so the "
@@ -223,12 +296,15 @@ def main():
                             "launch (all 3x3 stride-1 convs of one ResNet stage) is timed without its slab reduce" % args.profile_steps}
         out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+               "repeats": {"n": len(region_s), "pick": "median", "crops_per_s": [args.batch * world * args.steps / t for t in region_s]},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "configs[1]: Diving48-shaped synthetic crops 128x128, %s student (5-ch RGB+flow), " % ("ResNet-34" if args.arch == ARCH else args.arch) +
                                       "emb_dim 128, sum-MSE + AdamW, batch=%d per GPU" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "flop_per_crop": flop, "loss_last_step": loss_now},
                "roofline": roofline}
+        if world == 1 and not args.no_apply and args.arch == ARCH:
+            out["apply"] = apply_block(enc, device)
         if world == 1 and not args.no_cpu_baseline and args.arch == ARCH:
             out["cpu_baseline"] = cpu_baseline()
     if world > 1:

@@ -85,7 +85,10 @@ int vpd_forward_eval(vpd_plan_t* plan, const float* params, const float* x, int 
 /* Train-mode forward + loss: encoder(img) -> [fcn_time] -> F.mse_loss(reduction='sum')
  * (train_vpd_model.py:83-88) with train-mode BatchNorm (batch statistics, running-stat
  * update momentum 0.1).  target: f32 [N][emb_dim or 2*emb_dim].  loss_step[0] = this
- * batch's sum-MSE; loss_accum[0] += it (the epoch accumulator of :93 kept on device). */
+ * batch's sum-MSE; loss_accum[0] += it (the epoch accumulator of :93 kept on device).
+ * n == 0 is legal (a data-parallel rank whose shard of a ragged last batch is empty): loss_step[0] = 0, nothing else
+ * is touched; the matching vpd_backward(n = 0) zeroes `grads` and records every bucket event, so the rank still joins
+ * the gradient all-reduce with zeros. */
 int vpd_forward_train(vpd_plan_t* plan, const float* params, float* bn_running, const float* x,
                       const float* target, int n, float* emb_out, float* loss_step, double* loss_accum,
                       void* workspace, void* stream);

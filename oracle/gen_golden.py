@@ -162,6 +162,8 @@ CASES = [
     # Bottleneck students (row f2)
     ("r50_c5_d32_m0_n8", "resnet50", 5, 32, False, 8, 128, 5e-4),
     ("wr50_c3_d32_m1_n6", "wide_resnet50_2", 3, 32, True, 6, 128, 5e-4),
+    # BASELINE configs[2]: --motion two-stream, 6-channel input (SURVEY 8d runs C=6 in addition to C=5)
+    ("r34_c6_d128_m1_n6", "resnet34", 6, 128, True, 6, 128, 5e-4),
 ]
 TAP_BNS = ["resnet.bn1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1",
            "resnet.layer3.1.bn2", "resnet.layer4.1.bn2"]
@@ -175,7 +177,25 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
     tgt = O.synthetic_targets(N, D, motion, seed + 2)
 
     def build():
-        enc = ref_rgb.RGBF_EmbeddingModel(arch, D, c_in == 5, "cpu")
+        if c_in in (3, 5):
+            enc = ref_rgb.RGBF_EmbeddingModel(arch, D, c_in == 5, "cpu")
+        else:
+            # the reference hard-codes 5 input channels (models/rgb.py:21, :25): build its 3-channel student and swap the
+            # stem by add_flow_to_model's own recipe with c_in in place of 5 -- channel mean of the 3-channel kernel
+            # expanded (the weights are overwritten by the procedural state_dict anyway; the modules that run are the
+            # reference's).  embed()'s channel assert (models/rgb.py:79-82) only knows 3 / 5: use_flow=True + patched check.
+            enc = ref_rgb.RGBF_EmbeddingModel(arch, D, False, "cpu")
+            old = enc.resnet.conv1
+            new = nn.Conv2d(c_in, old.out_channels, old.kernel_size, old.stride, old.padding, bias=False)
+            new.weight.data = old.weight.data.mean(dim=1, keepdim=True).expand(
+                old.weight.shape[:1] + (c_in,) + old.weight.shape[2:]).contiguous()
+            enc.resnet.conv1 = new
+
+            def embed_any(x, enc=enc):
+                enc.eval()
+                with torch.no_grad():
+                    return enc(torch.as_tensor(x, dtype=torch.float32)).cpu().numpy()
+            enc.embed = embed_any
         enc.load_state_dict(enc_sd)
         tr = ref_train.ModelTrainer(enc, motion)
         if motion:
@@ -245,6 +265,34 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
         traj.append(float(tr.epoch([{"img": img, "emb": tgt}], optimizer=optimizer, scaler=scaler)))
     out["epoch_traj"] = np.asarray(traj, np.float64)
     return out
+
+
+def init_case(ref):
+    """Rows a3 / a4: statistics of FRESHLY CONSTRUCTED reference models (models/rgb.py:8-43 add_flow_to_model /
+    replace_last_layer on top of models/module.py:71-76) and of the motion head FCNet (models/module.py:133-156), so that
+    the product's reset_parameters() is pinned to what the reference's constructors produce."""
+    ref_module, ref_rgb, _, _, _, _ = ref
+    res = {}
+    for tag, arch, c_in, D in (("r34_c5_d128", "resnet34", 5, 128), ("r18_c3_d32", "resnet18", 3, 32),
+                               ("r50_c5_d32", "resnet50", 5, 32)):
+        torch.manual_seed(1234)
+        m = ref_rgb.RGBF_EmbeddingModel(arch, D, c_in == 5, "cpu")
+        rows = {}
+        for k, v in m.state_dict().items():
+            v64 = v.double()
+            rows[k] = dict(shape=list(v.shape), dtype=str(v.dtype), mean=float(v64.mean()), std=float(v64.std()) if v.numel() > 1 else 0.0,
+                           min=float(v64.min()), max=float(v64.max()))
+        w = m.state_dict()["resnet.conv1.weight"]
+        rows["__stem__"] = dict(slices_identical=bool((w == w[:, :1]).all()), c_in=int(w.shape[1]),
+                                kaiming_std_3ch=float(np.sqrt(2.0 / (64 * 49))))
+        fc = m.state_dict()["resnet.fc.weight"]
+        rows["__fc__"] = dict(in_features=int(fc.shape[1]), bound=float(1.0 / np.sqrt(fc.shape[1])))
+        res[tag] = rows
+    torch.manual_seed(4321)
+    fcn = ref_module.FCNet(128, [128, 128], 256, dropout=0)
+    res["fcnet_d128"] = {k: dict(shape=list(v.shape), mean=float(v.double().mean()), std=float(v.double().std()),
+                                 min=float(v.min()), max=float(v.max())) for k, v in fcn.state_dict().items()}
+    return res
 
 
 def adamw_case(ref):
@@ -333,6 +381,10 @@ def main():
         out = run_case(ref, *case, seed=100 + 10 * i)
         np.savez_compressed(os.path.join(OUT, case[0] + ".npz"), **out)
         print("wrote", case[0], "loss", float(out["loss_train"]), "traj", out["epoch_traj"])
+    if not only or "init" in only.split(","):
+        with open(os.path.join(OUT, "init_stats.json"), "w") as fp:
+            json.dump(init_case(ref), fp, indent=0, sort_keys=True)
+        print("wrote init_stats.json")
     if not only:
         np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
         np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))

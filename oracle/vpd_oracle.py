@@ -149,7 +149,7 @@ def reference_init_state_dict(arch: str, c_in: int, emb_dim: int, seed: int):
         if kind == "conv":
             co, ci, kh, kw = shape
             std = math.sqrt(2.0 / (co * kh * kw))
-            if key == "resnet.conv1.weight" and c_in == 5:
+            if key == "resnet.conv1.weight" and c_in != 3:      # add_flow_to_model: channel mean expanded (5; 6 = configs[2])
                 w3 = torch.randn((co, 3, kh, kw), generator=g) * std
                 sd[key] = w3.mean(dim=1, keepdim=True).expand(shape).contiguous()
             else:
@@ -161,7 +161,7 @@ def reference_init_state_dict(arch: str, c_in: int, emb_dim: int, seed: int):
         elif kind == "bn_nbt":
             sd[key] = torch.zeros((), dtype=torch.int64)
         else:
-            fan_in = 512
+            fan_in = 512 * arch_expansion(arch)      # fc.in_features (models/module.py:69): 2048 for Bottleneck students
             bound = 1.0 / math.sqrt(fan_in)
             sd[key] = (torch.rand(shape, generator=g) * 2 - 1) * bound
     return sd
@@ -202,6 +202,24 @@ class _RoundBf16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g.bfloat16().float()
+
+
+class _ScaleGrad(torch.autograd.Function):
+    """Identity forward, gradient scaled by `s`: a deliberately WRONG backward, used only by the tests that prove the
+    gradient gates would notice an orchestration error of that size (GRAD_FAULT below)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+# test hook: {"resnet.layerL.B": scale} multiplies the gradient flowing through that block's identity path
+GRAD_FAULT: Dict[str, float] = {}
 
 
 def _rb(x, on):
@@ -248,6 +266,8 @@ def encoder_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, arch: str,
                 idn = _bn(sd, p + ".downsample.1", idn, train, taps)
             else:
                 idn = h
+            if p in GRAD_FAULT:
+                idn = _ScaleGrad.apply(idn, GRAD_FAULT[p])
             h = _rb(F.relu(o + idn), q)
     h = h.mean(dim=(2, 3))                     # AdaptiveAvgPool2d((1,1)) + flatten
     return F.linear(h, sd["resnet.fc.weight"], sd["resnet.fc.bias"])
@@ -268,7 +288,16 @@ def sum_mse(e: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 
 def embed(sd, x, arch: str, use_flow: bool) -> np.ndarray:
     """models/rgb.py:72-86: ndarray/tensor in, 3-D promoted, channel assert,
-    eval-mode, numpy f32 out."""
+    eval-mode, numpy f32 out.  use_flow may be an int: the explicit input-channel count of the 6-channel variant
+    (BASELINE configs[2]; the reference hard-codes 5)."""
+    if not isinstance(use_flow, bool) and isinstance(use_flow, int):
+        if not isinstance(x, torch.Tensor):
+            x = torch.tensor(np.asarray(x), dtype=torch.float32)
+        if x.dim() == 3:
+            x = x.unsqueeze(0)
+        assert x.shape[1] == use_flow, "Wrong number of channels"
+        with torch.no_grad():
+            return encoder_forward(sd, x.float(), arch, train=False).numpy()
     if not isinstance(x, torch.Tensor):
         x = torch.tensor(np.asarray(x), dtype=torch.float32)
     if x.dim() == 3:

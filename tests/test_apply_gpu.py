@@ -90,3 +90,31 @@ def test_train_cli_synthetic_writes_reference_files(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(REPO, "train_vpd_model.py"), "diving48", "--save_dir", str(save),
                         "--synthetic", "8", "--num_epochs", "1"], cwd=REPO, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "FileExistsError" in r.stderr
+
+
+def test_train_cli_default_flags_run_the_reference_recipe_on_the_device(tmp_path, monkeypatch):
+    """with the reference's own flags (no extra switch) every train AND val batch goes through the device
+    input pipeline (vpd_plan_stage_crops: ColorJitter, mask noise, RandomResizedCrop, flip), as the reference's datasets
+    always augment (vpd_dataset/common.py:85-92, single_frame.py:267-272); --no_augment is the only opt-out."""
+    import train_vpd_model
+    from vpd_amd.engine import StudentEngine
+    calls = {"stage": 0, "train": 0, "eval": 0}
+    orig = StudentEngine.stage_crops
+
+    def counting(self, *a, **k):
+        calls["stage"] += 1
+        calls["train" if a[9] else "eval"] += 1
+        return orig(self, *a, **k)
+    monkeypatch.setattr(StudentEngine, "stage_crops", counting)
+    monkeypatch.setattr(sys, "argv", ["train_vpd_model.py", "diving48", "--save_dir", str(tmp_path / "a"), "--num_epochs", "1",
+                                      "--batch_size", "8", "--flow_img", "flow", "--encoder_arch", "resnet18",
+                                      "--img_dim", "64", "--synthetic", "24", "--synthetic_emb_dim", "16"])
+    train_vpd_model.main(**vars(train_vpd_model.get_args()))
+    assert calls["train"] == 3 and calls["eval"] == 1 and calls["stage"] == 4, calls
+    cfg = json.load(open(tmp_path / "a" / "config.json"))
+    assert cfg["augment"].startswith("device") and cfg["use_flow"] is True
+    calls.update(stage=0, train=0, eval=0)
+    monkeypatch.setattr(sys, "argv", sys.argv[:3] + [str(tmp_path / "b")] + sys.argv[4:] + ["--no_augment"])
+    train_vpd_model.main(**vars(train_vpd_model.get_args()))
+    assert calls["stage"] == 0
+    assert json.load(open(tmp_path / "b" / "config.json"))["augment"].startswith("cpu")

@@ -28,15 +28,42 @@ def test_param_struct_layout_matches_header():
         assert getattr(S, f).offset == A.AUG_DTYPE.fields[f][1]
 
 
-def test_sample_params_same_draws_as_oracle():
-    g1, g2 = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
-    p = A.sample_params(40, 128, 128, generator=g1)
-    for k in range(40):
-        o = AO.sample_item_params(128, 128, g2)
-        assert list(p['order'][k]) == o['order']
-        np.testing.assert_allclose(p['factor'][k], np.float32(o['factors']), rtol=0, atol=0)
-        assert bool(p['flip'][k]) == o['flip'] and bool(p['noise'][k]) == o['noise']
-        assert tuple(p['crop'][k]) == tuple(o['crop'])
+def test_sample_params_same_distribution_as_oracle():
+    """The product sampler is vectorised (batched draws), the oracle restates torchvision's per-item get_params loops:
+    different streams, same distributions -- compared on 4000 draws each (two-sample bounds far above sampling noise)."""
+    n = 4000
+    p = A.sample_params(n, 128, 128, generator=torch.Generator().manual_seed(11))
+    g2 = torch.Generator().manual_seed(12)
+    o = [AO.sample_item_params(128, 128, g2) for _ in range(n)]
+    # ColorJitter: every one of the 24 op orders with frequency 1/24, factors uniform in their ranges
+    perm_p = np.unique(p['order'], axis=0, return_counts=True)[1] / n
+    perm_o = np.unique(np.array([x['order'] for x in o]), axis=0, return_counts=True)[1] / n
+    assert len(perm_p) == 24 and len(perm_o) == 24
+    assert np.abs(perm_p - 1 / 24).max() < 0.015 and np.abs(perm_o - 1 / 24).max() < 0.015
+    fo = np.array([x['factors'] for x in o], dtype=np.float64)
+    fp = p['factor'].astype(np.float64)
+    for k, width in enumerate((0.4, 0.4, 0.1, 0.1)):
+        assert abs(fp[:, k].mean() - fo[:, k].mean()) < 0.03 * width
+        assert abs(fp[:, k].std() - width / np.sqrt(12)) < 0.03 * width and abs(fo[:, k].std() - width / np.sqrt(12)) < 0.03 * width
+    assert abs(p['flip'].mean() - np.mean([x['flip'] for x in o])) < 0.04
+    assert abs(p['noise'].mean() - np.mean([x['noise'] for x in o])) < 0.04
+    # RandomResizedCrop windows: same mean / spread of height, width, area and of the offsets relative to their range
+    co = np.array([x['crop'] for x in o], dtype=np.float64)
+    cp = p['crop'].astype(np.float64)
+    for k in (2, 3):
+        assert abs(cp[:, k].mean() - co[:, k].mean()) < 0.6 and abs(cp[:, k].std() - co[:, k].std()) < 0.6
+    assert abs((cp[:, 2] * cp[:, 3]).mean() - (co[:, 2] * co[:, 3]).mean()) < 0.01 * 128 * 128
+    rel = lambda c: np.stack([c[:, 0] / np.maximum(128 - c[:, 2], 1), c[:, 1] / np.maximum(128 - c[:, 3], 1)], 1)
+    m = (cp[:, 2] < 120) & (cp[:, 3] < 120)
+    mo = (co[:, 2] < 120) & (co[:, 3] < 120)
+    assert np.abs(rel(cp)[m].mean(0) - rel(co)[mo].mean(0)).max() < 0.03
+    # a fresh noise key per call unless one is given (ADVICE r1: the same key every batch repeats the noise pattern)
+    a = A.sample_params(4, 64, 64, generator=torch.Generator().manual_seed(1))
+    g = torch.Generator().manual_seed(1)
+    b1, b2 = A.sample_params(4, 64, 64, generator=g), A.sample_params(4, 64, 64, generator=g)
+    assert tuple(a['seed'][0]) == tuple(b1['seed'][0]) and tuple(b1['seed'][0]) != tuple(b2['seed'][0])
+    assert (b1['seed'] == b1['seed'][0]).all()
+    assert tuple(A.sample_params(2, 64, 64, seed=(5 << 32) | 7)['seed'][1]) == (7, 5)
 
 
 def test_sample_params_ranges():

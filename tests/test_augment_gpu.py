@@ -156,3 +156,32 @@ def test_trainer_epoch_on_raw_u8_batches():
     opt, scaler = tr.get_optimizer(5e-4)
     la = tr.epoch(DataLoader(SyntheticCrops(24, 5, 64, 32, False, MEAN_STD, seed=3, raw_u8=True), batch_size=8), opt, scaler)
     assert math.isfinite(la) and abs(la - losses[1][0]) > 1e-3 * losses[1][0]
+
+
+def test_trainer_draws_a_fresh_noise_key_per_batch():
+    """the device mask noise is keyed by a per-BATCH Philox key; the trainer must draw a new one for every
+    batch (the same key made every step of every epoch add the same noise pattern to a batch slot)."""
+    from vpd_amd.augment import CropAugmenter
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    n, h = 4, 64
+    rgb, flow, _, _ = _crops(n, h, h, seed=5)
+    mask = torch.full((n, h, h), 255, dtype=torch.uint8)
+    enc = RGBF_EmbeddingModel("resnet18", 16, True, "cuda")
+    aug = CropAugmenter(enc.device, MEAN_STD, h, True)
+    tr = ModelTrainer(enc, False, augmenter=aug)
+    batch = {"rgb_u8": rgb, "flow_u8": flow, "mask_u8": mask, "emb": torch.zeros(n, 16)}
+    keys, staged = [], []
+    for _ in range(3):
+        tr._forward_loss_raw(batch, train=False)
+        keys.append(tuple(int(v) for v in tr.last_aug_params["seed"][0]))
+        assert (tr.last_aug_params["seed"] == tr.last_aug_params["seed"][0]).all()
+    assert len(set(keys)) == 3, keys
+    # and the key reaches the device: identical decisions + different keys -> different noise on the noisy crops
+    p = tr.last_aug_params.copy()
+    p["noise"] = 1
+    a = aug(rgb.cuda(), flow.cuda(), mask.cuda(), p).clone()
+    p2 = p.copy()
+    p2["seed"] = (p["seed"][0][0] ^ 1, p["seed"][0][1])
+    b = aug(rgb.cuda(), flow.cuda(), mask.cuda(), p2)
+    assert float((a[:, :3] - b[:, :3]).abs().max()) > 0.05 and torch.equal(a[:, 3:], b[:, 3:])

@@ -28,19 +28,19 @@ def _flat_grads(orc, img, tgt, names):
     return torch.cat([grads[k].reshape(-1) for k in names]), loss
 
 
-def _setup():
+def _setup(n=N):
     enc = O.procedural_state_dict(O.encoder_schema(ARCH, C_IN, D), 3)
-    img = O.synthetic_crops(N, C_IN, HW, 4)
-    tgt = O.synthetic_targets(N, D, False, 5)
+    img = O.synthetic_crops(n, C_IN, HW, 4)
+    tgt = O.synthetic_targets(n, D, False, 5)
     return enc, img, tgt
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N=N):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    enc, img, tgt = _setup()
+    enc, img, tgt = _setup(N)
     orc = O.StudentOracle(ARCH, C_IN, D, False, enc)
     names = list(orc.params().keys())
     sl = shard_slice(N, rank, world)
@@ -66,12 +66,15 @@ def test_shard_sizes():
     assert (s[0].start, s[0].stop, s[1].start, s[1].stop) == (0, 4, 4, 7)
 
 
-def test_bucketed_sum_all_reduce_world2():
+@pytest.mark.parametrize("N", [7, 1], ids=["ragged_4_3", "rank1_empty"])
+def test_bucketed_sum_all_reduce_world2(N):
+    """N = 1: the last batch of an epoch leaves rank 1 without a crop; it still joins every bucket's all-reduce with
+    zero gradients and the loss / count all-reduce with (0, 0)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + N
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, N)) for r in range(world)]
     for p in procs:
         p.start()
     got, stats = q.get(timeout=240)
@@ -79,7 +82,7 @@ def test_bucketed_sum_all_reduce_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     # single-process emulation: BN per shard, gradients summed, loss summed
-    enc, img, tgt = _setup()
+    enc, img, tgt = _setup(N)
     exp = None
     loss_sum = 0.0
     for r in range(world):

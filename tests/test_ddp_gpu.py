@@ -47,6 +47,58 @@ def test_bucket_reducer_world1_matches_plain_run():
         dist.destroy_process_group()
 
 
+def _rank_main_ragged(rank, world, port, q):
+    """An epoch whose last batch leaves rank 1 without crops: batches of 6 (3 + 3) and 1 (1 + 0) crops."""
+    import torch.distributed as dist
+    from vpd_amd.ddp import shard_slice
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        sd = O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 2)
+        img = O.synthetic_crops(7, 5, 64, 3)
+        tgt = O.synthetic_targets(7, 32, False, 4)
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+        enc.load_state_dict(sd)
+        tr = ModelTrainer(enc, False, process_group=dist.group.WORLD)
+        opt, sc = tr.get_optimizer(5e-4)
+        batches = []
+        for lo, hi in ((0, 6), (6, 7)):
+            sl = shard_slice(hi - lo, rank, world)
+            batches.append({"img": img[lo:hi][sl], "emb": tgt[lo:hi][sl]})
+        assert batches[1]["img"].shape[0] == (1 if rank == 0 else 0)
+        ep = tr.epoch(batches, optimizer=opt, scaler=sc)
+        torch.cuda.synchronize()
+        q.put((rank, enc.engine.grads.clone().cpu().numpy(), ep, enc.engine.params.clone().cpu().numpy(),
+               int(enc.engine.num_batches_tracked[0].item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero_crop_rank_joins_the_collective():
+    """a rank with an empty shard of the ragged last batch still takes part in the step: vpd_forward_train /
+    vpd_backward accept n = 0 (zero loss, zero gradients, bucket events recorded), both ranks end the epoch with the
+    SAME gradients (rank 0's, since rank 1 added zeros), the same weights and the same epoch value over 7 crops."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main_ragged, args=(r, 2, 29571, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, ep0, w0, nbt0), (_, g1, ep1, w1, nbt1) = res
+    assert np.array_equal(g0, g1) and np.isfinite(g0).all() and np.abs(g0).max() > 0
+    assert ep0 == ep1 and np.isfinite(ep0)
+    assert np.allclose(w0, w1, rtol=0, atol=1e-7)
+    assert (nbt0, nbt1) == (2, 1)               # the empty batch is not a BatchNorm step on rank 1
+
+
 def _rank_main(rank, world, port, q):
     import torch.distributed as dist
     from vpd_amd.ddp import shard_slice
@@ -135,3 +187,29 @@ def test_train_cli_two_ranks_keep_identical_replicas(tmp_path):
     outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert os.path.exists(os.path.join(out, "epoch0002.encoder.pt")) and os.path.exists(os.path.join(out, "epoch0002.decoder.pt"))
+
+
+def test_bench_self_launches_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no torchrun environment spawns its own ranks (before anything
+    touches the GPU) and rank 0 prints the one JSON line.  On this 1-GPU box the ranks share the device and exchange
+    the gradient buckets over gloo; on an 8-GPU node the same command runs RCCL (backend "nccl")."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VPD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--repeats", "2", "--batch", "16", "--profile-steps", "1", "--no-cpu-baseline", "--no-apply"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak"
+    assert out["steps"] == 3 and out["repeats"]["n"] == 2 and out["value"] > 0 and np.isfinite(out["config"]["loss_last_step"])
+    # a failing rank fails the launcher
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--arch", "no_such_arch", "--no-cpu-baseline", "--no-apply"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0

@@ -85,6 +85,112 @@ def test_train_step_is_permutation_invariant():
     assert abs(host - l0) <= 1e-4 * l0, (host, l0)
 
 
+# ---------------------------------------------------------------------------
+# BASELINE configs[2] / configs[3] at their per-GPU size: --motion two-stream head, 512 crops per GPU,
+# figure-skating-shaped crops (RGB_MEAN_STD['fs']), and the ragged final batch of a 4096-crop global batch on 8 GPUs
+# (3616 = 8 x 452) against the SAME plan
+# ---------------------------------------------------------------------------
+B4, RAGGED = 512, 452
+
+
+def _fs_batch(n, seed, motion=True):
+    from vpd_amd.data import RGB_MEAN_STD
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    rgb = torch.randint(0, 256, (n, 3, HW, HW), generator=g, device="cuda").float() / 255.0
+    mean = torch.tensor(RGB_MEAN_STD["fs"][0], device="cuda").view(1, 3, 1, 1)
+    std = torch.tensor(RGB_MEAN_STD["fs"][1], device="cuda").view(1, 3, 1, 1)
+    flow = (124 + 12 * torch.randn((n, 2, HW, HW), generator=g, device="cuda")).round().clamp(0, 255) / 255.0 - 0.5
+    img = torch.cat([(rgb - mean) / std, flow], dim=1).contiguous()
+    t = torch.randn((n, D), generator=g, device="cuda")
+    tgt = torch.cat([t, t - torch.randn((n, D), generator=g, device="cuda")], dim=1).contiguous() if motion else t
+    return img, tgt
+
+
+def test_c3_c4_shape_512_crops_motion_fs_and_ragged_452():
+    from vpd_amd.trainer import ModelTrainer
+    img, tgt = _fs_batch(B4, 11)
+    # --- eval forward: per-crop, so the 512-crop batch == its 256 + 256 split == the hipGraph launch, bit for bit;
+    #     the ragged 452-crop batch through the same (512-crop) plan == the first 452 rows
+    enc = _model()
+    eng = enc.engine
+    enc.eval()
+    full = eng.forward_eval(img).clone()
+    halves = torch.cat([eng.forward_eval(img[:256].contiguous()).clone(), eng.forward_eval(img[256:].contiguous()).clone()])
+    assert torch.equal(full, halves)
+    rag = eng.forward_eval(img[:RAGGED].contiguous()).clone()
+    assert torch.equal(rag, full[:RAGGED])
+    out = torch.empty_like(full)
+    pl = eng.capture_eval_graph(img, out)
+    eng.launch_eval_graph(pl, B4)
+    torch.cuda.synchronize()
+    assert torch.equal(out, full) and torch.isfinite(full).all()
+    del enc, eng, pl
+    # --- train step with the motion head: permutation invariance at 512 and at the ragged 452 (same plan: the
+    #     second call reuses the 512-crop workspace), device loss == host sum over crops of |pred - target|^2
+    perm = {n: torch.randperm(n, generator=torch.Generator().manual_seed(3 + n)).cuda() for n in (B4, RAGGED)}
+    for n in (B4, RAGGED):
+        res = []
+        for p in (None, perm[n]):
+            enc = _model(damp_residual=True)
+            tr = ModelTrainer(enc, True)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                for q in tr.fcn_time.parameters():               # same motion head in both runs
+                    q.copy_(torch.randn(q.shape, generator=torch.Generator().manual_seed(q.numel())).to(q.device) * 0.05)
+            enc.train()
+            enc.engine.plan(HW, HW, B4, True, True)              # the 512-crop plan serves the ragged batch too
+            x, t = img[:n], tgt[:n]
+            x, t = (x.contiguous(), t.contiguous()) if p is None else (x[p].contiguous(), t[p].contiguous())
+            emb = enc.engine.forward_train(x, t, motion=True, accumulate_loss=False).clone()
+            loss = float(enc.engine.loss_step.item())
+            enc.engine.backward()
+            torch.cuda.synchronize()
+            assert enc.engine._step_plan.max_batch == B4
+            res.append((emb, loss, enc.engine.grads.clone(), tr))
+        (e0, l0, g0, tr0), (e1, l1, g1, _) = res
+        assert abs(l0 - l1) <= 2e-3 * l0, (n, l0, l1)
+        rel_e = float((e1 - e0[perm[n]]).norm() / e0.norm())
+        rel_g = float((g1 - g0).norm() / g0.norm())
+        assert rel_e <= 1e-2 and rel_g <= 0.1, (n, rel_e, rel_g)
+        assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+        with torch.no_grad():                                    # FCNet D->128->128->2D (models/module.py:139-156)
+            w = tr0.fcn_time.state_dict()
+            lin = torch.nn.functional.linear
+            pred = lin(torch.relu(lin(torch.relu(lin(e0, w["layers.0.weight"], w["layers.0.bias"])),
+                                      w["layers.2.weight"], w["layers.2.bias"])), w["layers.5.weight"], w["layers.5.bias"])
+        host = float(((pred.double() - tgt[:n].double()) ** 2).sum())
+        assert abs(host - l0) <= 2e-3 * l0, (n, host, l0)
+
+
+def test_c5_shape_1000_crop_graph_batch_equals_eager():
+    """apply_vpd_model.py's batch (BATCH_SIZE 500 frames x 2 views = 1000 crops, apply_vpd_model.py:15) as ONE hipGraph
+    launch: bit-identical to the eager eval forward of the same batch and to ten 100-crop calls; the tail batch of a
+    1 M-crop run (fewer frames) gets its own graph on the same plan."""
+    enc = _model()
+    eng = enc.engine
+    enc.eval()
+    n = 1000
+    g = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.randn((n, C_IN, HW, HW), generator=g, device="cuda")
+    eager = eng.forward_eval(img).clone()
+    out = torch.empty_like(eager)
+    pl = eng.capture_eval_graph(img, out)
+    eng.launch_eval_graph(pl, n)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager) and torch.isfinite(out).all()
+    parts = torch.cat([eng.forward_eval(img[i:i + 100].contiguous()).clone() for i in range(0, n, 100)])
+    assert torch.equal(parts, eager)
+    tail = 2 * 157                                              # a Diving48-sized last video (SURVEY 8d)
+    out_t = torch.empty((tail, D), dtype=torch.float32, device="cuda")
+    xt = img[:tail].contiguous()
+    pl2 = eng.capture_eval_graph(xt, out_t)
+    eng.launch_eval_graph(pl2, tail)
+    out.zero_()
+    eng.launch_eval_graph(pl, n)                                # both graphs stay valid side by side
+    torch.cuda.synchronize()
+    assert pl2 is pl and torch.equal(out_t, eager[:tail]) and torch.equal(out, eager)
+
+
 def test_fused_adamw_full_buffer_matches_torch():
     enc = _model()
     eng = enc.engine

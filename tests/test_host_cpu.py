@@ -113,6 +113,32 @@ def test_teacher_dataset_contract(tmp_path):
     assert item["img"].shape == (5, 32, 32) and item["img"].dtype == torch.float32
     assert item["emb"].shape == (16,) and item["emb"].dtype == torch.float32
     assert float(item["img"][3:].abs().max()) <= 0.5
+    # a teacher pickle without any pose score cannot be filtered: NotImplementedError, as vpd_dataset/single_frame.py:44
+    with open(emb_dir / "bad.emb.pkl", "wb") as fp:
+        pickle.dump([(1, rs.randn(2, 8).astype(np.float32), {})], fp)
+    with pytest.raises(NotImplementedError):
+        TeacherEmbDataset.load_default(str(emb_dir), str(img_dir), 32, False, 50, RGB_MEAN_STD["diving48"])
+
+
+def test_split_is_shared_across_ranks_when_seeded(tmp_path):
+    """Data-parallel runs give every rank the same split seed (train_vpd_model.py broadcasts rank 0's): identical
+    train / val frame sets whatever the directory listing order; 20 % (ceil, as sklearn's train_test_split) validate."""
+    from vpd_amd.data import RGB_MEAN_STD, TeacherEmbDataset
+    emb_dir = tmp_path / "embs"
+    emb_dir.mkdir()
+    rs = np.random.RandomState(1)
+    for v in range(3):
+        embs = [(f, rs.randn(8).astype(np.float32), {"kp_score": 0.9}) for f in range(7)]
+        with open(emb_dir / ("v%d.emb.pkl" % v), "wb") as fp:
+            pickle.dump(embs, fp)
+    load = lambda seed: TeacherEmbDataset.load_default(str(emb_dir), "/nonexistent", 32, False, 100,
+                                                       RGB_MEAN_STD["fs"], split_seed=seed)
+    key = lambda ds: [x[:2] for x in ds.data]
+    (t0, v0, _), (t1, v1, _), (t2, v2, _) = load(1234), load(1234), load(99)
+    assert key(t0) == key(t1) and key(v0) == key(v1)
+    assert key(v0) != key(v2)
+    assert len(v0.data) == 5 and len(t0.data) == 16            # ceil(0.2 * 21)
+    assert not set(key(t0)) & set(key(v0))
 
 
 def test_synthetic_dataset_is_seeded_and_in_range():

@@ -67,7 +67,8 @@ def build(meta):
     dec_sd = O.procedural_state_dict(O.decoder_schema(meta["emb_dim"]), meta["seed"] + 7) if meta["motion"] else None
     img = O.synthetic_crops(meta["n"], meta["c_in"], meta["hw"], meta["seed"] + 1)
     tgt = O.synthetic_targets(meta["n"], meta["emb_dim"], meta["motion"], meta["seed"] + 2)
-    enc = RGBF_EmbeddingModel(meta["arch"], meta["emb_dim"], meta["c_in"] == 5, "cuda")
+    enc = RGBF_EmbeddingModel(meta["arch"], meta["emb_dim"], meta["c_in"] != 3, "cuda",
+                              in_channels=None if meta["c_in"] in (3, 5) else meta["c_in"])
     enc.load_state_dict(enc_sd)
     tr = ModelTrainer(enc, meta["motion"])
     if meta["motion"]:
@@ -231,6 +232,125 @@ def test_backward_in_a_well_conditioned_regime(arch):
         acc[key][0] += float((gh * r).sum()); acc[key][1] += float((r * r).sum()); acc[key][2] += float((gh * gh).sum())
     res = {k: (round(v[0] / (v[1] * v[2]) ** 0.5, 3), round(v[0] / v[1], 3)) for k, v in acc.items()}      # (cos, projection)
     assert all(c >= 0.93 and 0.9 <= b <= 1.1 for c, b in res.values()), res
+
+
+def test_reset_parameters_matches_reference_init_statistics():
+    """Rows a3 / a4: the PRODUCT's initialisation (RGBF_EmbeddingModel.reset_parameters, FCNet) against
+    statistics of freshly constructed reference models (tests/golden/init_stats.json from oracle/gen_golden.py;
+    reference models/rgb.py:8-43, models/module.py:71-76, :139-150): per-tensor kaiming std, the identical stem slices
+    of add_flow_to_model, nn.Linear bounds of replace_last_layer / FCNet, BN tensors and buffers exactly."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    ref = json.load(open(os.path.join(GOLDEN, "init_stats.json")))
+    for tag, (arch, c_in, D) in {"r34_c5_d128": ("resnet34", 5, 128), "r18_c3_d32": ("resnet18", 3, 32),
+                                 "r50_c5_d32": ("resnet50", 5, 32)}.items():
+        rows = ref[tag]
+        torch.manual_seed(99)
+        enc = RGBF_EmbeddingModel(arch, D, c_in == 5, "cuda")      # the constructor initialises (no explicit reset)
+        sd = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+        assert list(sd.keys()) == [k for k in O.encoder_schema(arch, c_in, D).keys()]
+        assert set(sd.keys()) == {k for k in rows if not k.startswith("__")}
+        for k, v in sd.items():
+            r = rows[k]
+            kind = O.encoder_schema(arch, c_in, D)[k][1]
+            assert list(v.shape) == r["shape"] and str(v.dtype) == r["dtype"], (tag, k)
+            if kind == "conv":
+                n = v.numel() // (c_in if (k == "resnet.conv1.weight" and c_in != 3) else 1)
+                assert abs(float(v.double().std()) / r["std"] - 1) < 10.0 / (2 * n) ** 0.5 + 0.02, (tag, k)
+                assert abs(float(v.double().mean()) - r["mean"]) < 6 * r["std"] / n ** 0.5, (tag, k)
+            elif kind.startswith("bn"):
+                assert float(v.double().min()) == r["min"] and float(v.double().max()) == r["max"], (tag, k)
+            else:
+                b = rows["__fc__"]["bound"]
+                assert float(v.min()) >= -b and float(v.max()) <= b, (tag, k)
+                if v.numel() >= 4096:
+                    assert float(v.max()) > 0.9 * b and abs(float(v.double().std()) / r["std"] - 1) < 0.05, (tag, k)
+        w = sd["resnet.conv1.weight"]
+        if c_in != 3:
+            assert rows["__stem__"]["slices_identical"] and bool((w == w[:, :1]).all())
+            assert abs(float(w.double().std()) / rows["resnet.conv1.weight"]["std"] - 1) < 0.1
+    enc = RGBF_EmbeddingModel("resnet18", 128, True, "cuda")
+    tr = ModelTrainer(enc, True)
+    fr = ref["fcnet_d128"]
+    dsd = {k: v.detach().cpu() for k, v in tr.fcn_time.state_dict().items()}
+    assert list(dsd.keys()) == list(O.decoder_schema(128).keys()) and set(dsd.keys()) == set(fr.keys())
+    for k, v in dsd.items():
+        fan_in = v.shape[1] if v.dim() == 2 else {"layers.0.bias": 128, "layers.2.bias": 128, "layers.5.bias": 128}[k]
+        b = 1.0 / fan_in ** 0.5
+        assert list(v.shape) == fr[k]["shape"] and float(v.min()) >= -b and float(v.max()) <= b
+        assert fr[k]["min"] >= -b and fr[k]["max"] <= b
+        if v.numel() >= 4096:
+            assert abs(float(v.double().std()) / fr[k]["std"] - 1) < 0.05, k
+    # 6-channel variant (BASELINE configs[2]): the same stem recipe with 6 slices
+    enc6 = RGBF_EmbeddingModel("resnet18", 32, True, "cuda", in_channels=6)
+    w6 = enc6.state_dict()["resnet.conv1.weight"].cpu()
+    assert tuple(w6.shape) == (64, 6, 7, 7) and bool((w6 == w6[:, :1]).all())
+    with pytest.raises(AssertionError):
+        enc6.embed(np.zeros((1, 5, 64, 64), np.float32))
+    assert enc6.embed(np.zeros((6, 64, 64), np.float32)).shape == (1, 32)
+
+
+def _group_of(name):
+    return "fc" if ".fc." in name else (name.split(".")[1] if name.split(".")[1].startswith("layer") else "stem")
+
+
+def _group_metrics(get_a, get_b, names):
+    """per network stage: (rel-L2 of a against b, cosine) over the concatenated tensors of the stage"""
+    acc = {}
+    for name in names:
+        a, b = get_a(name).double().flatten(), get_b(name).double().flatten()
+        v = acc.setdefault(_group_of(name), [0.0, 0.0, 0.0, 0.0])
+        v[0] += float(((a - b) ** 2).sum()); v[1] += float((b * b).sum()); v[2] += float((a * b).sum()); v[3] += float((a * a).sum())
+    return {k: ((v[0] / v[1]) ** 0.5, v[2] / (v[1] * v[3]) ** 0.5) for k, v in acc.items()}
+
+
+# HIP gradient against the bf16 EMULATION (same algorithm, same rounding points, CPU) in the damped regime: the
+# two differ only by summation order inside fp32 accumulators and the rounding flips that causes
+DIRECT_TOL = {"fc": 0.02, "layer4": 0.03, "layer3": 0.04, "layer2": 0.05, "layer1": 0.06, "stem": 0.08}
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet34"])
+def test_backward_matches_bf16_emulation_directly(arch):
+    """gate the HIP gradients DIRECTLY against the oracle's emulate_bf16 gradients (not error magnitudes
+    against each other), stage by stage, in the well-conditioned regime -- and prove the gate's resolution: the same
+    comparison applied to an emulation whose layer2.1 identity-path gradient is scaled by 1.05 (a 5 % orchestration
+    error in one residual path) must come out RED for the stages upstream of the fault."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    sd = O.reference_init_state_dict(arch, 5, 32, 3)
+    for k in sd:
+        if k.endswith(".bn2.weight"):
+            sd[k] = sd[k] * 0.1
+    enc = RGBF_EmbeddingModel(arch, 32, True, "cuda")
+    enc.load_state_dict(sd)
+    tr = ModelTrainer(enc, False)
+    img, tgt = O.synthetic_crops(8, 5, 128, 5), O.synthetic_targets(8, 32, False, 6)
+    enc.train()
+    loss = tr._forward_loss(img, tgt, train=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [n for n, _ in enc.named_parameters()]
+    g_hip = {n: p.grad.detach().cpu() for n, p in enc.named_parameters()}
+    emu = O.StudentOracle(arch, 5, 32, False, sd, None)
+    _, _, _, g_emu = emu.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
+    direct = _group_metrics(lambda n: g_hip[n], lambda n: g_emu["enc." + n], names)
+    # the faulty emulation: identical except for the 1.05 on one residual path
+    O.GRAD_FAULT["resnet.layer2.1"] = 1.05
+    try:
+        bad = O.StudentOracle(arch, 5, 32, False, sd, None)
+        _, _, _, g_bad = bad.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
+    finally:
+        O.GRAD_FAULT.clear()
+    fault = _group_metrics(lambda n: g_bad["enc." + n], lambda n: g_emu["enc." + n], names)
+    rec = {"arch": arch, "hip_vs_emulation": {k: [round(x, 5) for x in v] for k, v in direct.items()},
+           "faulty_emulation_vs_emulation": {k: [round(x, 5) for x in v] for k, v in fault.items()}}
+    _dump("direct_%s" % arch, rec)
+    print(rec)
+    for k, (err, cos) in direct.items():
+        assert err <= DIRECT_TOL[k] and cos >= 1 - DIRECT_TOL[k], (k, err, cos, rec)
+    # resolution of the gate: the 5 % fault is caught (a gradient projection off by the fault's size upstream of it)
+    red = [k for k, (err, cos) in fault.items() if err > DIRECT_TOL[k]]
+    assert red, rec
 
 
 @pytest.mark.parametrize("motion", [False, True])

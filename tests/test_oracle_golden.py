@@ -40,7 +40,7 @@ def test_oracle_matches_reference(path):
 
     # eval-mode embed() and eval epoch value
     st, img, tgt = build(meta)
-    e = O.embed(st.enc, img.numpy(), meta["arch"], meta["c_in"] == 5)
+    e = O.embed(st.enc, img.numpy(), meta["arch"], meta["c_in"] == 5 if meta["c_in"] in (3, 5) else meta["c_in"])
     assert e.dtype == np.float32 and e.shape == g["emb_eval"].shape
     assert rel_l2(e, g["emb_eval"]) < 1e-5
     assert abs(st.epoch([{"img": img, "emb": tgt}], train=False) - float(g["epoch_eval"])) < 1e-4 * abs(float(g["epoch_eval"]))
@@ -114,6 +114,44 @@ def test_state_dict_schema_matches_reference():
     ours = [(k, list(s), "torch.float32") for k, (s, _) in O.decoder_schema(128).items()]
     assert ours == by_model["fcnet d128"]
     assert len(O.encoder_schema("resnet34", 5, 128)) == 218
+
+
+def test_reference_init_statistics():
+    """Rows a3 / a4: the oracle's reference_init_state_dict against statistics of freshly constructed reference models
+    (tests/golden/init_stats.json, written by oracle/gen_golden.py from models/rgb.py:8-43 + models/module.py:71-76).
+    Random tensors are compared through what is deterministic about them: the std of a kaiming-normal sample of n
+    elements (relative sampling error 1/sqrt(2n)), uniform bounds, the stem's identical slices; BN tensors exactly."""
+    ref = json.load(open(os.path.join(GOLDEN, "init_stats.json")))
+    for tag, (arch, c_in, D) in {"r34_c5_d128": ("resnet34", 5, 128), "r18_c3_d32": ("resnet18", 3, 32),
+                                 "r50_c5_d32": ("resnet50", 5, 32)}.items():
+        rows = ref[tag]
+        sd = O.reference_init_state_dict(arch, c_in, D, 7)
+        assert [k for k in rows if not k.startswith("__")] == list(sd.keys()) or \
+            sorted(k for k in rows if not k.startswith("__")) == sorted(sd.keys())
+        for k, v in sd.items():
+            r = rows[k]
+            assert list(v.shape) == r["shape"]
+            kind = O.encoder_schema(arch, c_in, D)[k][1]
+            if kind == "conv":
+                n = v.numel() if not (k == "resnet.conv1.weight" and c_in != 3) else v.numel() // c_in
+                tol = 5.0 / np.sqrt(2 * n)
+                assert abs(float(v.double().std()) / r["std"] - 1) < 2 * tol + 0.02, (tag, k)
+                assert abs(float(v.double().mean()) - r["mean"]) < 6 * r["std"] / np.sqrt(n), (tag, k)
+            elif kind in ("bn_w", "bn_b", "bn_rm", "bn_rv", "bn_nbt"):
+                assert float(v.double().min()) == r["min"] and float(v.double().max()) == r["max"], (tag, k)
+            else:   # fc: U(-1/sqrt(in_features), +1/sqrt(in_features))
+                b = rows["__fc__"]["bound"]
+                assert abs(b - 1.0 / np.sqrt(512 * O.arch_expansion(arch))) < 1e-12
+                assert r["min"] >= -b and r["max"] <= b and float(v.min()) >= -b and float(v.max()) <= b
+                if v.numel() >= 4096:      # the bias has only D elements: bounds only
+                    assert float(v.max()) > 0.9 * b and r["max"] > 0.9 * b
+                    assert abs(float(v.double().std()) / (b / np.sqrt(3)) - 1) < 0.05 and abs(r["std"] / (b / np.sqrt(3)) - 1) < 0.05
+        w = sd["resnet.conv1.weight"]
+        assert rows["__stem__"]["c_in"] == c_in
+        if c_in != 3:      # add_flow_to_model: every input-channel slice is the mean of the 3-channel kernel
+            assert rows["__stem__"]["slices_identical"] and bool((w == w[:, :1]).all())
+            # mean over 3 iid channels: std shrinks by sqrt(3)
+            assert abs(rows["resnet.conv1.weight"]["std"] / (rows["__stem__"]["kaiming_std_3ch"] / np.sqrt(3)) - 1) < 0.05
 
 
 def test_embed_contract():

@@ -41,8 +41,11 @@ def get_args():
     parser.add_argument('--synthetic', type=int, help='train on N seeded synthetic crops per epoch')
     parser.add_argument('--synthetic_emb_dim', type=int, default=128)
     parser.add_argument('--gpu_augment', action='store_true',
-                        help='loaders hand over decoded u8 crops; ColorJitter / mask noise / RandomResizedCrop / '
-                             'normalisation run on the GPU (vpd_amd/augment.py) instead of flips-only on the CPU')
+                        help='(default behaviour, kept for compatibility) loaders hand over decoded u8 crops; ColorJitter / '
+                             'mask noise / RandomResizedCrop / normalisation run on the GPU (vpd_amd/augment.py)')
+    parser.add_argument('--no_augment', action='store_true',
+                        help='escape hatch: fp32 batches from the CPU loaders with h-flips only -- NOT the reference '
+                             'recipe, whose datasets always augment (vpd_dataset/common.py:85-92)')
     return parser.parse_args()
 
 
@@ -64,13 +67,35 @@ def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
 
 def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, motion, encoder_arch, save_dir,
          model_select_window, checkpoint_frequency, pretrained, emb_dir, penn_dir, no_test_video, min_pose_score,
-         synthetic=None, synthetic_emb_dim=128, gpu_augment=False):
+         synthetic=None, synthetic_emb_dim=128, gpu_augment=False, no_augment=False):
     device = 'cuda'
+    # The reference builds train AND val datasets with augment=True (vpd_dataset/single_frame.py:267-272,
+    # common.py:85-92): ColorJitter, mask noise, RandomResizedCrop and flips are part of the recipe, so they are the
+    # default here too and run on the device; --no_augment is the only way to switch them off.
+    gpu_augment = not no_augment
     rank, world = 0, 1
     if 'RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
         rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         torch.distributed.init_process_group(os.environ.get('VPD_DIST_BACKEND', 'nccl'))      # 'nccl' = RCCL
+    # save_dir must not exist (train_vpd_model.py:221).  Rank 0 creates it FIRST and tells the others, so that every
+    # rank leaves together instead of waiting in a collective for a rank that has raised
+    made = [None, int.from_bytes(os.urandom(4), 'little')]       # [makedirs error or None, split seed]
+    if rank == 0:
+        try:
+            os.makedirs(save_dir)
+        except OSError as e:
+            made[0] = repr(e)
+    split_seed = None
+    if world > 1:
+        # one train/val split for all ranks (the reference's train_test_split is unseeded, vpd_dataset/
+        # single_frame.py:263: a split per rank would train the shared weights on other ranks' validation frames)
+        torch.distributed.broadcast_object_list(made, src=0)
+        split_seed = made[1]
+    if made[0] is not None:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        raise FileExistsError('cannot create save_dir {!r}: {}'.format(save_dir, made[0]))
     rgb_mean_std = RGB_MEAN_STD['resnet' if pretrained else dataset]
 
     if synthetic is not None:
@@ -81,11 +106,12 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
         train_dataset, val_dataset = mk(synthetic, 1 + rank), mk(max(synthetic // 5, 1), 1001 + rank)
     else:
         dataset_kwargs = {'img_dim': img_dim, 'flow_img_name': flow_img, 'embed_time': motion,
-                          'rgb_mean_std': rgb_mean_std, 'target_len': 20000 // world}
+                          'rgb_mean_std': rgb_mean_std, 'target_len': 20000 // world, 'split_seed': split_seed}
         if min_pose_score is not None:
             dataset_kwargs['min_pose_score'] = min_pose_score
         train_dataset, val_dataset, emb_dim = load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video)
         train_dataset.raw_u8 = val_dataset.raw_u8 = gpu_augment
+        train_dataset.augment = val_dataset.augment = True      # flips stay on with --no_augment (the CPU float path)
 
     if rank == 0:
         print('Device:', device)
@@ -112,7 +138,7 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     if gpu_augment:
         from vpd_amd.augment import CropAugmenter
         augmenter = CropAugmenter(encoder.device, rgb_mean_std, img_dim, flow_img is not None)
-    trainer = ModelTrainer(encoder, motion, augmenter=augmenter)
+    trainer = ModelTrainer(encoder, motion, augmenter=augmenter, augment=True)
     if world > 1:      # same initial weights on every rank (after the trainer: the motion head is initialised there)
         torch.distributed.broadcast(encoder.engine.params, 0)
         torch.distributed.broadcast(encoder.engine.bn_running, 0)
@@ -120,12 +146,14 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     optimizer, scaler = trainer.get_optimizer(learning_rate)
 
     if rank == 0:
-        os.makedirs(save_dir)     # fails on an existing directory, as the reference (train_vpd_model.py:221)
         store_json(os.path.join(save_dir, 'config.json'), {
             'num_epochs': num_epochs, 'batch_size': batch_size, 'learning_rate': learning_rate, 'img_dim': img_dim,
             'use_flow': flow_img is not None, 'motion': motion,
             'embed_time': motion,      # apply_vpd_model.py:102 reads this key; the reference never writes it
-            'emb_dim': emb_dim, 'encoder_arch': encoder_arch, 'rgb_mean_std': rgb_mean_std})
+            'emb_dim': emb_dim, 'encoder_arch': encoder_arch, 'rgb_mean_std': rgb_mean_std,
+            # not in the reference: which input pipeline produced the loss curves
+            'augment': 'device: ColorJitter + mask noise + RandomResizedCrop + flip (reference recipe)' if gpu_augment
+                       else 'cpu: h-flip only (--no_augment)'})
 
     loss_file = os.path.join(save_dir, 'loss.json')
     losses = []

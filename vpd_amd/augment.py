@@ -42,53 +42,59 @@ def identity_params(n, height, width):
     return p
 
 
-def _uniform(lo, hi, g):
-    return float(torch.empty(1).uniform_(lo, hi, generator=g))
+def sample_params(n, height, width, augment=True, flip=True, generator=None, seed=None):
+    """Random decisions for n crops, drawn from torch's CPU RNG (`generator` or the global one) -- vectorised: a
+    handful of batched draws per call instead of ~10 one-element draws per crop, so that the host side keeps up with
+    the device (the per-crop loop capped the loop near 20 k crops/s).  Same distributions as torchvision's
+    ColorJitter.get_params / RandomResizedCrop.get_params (up to ten (area, log-ratio) tries, first valid one wins,
+    central fallback); the reference seeds nothing, so there is no stream to reproduce.
 
-
-def sample_params(n, height, width, augment=True, flip=True, generator=None, seed=0):
-    """Random decisions for n crops, drawn from torch's CPU RNG (`generator` or the global one)."""
+    seed: 64-bit Philox key of the device-side mask noise for this BATCH (the device counter is (pixel, batch slot)).
+    None draws a fresh key from the same RNG: two batches never share a noise pattern."""
     p = identity_params(n, height, width)
-    if not augment:
+    if not augment or n == 0:
         return p
     g = generator
+    rand = lambda *shape: torch.rand(shape, generator=g, dtype=torch.float64).numpy()
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=g, dtype=torch.int64))
+    if flip:
+        p['flip'] = torch.randint(0, 2, (n,), generator=g).numpy()
+    # ColorJitter.get_params: a uniformly random permutation of the four ops (argsort of iid uniforms), then b, c, s, h
+    p['order'] = np.argsort(rand(n, 4), axis=1).astype(np.int32)
+    u = rand(n, 4)
+    jk = JITTER_KWARGS
+    lo = np.array([1 - jk['brightness'], 1 - jk['contrast'], 1 - jk['saturation'], -jk['hue']])
+    hi = np.array([1 + jk['brightness'], 1 + jk['contrast'], 1 + jk['saturation'], jk['hue']])
+    p['factor'] = (lo + u * (hi - lo)).astype(np.float32)
+    p['noise'] = (rand(n) <= RANDOM_MASK_PROB).astype(np.int32)
+    # RandomResizedCrop.get_params: ten candidate (area, aspect) pairs per crop, the first that fits is taken
     area = height * width
-    log_ratio = (math.log(RRC_RATIO[0]), math.log(RRC_RATIO[1]))
-    for k in range(n):
-        if flip:
-            p['flip'][k] = int(torch.randint(0, 2, (1,), generator=g))
-        # ColorJitter.get_params
-        p['order'][k] = torch.randperm(4, generator=g).numpy()
-        p['factor'][k] = (_uniform(1 - JITTER_KWARGS['brightness'], 1 + JITTER_KWARGS['brightness'], g),
-                          _uniform(1 - JITTER_KWARGS['contrast'], 1 + JITTER_KWARGS['contrast'], g),
-                          _uniform(1 - JITTER_KWARGS['saturation'], 1 + JITTER_KWARGS['saturation'], g),
-                          _uniform(-JITTER_KWARGS['hue'], JITTER_KWARGS['hue'], g))
-        p['noise'][k] = int(float(torch.rand(1, generator=g)) <= RANDOM_MASK_PROB)
-        # RandomResizedCrop.get_params
-        crop = None
-        for _ in range(10):
-            target_area = area * _uniform(RRC_SCALE[0], RRC_SCALE[1], g)
-            aspect = math.exp(_uniform(log_ratio[0], log_ratio[1], g))
-            w = int(round(math.sqrt(target_area * aspect)))
-            h = int(round(math.sqrt(target_area / aspect)))
-            if 0 < w <= width and 0 < h <= height:
-                i = int(torch.randint(0, height - h + 1, size=(1,), generator=g))
-                j = int(torch.randint(0, width - w + 1, size=(1,), generator=g))
-                crop = (i, j, h, w)
-                break
-        if crop is None:                      # fallback: central crop at the nearest allowed ratio
-            in_ratio = float(width) / float(height)
-            if in_ratio < min(RRC_RATIO):
-                w = width
-                h = int(round(w / min(RRC_RATIO)))
-            elif in_ratio > max(RRC_RATIO):
-                h = height
-                w = int(round(h * max(RRC_RATIO)))
-            else:
-                w, h = width, height
-            crop = ((height - h) // 2, (width - w) // 2, h, w)
-        p['crop'][k] = crop
-        p['seed'][k] = (seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+    ta = area * (RRC_SCALE[0] + rand(n, 10) * (RRC_SCALE[1] - RRC_SCALE[0]))
+    lr0, lr1 = math.log(RRC_RATIO[0]), math.log(RRC_RATIO[1])
+    aspect = np.exp(lr0 + rand(n, 10) * (lr1 - lr0))
+    w = np.rint(np.sqrt(ta * aspect)).astype(np.int64)
+    h = np.rint(np.sqrt(ta / aspect)).astype(np.int64)
+    ok = (w > 0) & (w <= width) & (h > 0) & (h <= height)
+    first = np.argmax(ok, axis=1)
+    has = ok.any(axis=1)
+    rows = np.arange(n)
+    cw, ch = w[rows, first], h[rows, first]
+    # fallback: central crop at the nearest allowed ratio
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(RRC_RATIO):
+        fw, fh = width, int(round(width / min(RRC_RATIO)))
+    elif in_ratio > max(RRC_RATIO):
+        fh, fw = height, int(round(height * max(RRC_RATIO)))
+    else:
+        fw, fh = width, height
+    cw = np.where(has, cw, fw)
+    ch = np.where(has, ch, fh)
+    ui, uj = rand(n), rand(n)
+    ci = np.where(has, np.minimum((ui * (height - ch + 1)).astype(np.int64), height - ch), (height - ch) // 2)   # randint(0, H-h+1)
+    cj = np.where(has, np.minimum((uj * (width - cw + 1)).astype(np.int64), width - cw), (width - cw) // 2)
+    p['crop'] = np.stack([ci, cj, ch, cw], axis=1).astype(np.int32)
+    p['seed'] = (seed & 0xffffffff, (seed >> 32) & 0xffffffff)
     return p
 
 

@@ -716,10 +716,12 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
         if (_e != hipSuccess) return fail(#expr, _e);  \
     } while (0)
 
-int check_call(const vpd_plan* p, const void* ws, int n) {
+// min_n = 0 for the train-step entry points: a data-parallel rank whose shard of a ragged last batch is empty still
+// takes part in the step (zero loss, zero gradients, bucket events recorded) so that the collective stays matched
+int check_call(const vpd_plan* p, const void* ws, int n, int min_n = 1) {
     if (!p || !ws) return fail("null plan / workspace");
     if (p->bound_ws != ws) return fail("workspace not initialised with vpd_plan_init_workspace");
-    if (n < 1 || n > p->max_batch) return fail("batch size outside 1..max_batch");
+    if (n < min_n || n > p->max_batch) return fail(min_n ? "batch size outside 1..max_batch" : "batch size outside 0..max_batch");
     return 0;
 }
 
@@ -825,10 +827,14 @@ extern "C" int vpd_forward_eval(vpd_plan_t* p, const float* params, const float*
 extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_running, const float* x,
                                  const float* target, int n, float* emb_out, float* loss_step, double* loss_accum,
                                  void* workspace, void* stream) {
-    if (check_call(p, workspace, n)) return -1;
+    if (check_call(p, workspace, n, 0)) return -1;
     if (!p->train) return fail("plan was created with train=0");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
+    if (n == 0) {      // empty shard: no crops, no statistics update, zero loss (the running buffers stay as they are)
+        if (loss_step) HCHECK(hipMemsetAsync(loss_step, 0, sizeof(float), s));
+        return 0;
+    }
     Ctx c{p, ws, s, params, n};
     {
         ZeroRanges z;
@@ -889,10 +895,16 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
 
 extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, int n, void** bucket_events,
                             void* workspace, void* stream) {
-    if (check_call(p, workspace, n)) return -1;
+    if (check_call(p, workspace, n, 0)) return -1;
     if (!p->train) return fail("plan was created with train=0");
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
+    if (n == 0) {      // empty shard: the gradient of a sum over no crops is zero; every bucket is "ready" at once
+        HCHECK(hipMemsetAsync(grads, 0, (size_t)p->nparam_padded * sizeof(float), s));
+        for (int b = 0; b < 4; ++b)
+            if (bucket_events && bucket_events[b]) HCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
+        return 0;
+    }
     Ctx c{p, ws, s, params, n};
     // one launch zeroes the accumulator rows and every weight-gradient range the atomics kernel will add into
     ZeroRanges zr;

@@ -14,6 +14,7 @@
 
 PNG decoding uses PIL (cv2 is not in this image).
 """
+import math
 import os
 import random
 import re
@@ -64,13 +65,12 @@ def load_flow(path, img_dim):
 
 
 def _pose_score(meta):
-    """_get_pose_score (vpd_dataset/single_frame.py:33-44): dp_score, else kp_score; student pickles carry neither."""
-    if not isinstance(meta, dict):
-        return 1.
+    """_get_pose_score (vpd_dataset/single_frame.py:35-44): dp_score, else kp_score, else NotImplementedError -- a
+    teacher pickle without either score cannot be filtered (student pickles carry {} and are not training targets)."""
     for k in ('dp_score', 'kp_score'):
         if meta.get(k) is not None:
             return meta[k]
-    return 1.
+    raise NotImplementedError('teacher embedding meta has neither dp_score nor kp_score')
 
 
 class TeacherEmbDataset(torch.utils.data.Dataset):
@@ -123,7 +123,9 @@ class TeacherEmbDataset(torch.utils.data.Dataset):
 
     @staticmethod
     def load_default(emb_dir, img_dir, img_dim, embed_time, target_len, rgb_mean_std, flow_img_name=None,
-                     min_pose_score=None, exclude_prefixes=None):
+                     min_pose_score=None, exclude_prefixes=None, split_seed=None):
+        """split_seed: None = unseeded 80/20 split like the reference (vpd_dataset/single_frame.py:263); data-parallel
+        runs pass one seed to every rank so that all replicas train and validate on the same frames."""
         all_data, emb_dim = [], None
         thresh = DEFAULT_MIN_POSE_SCORE if min_pose_score is None else min_pose_score
         for emb_file in sorted(os.listdir(emb_dir)):
@@ -149,8 +151,9 @@ class TeacherEmbDataset(torch.utils.data.Dataset):
                                                 axis=0 if len(emb_target.shape) == 1 else 1)
                 all_data.append((video_name, frame_num, emb_target, emb_meta))
         print('Videos:', len({x[0] for x in all_data}))
-        random.shuffle(all_data)                     # unseeded 80/20 split, like train_test_split(test_size=0.2)
-        n_val = int(round(0.2 * len(all_data)))
+        all_data.sort(key=lambda x: x[:2])            # listing order must not matter for a seeded split
+        (random if split_seed is None else random.Random(split_seed)).shuffle(all_data)      # train_test_split(test_size=0.2)
+        n_val = int(math.ceil(0.2 * len(all_data)))   # sklearn: n_test = ceil(test_size * n)
         val_data, train_data = sorted(all_data[:n_val], key=lambda x: x[:2]), sorted(all_data[n_val:], key=lambda x: x[:2])
         mk = lambda d, n: TeacherEmbDataset(d, img_dir, img_dim, rgb_mean_std, n, flow_img_name=flow_img_name)
         return mk(train_data, target_len), mk(val_data, int(target_len * 0.2)), emb_dim
@@ -213,7 +216,7 @@ def color_jitter(img, brightness=0.2, contrast=0.2, saturation=0.05, hue=0.05):
 
 
 def load_tennis_default(emb_dir, img_dir, img_dim, embed_time, target_len, rgb_mean_std, flow_img_name=None,
-                        min_pose_score=None, exclude_prefixes=None):
+                        min_pose_score=None, exclude_prefixes=None, split_seed=None):
     """TennisDataset.load_default (vpd_dataset/single_frame.py:88-162): teacher pickles are named
     <player>__<video>_<start>_<end>.emb.pkl with clip-relative frame numbers, crops live in
     <img_dir>/<video>/<player>/<start + frame>.png, and the 80/20 split is over CLIPS, not frames."""
@@ -249,8 +252,8 @@ def load_tennis_default(emb_dir, img_dir, img_dim, embed_time, target_len, rgb_m
         return out
 
     print('Videos:', len(clips))
-    random.shuffle(clips)                            # unseeded, like train_test_split(videos, test_size=0.2)
-    n_val = int(round(0.2 * len(clips)))
+    (random if split_seed is None else random.Random(split_seed)).shuffle(clips)      # train_test_split(videos, test_size=0.2)
+    n_val = int(math.ceil(0.2 * len(clips)))         # sklearn: n_test = ceil(test_size * n)
     val, train = items(clips[:n_val]), items(clips[n_val:])
     key = lambda x: x[:2]
     mk = lambda d, n: TeacherEmbDataset(sorted(d, key=key), img_dir, img_dim, rgb_mean_std, n, flow_img_name=flow_img_name)

@@ -47,12 +47,17 @@ class GradBucketReducer:
         self.engine = engine
         self.group = group
         self.comm_stream = torch.cuda.Stream(device=engine.device)
-        self.events = [torch.cuda.Event() for _ in range(4)]
-        for e in self.events:           # materialise the hipEvent_t handles
-            e.record(torch.cuda.current_stream(engine.device))
+        self.events = []                # one per gradient bucket of the plan (vpd_plan_num_buckets), made on first use
 
-    def event_handles(self):
-        return [e.cuda_event for e in self.events]
+    def _ensure_events(self, n):
+        while len(self.events) < n:
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(self.engine.device))      # materialises the hipEvent_t handle
+            self.events.append(e)
+
+    def event_handles(self, nbuckets):
+        self._ensure_events(nbuckets)
+        return [e.cuda_event for e in self.events[:nbuckets]]
 
     def reduce(self, plan):
         cur = torch.cuda.current_stream(self.engine.device)
@@ -63,6 +68,7 @@ class GradBucketReducer:
             return
         works = []
         with torch.cuda.stream(self.comm_stream):
+            assert len(self.events) >= len(plan.buckets), "backward() was not given this plan's bucket events"
             for ev, (off, numel) in zip(self.events, plan.buckets):
                 self.comm_stream.wait_event(ev)
                 works += all_reduce_buckets(self.engine.grads, [(off, numel)], self.group, async_op=True)

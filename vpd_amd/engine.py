@@ -240,7 +240,8 @@ class StudentEngine:
         # BN running stats were rewritten by HIP kernels: packed eval scale/shift are stale
         self._hip_version += 1
         pl.packed_version = (self.params._version, self.bn_running._version, self._hip_version)
-        self.num_batches_tracked += 1
+        if n > 0:
+            self.num_batches_tracked += 1
         self._last = (pl, n) if target is not None else None
         return emb
 

@@ -14,7 +14,11 @@ from .module import ENCODER_ARCH, attach_views
 class RGBF_EmbeddingModel(nn.Module):
     """Basic embedding model with single frame features (HIP / MI355X)."""
 
-    def __init__(self, model_arch, emb_dim, use_flow, device, pretrained=False):
+    def __init__(self, model_arch, emb_dim, use_flow, device, pretrained=False, in_channels=None):
+        """Reference signature (models/rgb.py:49-50) + in_channels: an explicit input-channel count (1..8) for the
+        variants the reference's hard-coded 5 cannot express -- BASELINE configs[2] runs a 6-channel two-stream input.
+        The stem is then initialised by the same recipe as add_flow_to_model (models/rgb.py:19-23): the channel mean of
+        a 3-channel kaiming kernel expanded to in_channels."""
         super().__init__()
         if "effnet" in model_arch:
             raise NotImplementedError("EfficientNet students are out of scope (SURVEY.md 2.1 #3)")
@@ -27,6 +31,11 @@ class RGBF_EmbeddingModel(nn.Module):
         self.emb_dim = emb_dim
         self.model_arch = model_arch
         c_in = 5 if use_flow else 3
+        if in_channels is not None:
+            c_in = int(in_channels)
+            if not 1 <= c_in <= 8:
+                raise ValueError("in_channels must be in 1..8")
+        self.in_channels = c_in
         eng = StudentEngine(model_arch, c_in, emb_dim, device="cuda" if str(device) == "cuda" else device)
         self._engine_ref = [eng]
         attach_views(self, eng.enc_names, eng.view)
@@ -59,7 +68,7 @@ class RGBF_EmbeddingModel(nn.Module):
                 if kind == 0:
                     co, ci, kh, kw = p.shape
                     std = math.sqrt(2.0 / (co * kh * kw))
-                    if name == "resnet.conv1.weight" and self.use_flow:
+                    if name == "resnet.conv1.weight" and self.in_channels != 3:
                         w3 = torch.randn((co, 3, kh, kw), device=eng.device, generator=g) * std
                         p.copy_(w3.mean(dim=1, keepdim=True).expand_as(p))
                     else:
@@ -100,7 +109,9 @@ class RGBF_EmbeddingModel(nn.Module):
         if len(x.shape) == 3:
             x = x.unsqueeze(0)
 
-        if self.use_flow:
+        if self.in_channels not in (3, 5):
+            assert x.shape[1] == self.in_channels, 'Wrong number of channels'
+        elif self.use_flow:
             assert x.shape[1] == 5, 'Wrong number of channels for RGB + flow'
         else:
             assert x.shape[1] == 3, 'Wrong number of channels for RGB'

@@ -83,7 +83,9 @@ class ModelTrainer:
         n, h, w, _ = rgb.shape
         # like the reference validation batches are augmented too: augmentation is a property
         # of the dataset objects, which are all built with augment=True (vpd_dataset/single_frame.py:267-272)
+        # seed=None: a fresh Philox key for the device-side mask noise of THIS batch (drawn from torch's global RNG)
         params = sample_params(n, h, w, augment=self.augment, flip=False)
+        self.last_aug_params = params
         if 'flip' in batch:
             params['flip'] = batch['flip'].numpy() if hasattr(batch['flip'], 'numpy') else batch['flip']
         staged = self.augmenter.stage(eng, rgb, dev(batch.get('flow_u8')), dev(batch.get('mask_u8')), params,
@@ -98,7 +100,8 @@ class ModelTrainer:
     def _backward(self):
         eng = self.encoder.engine
         if self._reducer is not None:
-            pl = eng.backward(self._reducer.event_handles())
+            nb = len(eng._last[0].buckets) if eng._last is not None else 0      # (backward() raises without a forward)
+            pl = eng.backward(self._reducer.event_handles(nb))
             self._reducer.reduce(pl)
         else:
             eng.backward()
