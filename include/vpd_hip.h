@@ -150,6 +150,12 @@ int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x
                            void* workspace, void* stream);
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 
+/* The fused BatchNorm-backward launches synchronise their (fully resident) grid in the launch; every wait is bounded
+ * (1 s) and a time-out is counted in a sticky word of the workspace instead of hanging the GPU.  Copies that count to
+ * the host (synchronises `stream`); non-zero means the results of the step(s) since vpd_plan_init_workspace are not
+ * to be trusted.  No reference counterpart (torch launches one kernel per BatchNorm pass). */
+int vpd_plan_sync_errors(vpd_plan_t* plan, void* workspace, void* stream, unsigned* count_out);
+
 /* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
  * bracketed by HIP events on its own stream.  One class per kernel function: 0 conv3x3_c64_persistent_kernel<224>,
  * 1 conv3x3_ws_kernel<256,128,352>, 2 conv3x3_ws_kernel<128,128,288>, 3 conv3x3_ws_kernel<128,64,288>,

@@ -166,6 +166,7 @@ def test_trainer_draws_a_fresh_noise_key_per_batch():
     from vpd_amd.trainer import ModelTrainer
     n, h = 4, 64
     rgb, flow, _, _ = _crops(n, h, h, seed=5)
+    rgb, flow = torch.from_numpy(rgb), torch.from_numpy(flow)
     mask = torch.full((n, h, h), 255, dtype=torch.uint8)
     enc = RGBF_EmbeddingModel("resnet18", 16, True, "cuda")
     aug = CropAugmenter(enc.device, MEAN_STD, h, True)

@@ -295,26 +295,37 @@ def _group_of(name):
 
 
 def _group_metrics(get_a, get_b, names):
-    """per network stage: (rel-L2 of a against b, cosine) over the concatenated tensors of the stage"""
+    """per network stage over the concatenated tensors of the stage: (rel-L2 of a against b, cosine, projection
+    <a, b> / <b, b>)"""
     acc = {}
     for name in names:
         a, b = get_a(name).double().flatten(), get_b(name).double().flatten()
         v = acc.setdefault(_group_of(name), [0.0, 0.0, 0.0, 0.0])
         v[0] += float(((a - b) ** 2).sum()); v[1] += float((b * b).sum()); v[2] += float((a * b).sum()); v[3] += float((a * a).sum())
-    return {k: ((v[0] / v[1]) ** 0.5, v[2] / (v[1] * v[3]) ** 0.5) for k, v in acc.items()}
+    return {k: ((v[0] / v[1]) ** 0.5, v[2] / (v[1] * v[3]) ** 0.5, v[2] / v[1]) for k, v in acc.items()}
 
 
-# HIP gradient against the bf16 EMULATION (same algorithm, same rounding points, CPU) in the damped regime: the
-# two differ only by summation order inside fp32 accumulators and the rounding flips that causes
-DIRECT_TOL = {"fc": 0.02, "layer4": 0.03, "layer3": 0.04, "layer2": 0.05, "layer1": 0.06, "stem": 0.08}
+# Gate of test_backward_matches_bf16_emulation_directly: per stage, the PROJECTION of the HIP gradient on the emulation's
+# gradient must be 1 within PROJ_TOL and the cosine at least COS_MIN.
+PROJ_TOL, COS_MIN = 0.025, 0.985
 
 
 @pytest.mark.parametrize("arch", ["resnet18", "resnet34"])
 def test_backward_matches_bf16_emulation_directly(arch):
-    """gate the HIP gradients DIRECTLY against the oracle's emulate_bf16 gradients (not error magnitudes
-    against each other), stage by stage, in the well-conditioned regime -- and prove the gate's resolution: the same
-    comparison applied to an emulation whose layer2.1 identity-path gradient is scaled by 1.05 (a 5 % orchestration
-    error in one residual path) must come out RED for the stages upstream of the fault."""
+    """the HIP gradients DIRECTLY against the oracle's emulate_bf16 gradients (same algorithm, same
+    rounding points, on the CPU), stage by stage, in the well-conditioned regime, summed over three independent batches.
+
+    What can be gated.  Measured (profiles/r02_parity_direct.json): the two gradients differ by 0.07-0.14 rel-L2 per
+    stage at cos 0.990-0.997 -- NOT the 2e-2 one might expect from "same rounding points".  The fp32 accumulation order
+    differs between an MFMA tile loop and a CPU convolution, so ~1 % of the bf16-rounded activations differ by one ulp,
+    and every such flip re-draws the downstream rounding noise (the same chaos that separates either of them from fp32
+    by 0.1-0.2): HIP and the emulation are two SAMPLES of one noise distribution, not two computations of one number.
+    That noise is zero-mean and incoherent with the gradient, while an orchestration error (a residual path scaled
+    wrongly, a missing term) is a coherent bias; so the gate is on the projection <g_hip, g_emu> / |g_emu|^2 per stage,
+    in which the incoherent part averages out over 10^5-10^7 elements and three batches: it must be 1 +- 2.5 %.
+    Resolution of the gate, proven here: the same metric applied to an emulation whose layer2.1 identity-path
+    gradient is scaled by 1.05 (a 5 % error in ONE residual path) reads 1.044-1.050 on the stages upstream of the fault:
+    red."""
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
     from vpd_amd.trainer import ModelTrainer
     sd = O.reference_init_state_dict(arch, 5, 32, 3)
@@ -324,33 +335,41 @@ def test_backward_matches_bf16_emulation_directly(arch):
     enc = RGBF_EmbeddingModel(arch, 32, True, "cuda")
     enc.load_state_dict(sd)
     tr = ModelTrainer(enc, False)
-    img, tgt = O.synthetic_crops(8, 5, 128, 5), O.synthetic_targets(8, 32, False, 6)
-    enc.train()
-    loss = tr._forward_loss(img, tgt, train=True)
-    loss.backward()
-    torch.cuda.synchronize()
     names = [n for n, _ in enc.named_parameters()]
-    g_hip = {n: p.grad.detach().cpu() for n, p in enc.named_parameters()}
-    emu = O.StudentOracle(arch, 5, 32, False, sd, None)
-    _, _, _, g_emu = emu.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
-    direct = _group_metrics(lambda n: g_hip[n], lambda n: g_emu["enc." + n], names)
-    # the faulty emulation: identical except for the 1.05 on one residual path
-    O.GRAD_FAULT["resnet.layer2.1"] = 1.05
-    try:
-        bad = O.StudentOracle(arch, 5, 32, False, sd, None)
-        _, _, _, g_bad = bad.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
-    finally:
-        O.GRAD_FAULT.clear()
-    fault = _group_metrics(lambda n: g_bad["enc." + n], lambda n: g_emu["enc." + n], names)
-    rec = {"arch": arch, "hip_vs_emulation": {k: [round(x, 5) for x in v] for k, v in direct.items()},
+    g_hip = {n: 0.0 for n in names}
+    g_emu = {n: 0.0 for n in names}
+    g_bad = {n: 0.0 for n in names}
+    for b in range(3):
+        img, tgt = O.synthetic_crops(8, 5, 128, 5 + 10 * b), O.synthetic_targets(8, 32, False, 6 + 10 * b)
+        enc.load_state_dict(sd)                               # fresh running statistics: every batch from the same state
+        enc.train()
+        loss = tr._forward_loss(img, tgt, train=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        emu = O.StudentOracle(arch, 5, 32, False, sd, None)
+        _, _, _, ge = emu.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
+        O.GRAD_FAULT["resnet.layer2.1"] = 1.05              # the faulty emulation: identical except for one residual path
+        try:
+            bad = O.StudentOracle(arch, 5, 32, False, sd, None)
+            _, _, _, gb = bad.forward_loss(img, tgt, train=True, need_grad=True, emulate_bf16=True)
+        finally:
+            O.GRAD_FAULT.clear()
+        for n, p in enc.named_parameters():
+            g_hip[n] = g_hip[n] + p.grad.detach().cpu().double()
+            g_emu[n] = g_emu[n] + ge["enc." + n].double()
+            g_bad[n] = g_bad[n] + gb["enc." + n].double()
+    direct = _group_metrics(lambda n: g_hip[n], lambda n: g_emu[n], names)
+    fault = _group_metrics(lambda n: g_bad[n], lambda n: g_emu[n], names)
+    rec = {"arch": arch, "columns": ["rel_l2", "cos", "projection"],
+           "hip_vs_emulation": {k: [round(x, 5) for x in v] for k, v in direct.items()},
            "faulty_emulation_vs_emulation": {k: [round(x, 5) for x in v] for k, v in fault.items()}}
     _dump("direct_%s" % arch, rec)
     print(rec)
-    for k, (err, cos) in direct.items():
-        assert err <= DIRECT_TOL[k] and cos >= 1 - DIRECT_TOL[k], (k, err, cos, rec)
-    # resolution of the gate: the 5 % fault is caught (a gradient projection off by the fault's size upstream of it)
-    red = [k for k, (err, cos) in fault.items() if err > DIRECT_TOL[k]]
-    assert red, rec
+    for k, (err, cos, proj) in direct.items():
+        assert abs(proj - 1) <= PROJ_TOL and cos >= COS_MIN, (k, err, cos, proj, rec)
+    # resolution: the 5 % fault in one residual path is caught by the same gate
+    red = [k for k, (err, cos, proj) in fault.items() if abs(proj - 1) > PROJ_TOL]
+    assert {"stem", "layer1"} <= set(red), rec
 
 
 @pytest.mark.parametrize("motion", [False, True])

@@ -688,3 +688,314 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
     }
     return hipGetLastError();
 }
+
+// ===========================================================================
+// Fused BatchNorm passes (one launch per BatchNorm and direction instead of two / three).
+//
+// Forward:  bn_fwd_fused_kernel = finalize (per-channel sums -> mean, rstd, scale, shift, running statistics) + apply.
+//   The sums are complete when the kernel starts (the producing convolution is the previous launch), so every block
+//   finalizes the channels itself from the BatchNorm's OWN accumulator rows (VPD_FUSED_ROWS fp64 rows, 4x fewer than the
+//   shared rows of the separate finalize kernel: a block reads 2*C*4 doubles, <= 32 KB) into LDS; block 0 also stores
+//   mean / rstd / scale / shift for backward and updates the running statistics.  The residual of a down-sampling
+//   block (conv1x1 -> BN, res_kind 2) is finalized in the same prologue.
+// Backward: bn_bwd_fused_kernel = reduce (sum g, sum g*xhat) + finalize + apply in ONE launch with an in-launch grid
+//   barrier (sync.h).  One 1024-thread block per CU owns a contiguous pixel range; g = dy*[mask] (and z when it fits)
+//   stays in LDS across the barrier, so dy / z / act are read once instead of twice and two launches (~5 us of fixed
+//   cost each at these sizes) disappear.  Per-block partial sums are reduced in a fixed order and added with fp64
+//   atomics to the BatchNorm's own rows, as before: results do not depend on the arrival order beyond 1e-16.
+// ===========================================================================
+#include "sync.h"
+
+struct BnFusedFwdArgs {
+    double* rows; float count;                 // this BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][C]
+    const float* gamma; const float* beta; float* rm; float* rv;
+    float* mean; float* rstd; float* scale; float* shift;
+    // residual BatchNorm (res_kind 2) or rows2 == null
+    double* rows2; float count2;
+    const float* gamma2; const float* beta2; float* rm2; float* rv2;
+    float* mean2; float* rstd2; float* scale2; float* shift2;
+    float momentum, eps;
+};
+
+static __device__ __forceinline__ void bn_finalize_channel(const double* rows, int C, int ch, float count, float eps,
+                                                           float gamma, float beta, float* mu_o, float* r_o, float* sc_o,
+                                                           float* sh_o, double* var_o) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
+        s1 += rows[((size_t)t * 2) * C + ch];
+        s2 += rows[((size_t)t * 2 + 1) * C + ch];
+    }
+    const double mu = s1 / (double)count;
+    double var = s2 / (double)count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma * r;
+    *mu_o = (float)mu; *r_o = r; *sc_o = sc; *sh_o = beta - (float)mu * sc; *var_o = var;
+}
+
+__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams p, const BnFusedFwdArgs f) {
+    extern __shared__ float sm[];                      // scale[C] shift[C] (rscale[C] rshift[C])
+    const int C = p.C;
+    float* s_sc = sm; float* s_sh = sm + C; float* s_rsc = sm + 2 * C; float* s_rsh = sm + 3 * C;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float mu, r, sc, sh; double var;
+        bn_finalize_channel(f.rows, C, ch, f.count, f.eps, f.gamma[ch], f.beta[ch], &mu, &r, &sc, &sh, &var);
+        s_sc[ch] = sc; s_sh[ch] = sh;
+        if (blockIdx.x == 0) {
+            f.mean[ch] = mu; f.rstd[ch] = r; f.scale[ch] = sc; f.shift[ch] = sh;
+            if (f.rm) {
+                const double unb = f.count > 1.f ? var * (double)f.count / ((double)f.count - 1.0) : var;
+                f.rm[ch] = (1.f - f.momentum) * f.rm[ch] + f.momentum * mu;
+                f.rv[ch] = (1.f - f.momentum) * f.rv[ch] + f.momentum * (float)unb;
+            }
+        }
+        if (f.rows2) {
+            bn_finalize_channel(f.rows2, C, ch, f.count2, f.eps, f.gamma2[ch], f.beta2[ch], &mu, &r, &sc, &sh, &var);
+            s_rsc[ch] = sc; s_rsh[ch] = sh;
+            if (blockIdx.x == 0) {
+                f.mean2[ch] = mu; f.rstd2[ch] = r; f.scale2[ch] = sc; f.shift2[ch] = sh;
+                if (f.rm2) {
+                    const double unb = f.count2 > 1.f ? var * (double)f.count2 / ((double)f.count2 - 1.0) : var;
+                    f.rm2[ch] = (1.f - f.momentum) * f.rm2[ch] + f.momentum * mu;
+                    f.rv2[ch] = (1.f - f.momentum) * f.rv2[ch] + f.momentum * (float)unb;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cv = C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(it / cv);
+        const int c = (int)(it - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * s_sc[c + j] + s_sh[c + j];
+        if (p.res_kind == 1) {
+            float rr[8];
+            const size_t ro = ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * C + c;
+            unpack8(*reinterpret_cast<const uint4*>(p.res + ro), rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        } else if (p.res_kind == 2) {
+            float rr[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)m * C + c), rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j] * s_rsc[c + j] + s_rsh[c + j];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+        }
+        const size_t oo = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + c;
+        *reinterpret_cast<uint4*>(p.out + oo) = pack8(v);
+    }
+}
+
+hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f0, hipStream_t s) {
+    if (p.C % 8 || p.C > 4096) return hipErrorInvalidValue;
+    BnFusedFwdArgs f;
+    f.rows = f0.rows; f.count = f0.count; f.gamma = f0.gamma; f.beta = f0.beta; f.rm = f0.rm; f.rv = f0.rv;
+    f.mean = f0.mean; f.rstd = f0.rstd; f.scale = f0.scale; f.shift = f0.shift;
+    f.rows2 = f0.rows2; f.count2 = f0.count2; f.gamma2 = f0.gamma2; f.beta2 = f0.beta2; f.rm2 = f0.rm2; f.rv2 = f0.rv2;
+    f.mean2 = f0.mean2; f.rstd2 = f0.rstd2; f.scale2 = f0.scale2; f.shift2 = f0.shift2;
+    f.momentum = f0.momentum; f.eps = f0.eps;
+    const long items = (long)p.M * (p.C / 8);
+    long g = (items + 1023) / 1024;
+    // every block pays the finalize prologue (2*C*VPD_FUSED_ROWS doubles): few, fat blocks -- two per CU
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)4 * p.C * sizeof(float), s, p, f);
+    return hipGetLastError();
+}
+
+struct BnFusedBwdArgs {
+    double* rows;                              // this BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][C], zeroed
+    GridSync* sync;                            // zeroed
+    unsigned* err;                             // sticky time-out counter
+    const float* gamma; float* dgamma; float* dbeta;
+    float count;
+    int keep_g, keep_z, iters;                 // LDS residency of g / z across the barrier; pixel iterations per thread
+};
+
+template <int MASK, int WRITE_G>
+__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p, const BnFusedBwdArgs f) {
+    extern __shared__ uint4 smem4[];
+    const int T = 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C, cv = C >> 3;
+    const int ppi = T / cv;
+    const int c8 = tid % cv, pl = tid / cv, c = c8 << 3;
+    const int HW = p.H * p.W;
+    uint4* sG = smem4;
+    uint4* sZ = sG + (f.keep_g ? (size_t)f.iters * T : 0);
+    float* red = reinterpret_cast<float*>(sZ + (f.keep_z ? (size_t)f.iters * T : 0));      // [16 waves][2][C], then coef [2][C]
+
+    float mu[8], rs[8], msc[8], msh[8], a1[8], a2[8];
+#define LD8(dst, src) \
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
+    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+    LD8(mu, p.mean + c) LD8(rs, p.rstd + c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { msc[j] = 0.f; msh[j] = 1.f; a1[j] = 0.f; a2[j] = 0.f; }
+    if (MASK == 2) { LD8(msc, p.mscale + c) LD8(msh, p.mshift + c) }
+
+    const int mbeg = blockIdx.x * p.ppb;
+    int mend = mbeg + p.ppb;
+    mend = mend < p.M ? mend : p.M;
+    // ---- phase 1: g = dy * mask, per-thread partial sums; g (and z) parked in LDS ----
+    int it = 0;
+    for (int m = mbeg + pl; m < mend; m += ppi, ++it) {
+        float g[8], z[8];
+        const uint4 zr = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c);
+        uint4 gr = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c);
+        unpack8(gr, g);
+        unpack8(zr, z);
+        if (MASK == 1) {
+            const int b = m / HW;
+            const int r = m - b * HW;
+            const int y = r / p.W;
+            const int x = r - y * p.W;
+            float a[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * C + c), a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+            gr = pack8(g);                                  // exact: g is dy or 0
+            if (WRITE_G) *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * C + c) = gr;
+        } else if (MASK == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
+            gr = pack8(g);
+        }
+        if (f.keep_g) sG[(size_t)it * T + tid] = gr;
+        if (f.keep_z) sZ[(size_t)it * T + tid] = zr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a1[j] += g[j];
+            a2[j] += g[j] * ((z[j] - mu[j]) * rs[j]);
+        }
+    }
+    // ---- block reduction in a fixed order: lanes of a wave that share a channel group, then the 16 waves ----
+    if (cv < 64) {
+        for (int o = cv; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
+        }
+    }
+    if (lane < cv) {                                        // (cv >= 64: every lane; its channel group is c8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(size_t)(wave * 2 + 0) * C + c + j] = a1[j];
+            red[(size_t)(wave * 2 + 1) * C + c + j] = a2[j];
+        }
+    }
+    __syncthreads();
+    // waves that hold the same channel groups: all 16 when cv <= 64, every (cv/64)-th otherwise
+    const int wstep = cv <= 64 ? 1 : cv / 64;
+    for (int t = tid; t < 2 * C; t += T) {
+        const int which = t / C;
+        const int ch = t - which * C;
+        const int w0 = cv <= 64 ? 0 : (ch >> 3) / 64;
+        float tot = 0.f;
+        for (int w = w0; w < 16; w += wstep) tot += red[(size_t)(w * 2 + which) * C + ch];
+        atomicAdd(&f.rows[((size_t)(blockIdx.x & (VPD_FUSED_ROWS - 1)) * 2 + which) * C + ch], (double)tot);
+    }
+    vpd_grid_barrier(f.sync, false, f.err);
+    // ---- finalize: every block sums the rows of all channels (2*C*VPD_FUSED_ROWS doubles) ----
+    for (int t = tid; t < 2 * C; t += T) {
+        const int which = t / C;
+        const int ch = t - which * C;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < VPD_FUSED_ROWS; ++r)
+            s += __hip_atomic_load(&f.rows[((size_t)r * 2 + which) * C + ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[t] = (float)(s / (double)f.count);
+        if (blockIdx.x == 0) {
+            if (which == 0) f.dbeta[ch] = (float)s;
+            else f.dgamma[ch] = (float)s;
+        }
+    }
+    __syncthreads();
+    float c1[8], c2[8], c3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        c1[j] = f.gamma[c + j] * rs[j];
+        c2[j] = red[c + j];
+        c3[j] = red[C + c + j];
+    }
+    // ---- phase 2: dz = c1 * (g - c2 - xhat * c3) ----
+    it = 0;
+    for (int m = mbeg + pl; m < mend; m += ppi, ++it) {
+        float g[8], z[8];
+        const uint4 zr = f.keep_z ? sZ[(size_t)it * T + tid] : *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c);
+        unpack8(zr, z);
+        if (f.keep_g) {
+            unpack8(sG[(size_t)it * T + tid], g);
+        } else {
+            // not resident: g was written back over dy by this very thread (WRITE_G), or is recomputed from dy and z
+            unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c), g);
+            if (MASK == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
+            }
+        }
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = c1[j] * (g[j] - c2[j] - (z[j] - mu[j]) * rs[j] * c3[j]);
+        const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
+        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+    }
+#undef LD8
+}
+
+// false: this shape has to take the three-launch path (vpd_launch_bn_bwd)
+bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g) {
+    static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
+    if (off || C % 8 || C < 64 || C > 1024 || 1024 % (C / 8)) return false;
+    if (mask_act && !write_g) return false;             // (no caller: the masked g could not be recovered in phase 2)
+    return M >= 1024 / (C / 8);
+}
+
+hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, hipStream_t s) {
+    BnBwdParams p = p0;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
+    }
+    const int cv = p.C / 8, ppi = 1024 / cv;
+    int G = ncu;                                        // one 1024-thread block per CU: the whole grid is resident
+    int ppb = (p.M + G - 1) / G;
+    ppb = ((ppb + ppi - 1) / ppi) * ppi;
+    G = (p.M + ppb - 1) / ppb;
+    p.ppb = ppb;
+    BnFusedBwdArgs f;
+    f.rows = f0.rows; f.sync = reinterpret_cast<GridSync*>(f0.sync); f.err = f0.err; f.gamma = f0.gamma; f.dgamma = f0.dgamma; f.dbeta = f0.dbeta;
+    f.count = f0.count;
+    f.iters = ppb / ppi;
+    const size_t red_bytes = (size_t)16 * 2 * p.C * sizeof(float);
+    const size_t tile = (size_t)f.iters * 1024 * 16;    // bytes of one resident tensor slice
+    const size_t cap = 160 * 1024;
+    const int mask = p.act ? 1 : (p.mscale ? 2 : 0);
+    f.keep_g = red_bytes + tile <= cap;
+    f.keep_z = f.keep_g && red_bytes + 2 * tile <= cap;
+    if (!f.keep_g && mask == 1 && !p.write_g) return hipErrorInvalidValue;
+    const size_t lds = red_bytes + (f.keep_g ? tile : 0) + (f.keep_z ? tile : 0);
+    if (mask == 1 && p.write_g) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 1>), dim3(G), dim3(1024), lds, s, p, f);
+    else if (mask == 1) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 0>), dim3(G), dim3(1024), lds, s, p, f);
+    else if (mask == 2) hipLaunchKernelGGL((bn_bwd_fused_kernel<2, 0>), dim3(G), dim3(1024), lds, s, p, f);
+    else hipLaunchKernelGGL((bn_bwd_fused_kernel<0, 0>), dim3(G), dim3(1024), lds, s, p, f);
+    return hipGetLastError();
+}

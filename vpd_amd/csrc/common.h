@@ -22,6 +22,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #endif
 // per-channel statistics are accumulated into this many [2][C] fp32 rows (row = producer block % rows)
 #define VPD_STAT_ROWS 16
+// the fused BatchNorm passes (bn.hip) give every BatchNorm its OWN rows, fewer of them: every consumer block sums them itself
+#define VPD_FUSED_ROWS 4
 
 static __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
@@ -103,7 +105,8 @@ struct ConvParams {
     const bf16_t* x; int xHp, xWp, xC;          // padded dims, pixel stride (elements)
     const bf16_t* w;                            // [tap][Co][Kc] bf16
     bf16_t* y; int yHp, yWp, yC, ypad;
-    double* stats;                              // [VPD_STAT_ROWS][2][Co] accumulators of sum / sum of squares (fp64 atomics), or null
+    double* stats;                              // [stat_rows][2][Co] accumulators of sum / sum of squares (fp64 atomics), or null
+    int stat_rows;                              // power of two; 0 = VPD_STAT_ROWS
     const float* ep_scale; const float* ep_shift;   // eval epilogue: y = relu?(scale*acc+shift(+res))
     const bf16_t* res; int rHp, rWp, rC, rpad;  // residual for the eval epilogue (padded act) or null
     int ep_relu;

@@ -134,7 +134,8 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
             // VPD_STAT_ROWS accumulator rows spread the atomic traffic; bn_finalize sums and re-zeroes them.  The rows
             // are fp64: the order in which blocks arrive then perturbs a sum at the 1e-16 level, far below the fp32
             // rounding of mean / rstd, so the statistics (and with them the whole step) repeat run to run
-            atomicAdd(&p.stats[((size_t)(row & (VPD_STAT_ROWS - 1)) * 2 + which) * p.Co + n0 + c], (double)t);
+            const int rmask = (p.stat_rows ? p.stat_rows : VPD_STAT_ROWS) - 1;
+            atomicAdd(&p.stats[((size_t)(row & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
         }
     }
 }

@@ -318,13 +318,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
 // ---------------------------------------------------------------------------
 // HB: halo buffers (1 when the conv has a single 64-channel chunk: the smaller footprint lets two blocks share a
 // CU and overlap each other's prologue / epilogue); WPS: launch-bounds waves per SIMD (4 = two blocks per CU).
-template <int BM, int BN, int HROWS, int HB, int WPS, int EPM>
+template <int BM, int BN, int HROWS, int HB, int WPS, int EPM, int NS>
 __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
     constexpr int WN = BN / 64;
     constexpr int WM = 4 / WN;
     constexpr int WTM = BM / WM;
     constexpr int MI = WTM / 16, NI = 4;
-    constexpr int NS = 3;
+    constexpr int AHEAD = NS - 1;                    // weight tiles in flight beyond the one being consumed
     constexpr int WSTAGE = BN * 64;
     constexpr int HBUF = HROWS * 64;
     constexpr int W_PER = BN / 32;                   // weight-tile DMA instructions per loader wave per step
@@ -379,15 +379,22 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         };
 #pragma unroll
         for (int k = 0; k < HPASS; ++k) halo_instr(0, k);
+        // prologue: the halo of chunk 0 and the first AHEAD weight tiles; only the halo and tile 0 are waited for
         issue_w(0, 0);
-        issue_w(nsteps > 1 ? 1 : 0, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 1; k < AHEAD; ++k) issue_w(k < nsteps ? k : nsteps - 1, k);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * W_PER) : "memory");
         for (int s = 0; s < nsteps; ++s) {
-            if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+            // bundles s+1 .. s+AHEAD-1 may still be in flight; bundle s (and everything older) has landed
+            // (the first tiles were issued in the prologue without halo slices: exact counts of what is younger than tile s)
+            static_assert(AHEAD <= 4 && (AHEAD - 1) * PER_STEP < 64, "vmcnt range / peeled steps");
+            if (s == 1 && AHEAD > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD > 2 ? AHEAD - 2 : 0) * W_PER + PER_STEP) : "memory");
+            else if (s == 2 && AHEAD > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD > 3 ? AHEAD - 3 : 0) * W_PER + 2 * PER_STEP) : "memory");
+            else if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_STEP) : "memory");
             __builtin_amdgcn_s_barrier();                         // READY_s
-            const int sw = s + 2 < nsteps ? s + 2 : nsteps - 1;   // tail: harmless reload into a free stage
+            const int sw = s + AHEAD < nsteps ? s + AHEAD : nsteps - 1;   // tail: harmless reload into a free stage
             if (VPD_ABL(p, 1)) continue;
-            issue_w(sw, (s + 2) % NS);
+            issue_w(sw, (s + AHEAD) % NS);
             const int cc = s / 9;
             const int tap = s - cc * 9;
             // next chunk's halo, slice `tap`; on the last chunk (and in slice 8) re-load identical bytes
@@ -753,18 +760,27 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int HROWS, int HB, int WPS>
-static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+template <int BM, int BN, int HROWS, int HB, int WPS, int NS>
+static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
-    const size_t lds = ((size_t)HB * HROWS + 3 * BN) * 64 * sizeof(bf16_t);
+    const size_t lds = ((size_t)HB * HROWS + NS * BN) * 64 * sizeof(bf16_t);
+    static_assert(((size_t)HB * HROWS + NS * BN) * 64 * sizeof(bf16_t) <= 160 * 1024, "LDS");
     ConvParams q = p;
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0>), grid, dim3(512), lds, stream, q, g); break;
-        case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1>), grid, dim3(512), lds, stream, q, g); break;
-        case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2>), grid, dim3(512), lds, stream, q, g); break;
-        default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3>), grid, dim3(512), lds, stream, q, g); break;
+        case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2, NS>), grid, dim3(512), lds, stream, q, g); break;
+        default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3, NS>), grid, dim3(512), lds, stream, q, g); break;
     }
     return hipGetLastError();
+}
+// NSMAX: the deepest weight ring that fits LDS beside the two halo buffers.  VPD_WS_NS=3 selects the 3-stage ring (A/B).
+template <int BM, int BN, int HROWS, int HB, int WPS, int NSMAX>
+static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    static const int ns = getenv("VPD_WS_NS") ? atoi(getenv("VPD_WS_NS")) : NSMAX;
+    if (NSMAX >= 5 && ns >= 5) return launch_ws_ns<BM, BN, HROWS, HB, WPS, NSMAX >= 5 ? 5 : 3>(p, g, stream);
+    if (NSMAX >= 4 && ns >= 4) return launch_ws_ns<BM, BN, HROWS, HB, WPS, NSMAX >= 4 ? 4 : 3>(p, g, stream);
+    return launch_ws_ns<BM, BN, HROWS, HB, WPS, 3>(p, g, stream);
 }
 
 template <int BM, int BN, int HROWS, bool HALO2>
@@ -855,9 +871,11 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
         case 0: return launch_c64<224>(p, g, stream);
-        case 1: return launch_ws<256, 128, 352, 2, 2>(p, g, stream);
-        case 2: return launch_ws<128, 128, 288, 2, 2>(p, g, stream);
-        case 3: return launch_ws<128, 64, 288, 2, 2>(p, g, stream);
+        case 1: return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
+        // four ring stages (the loaders three weight tiles ahead): same-box A/B against 3 / 5 stages in
+        // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
+        case 2: return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
+        case 3: return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }

@@ -83,6 +83,23 @@ hipError_t vpd_launch_bn_bwd(const BnBwdParams& p, float count, const float* gam
 hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p, float count, const float* gamma, float* dgamma,
                                     float* dbeta, float* coef, bf16_t* dz, hipStream_t s);
 
+// fused BatchNorm passes (bn.hip): per-BatchNorm accumulator rows [VPD_FUSED_ROWS][2][C] of doubles, zeroed by the caller
+struct BnFusedFwd {
+    double* rows; float count; const float* gamma; const float* beta; float* rm; float* rv;
+    float* mean; float* rstd; float* scale; float* shift;
+    double* rows2; float count2; const float* gamma2; const float* beta2; float* rm2; float* rv2;      // residual BN or null
+    float* mean2; float* rstd2; float* scale2; float* shift2;
+    float momentum, eps;
+};
+struct BnFusedBwd {
+    double* rows; void* sync; unsigned* err;    // sync: VPD_GRID_SYNC_BYTES, zeroed; err: sticky time-out counter
+    const float* gamma; float* dgamma; float* dbeta; float count;
+};
+#define VPD_GRID_SYNC_BYTES (18 * 128)
+hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f, hipStream_t s);
+bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);
+hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
+
 // head.hip
 hipError_t vpd_launch_avgpool(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, float* pooled,
                               hipStream_t s);

@@ -20,10 +20,15 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const float* x, int N, 
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[q][c] = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const float4 f = *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * plane + (size_t)y * W + x0);
-            v[0][c] = f.x; v[1][c] = f.y; v[2][c] = f.z; v[3][c] = f.w;
-        }
+        // unrolled over the 8 channel slots (C <= 8 is a run-time value: a rolled loop indexes v[][c] dynamically, which
+        // sends it through scratch and serialises the plane loads -- 51 us for 84 MB); all loads go out before the packs
+        float4 f[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            f[c] = c < C ? *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * plane + (size_t)y * W + x0)
+                         : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v[0][c] = f[c].x; v[1][c] = f[c].y; v[2][c] = f[c].z; v[3][c] = f[c].w; }
         bf16_t* dst = out + ((size_t)(b * Hp + y + pad) * Wp + x0 + pad) * Cp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(dst + q * Cp) = pack8(v[q]);
@@ -39,8 +44,9 @@ __global__ __launch_bounds__(256) void pack_input_px_kernel(const float* x, int 
         const long r = it - (long)b * plane;
         const int y = (int)(r / W);
         const int xx = (int)(r - (long)y * W);
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int c = 0; c < C; ++c) v[c] = x[((size_t)b * C + c) * plane + r];
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[((size_t)b * C + c) * plane + r] : 0.f;
         *reinterpret_cast<uint4*>(out + ((size_t)(b * Hp + y + pad) * Wp + xx + pad) * Cp) = pack8(v);
     }
 }

@@ -44,6 +44,8 @@ struct BnInfo {
     long long w_off = 0, b_off = 0;      // gamma / beta in the flat param buffer
     long long rm_off = 0, rv_off = 0;    // in the running-stat buffer
     size_t fl_off = 0;                   // float scratch in ws: mean,rstd,scale,shift,coef[3],escale,eshift (9C)
+    size_t rows_off = 0;                 // fused passes: this BatchNorm's own accumulator rows [VPD_FUSED_ROWS][2][C] doubles
+    size_t sync_off = 0;                 // ... and the grid-barrier words of its fused backward launch
 };
 struct ConvInfo {
     int Ci = 0, Co = 0, k = 0, stride = 1, pad = 0;
@@ -117,6 +119,9 @@ struct vpd_plan {
     struct Graph { int n; hipGraph_t g; hipGraphExec_t e; };
     std::vector<Graph> graphs;
     void* bound_ws = nullptr;
+    bool fused_bn = true;       // one launch per BatchNorm and direction (VPD_FUSED_BN=0: finalize / reduce / apply launches)
+    size_t fused_off = 0, fused_bytes = 0;      // rows + barrier words of every BatchNorm: zeroed at the start of each pass
+    size_t syncerr_off = 0;                     // sticky counter of grid-barrier time-outs (zeroed by init_workspace only)
     bool wg_group = true;       // per-stage grouped weight gradients (VPD_WG_GROUP=0: one launch per conv)
     size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest stage
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
@@ -341,6 +346,16 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     p->arena_off = bp.take((size_t)p->arena_elems * 2);
     p->wg_off = bp.take((size_t)p->wg_elems * 4);
     for (BnInfo* b : p->bns) b->fl_off = bp.take((size_t)9 * b->C * 4);
+    p->fused_bn = !(getenv("VPD_FUSED_BN") && !atoi(getenv("VPD_FUSED_BN")));
+    {
+        const size_t start = bp.cur;
+        for (BnInfo* b : p->bns) {
+            b->rows_off = bp.take((size_t)VPD_FUSED_ROWS * 2 * b->C * sizeof(double));
+            b->sync_off = bp.take(VPD_GRID_SYNC_BYTES);
+        }
+        p->fused_off = start; p->fused_bytes = bp.cur - start;      // (Bump rounds every piece to 256 B: 16-byte multiples)
+        p->syncerr_off = bp.take(256);
+    }
     p->desc_off = bp.take(p->descs.size() * sizeof(PackDesc));
     p->bmap_pack_off = bp.take(p->bmap_pack.size() * sizeof(int));
     p->bmap_adam_off = bp.take(p->bmap_adam.size() * sizeof(int));
@@ -519,6 +534,8 @@ struct Ctx {
     bf16_t* b16(size_t off) const { return reinterpret_cast<bf16_t*>(ws + off); }
     float* f32(size_t off) const { return reinterpret_cast<float*>(ws + off); }
     double* stat_rows() const { return reinterpret_cast<double*>(ws + p->partial_off); }
+    double* bn_rows(const BnInfo& b) const { return reinterpret_cast<double*>(ws + b.rows_off); }
+    bool fused(const ConvInfo& cv) const { return p->fused_bn && !cv.stem; }
     float* bn_mean(const BnInfo& b) const { return f32(b.fl_off); }
     float* bn_rstd(const BnInfo& b) const { return f32(b.fl_off) + b.C; }
     float* bn_scale(const BnInfo& b) const { return f32(b.fl_off) + 2 * b.C; }
@@ -567,7 +584,8 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     else { q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci; }
     q.w = c.b16(c.p->arena_off) + cv.fwd_off;
     q.y = y; q.yHp = cv.Hout + 2 * ypad; q.yWp = cv.Wout + 2 * ypad; q.yC = cv.Co; q.ypad = ypad;
-    q.stats = stats ? c.stat_rows() : nullptr;
+    q.stats = stats ? (c.fused(cv) ? c.bn_rows(cv.bn) : c.stat_rows()) : nullptr;
+    q.stat_rows = c.fused(cv) ? VPD_FUSED_ROWS : 0;
     q.ep_scale = ep_scale; q.ep_shift = ep_shift; q.res = res; q.ep_relu = ep_relu;
     q.rHp = cv.Hout + 2; q.rWp = cv.Wout + 2; q.rC = cv.Co; q.rpad = 1;
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
@@ -692,6 +710,40 @@ hipError_t run_bn_apply(const Ctx& c, const ConvInfo& cv, int res_kind, const bf
     return vpd_launch_bn_apply(a, c.s);
 }
 
+// train-mode convolution: dense z + per-channel statistics.  Unfused BatchNorm: the statistics go to the SHARED rows,
+// which the finalize launch right behind the conv consumes and re-zeroes; fused: to the BatchNorm's own rows.
+hipError_t run_conv_train(const Ctx& c, const ConvInfo& cv, const bf16_t* x, float* bn_running) {
+    hipError_t e = run_conv_fwd(c, cv, x, c.b16(cv.z_off), 0, true, nullptr, nullptr, nullptr, 0);
+    if (e != hipSuccess || c.fused(cv)) return e;
+    return run_bn_finalize(c, cv, bn_running);
+}
+
+// BatchNorm (+ residual, ReLU) of a train-mode forward: statistics -> normalised padded activation.  rcv: the
+// down-sampling branch's conv (res_kind 2), whose BatchNorm is finalized here too.  One launch when fused.
+hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int res_kind, const bf16_t* res,
+                      const ConvInfo* rcv, bf16_t* out, int relu) {
+    if (!c.fused(cv)) return run_bn_apply(c, cv, res_kind, res, rcv, out, relu);      // (finalized by run_conv_train)
+    BnApplyParams a;
+    memset(&a, 0, sizeof a);
+    a.z = c.b16(cv.z_off);
+    a.res_kind = res_kind; a.res = res; a.rHp = cv.Hout + 2; a.rWp = cv.Wout + 2; a.rpad = 1;
+    a.out = out; a.oHp = cv.Hout + 2; a.oWp = cv.Wout + 2; a.opad = 1;
+    a.M = c.n * cv.Hout * cv.Wout; a.H = cv.Hout; a.W = cv.Wout; a.C = cv.Co; a.relu = relu;
+    BnFusedFwd f;
+    memset(&f, 0, sizeof f);
+    auto fill = [&](const ConvInfo& k, double** rows, float* count, const float** gamma, const float** beta, float** rm,
+                    float** rv, float** mean, float** rstd, float** scale, float** shift) {
+        *rows = c.bn_rows(k.bn); *count = (float)(c.n * k.Hout * k.Wout);
+        *gamma = c.params + k.bn.w_off; *beta = c.params + k.bn.b_off;
+        *rm = bn_running ? bn_running + k.bn.rm_off : nullptr; *rv = bn_running ? bn_running + k.bn.rv_off : nullptr;
+        *mean = c.bn_mean(k.bn); *rstd = c.bn_rstd(k.bn); *scale = c.bn_scale(k.bn); *shift = c.bn_shift(k.bn);
+    };
+    fill(cv, &f.rows, &f.count, &f.gamma, &f.beta, &f.rm, &f.rv, &f.mean, &f.rstd, &f.scale, &f.shift);
+    if (rcv) fill(*rcv, &f.rows2, &f.count2, &f.gamma2, &f.beta2, &f.rm2, &f.rv2, &f.mean2, &f.rstd2, &f.scale2, &f.shift2);
+    f.momentum = kBnMomentum; f.eps = kBnEps;
+    return vpd_launch_bn_fwd_fused(a, f, c.s);
+}
+
 // act != null: ReLU mask from the stored activation (needed when a residual was added before the ReLU);
 // relu_from_z: mask recomputed as scale*z + shift > 0 (plain conv-BN-ReLU), which saves reading the activation
 hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
@@ -706,6 +758,14 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
     if (relu_from_z && !reduce_done) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
     if (reduce_done) b.act = nullptr;        // dy already holds g (masked by the producing dgrad kernel)
+    if (c.fused(cv) && !reduce_done && vpd_bn_bwd_fused_ok(b.M, b.C, b.act != nullptr, write_g != 0)) {
+        BnFusedBwd f;
+        f.rows = c.bn_rows(cv.bn); f.sync = c.ws + cv.bn.sync_off;
+        f.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
+        f.gamma = c.params + cv.bn.w_off; f.dgamma = grads + cv.bn.w_off; f.dbeta = grads + cv.bn.b_off;
+        f.count = (float)b.M;
+        return vpd_launch_bn_bwd_fused(b, f, c.s);
+    }
     return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s,
                              reduce_done);
 }
@@ -840,6 +900,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         ZeroRanges z;
         memset(&z, 0, sizeof z);
         z.ptr[0] = c.f32(p->partial_off); z.n4[0] = (long)p->partial_bytes / 16; z.count = 1;      // accumulator rows
+        if (p->fused_bn) { z.ptr[1] = c.f32(p->fused_off); z.n4[1] = (long)p->fused_bytes / 16; z.count = 2; }
         LCHECK(vpd_launch_zero_ranges(z, s));
     }
     if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
@@ -859,34 +920,28 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     for (auto& B : p->blocks) {
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
-        LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-        LCHECK(run_bn_finalize(c, B.c1, bn_running));
-        LCHECK(run_bn_apply(c, B.c1, 0, nullptr, nullptr, a1, 1));
+        LCHECK(run_conv_train(c, B.c1, cur, bn_running));
+        LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
-            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-            LCHECK(run_bn_finalize(c, B.c2, bn_running));
-            LCHECK(run_bn_apply(c, B.c2, 0, nullptr, nullptr, a2, 1));
-            LCHECK(run_conv_fwd(c, B.c3, a2, c.b16(B.c3.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-            LCHECK(run_bn_finalize(c, B.c3, bn_running));
+            LCHECK(run_conv_train(c, B.c2, a1, bn_running));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1));
+            LCHECK(run_conv_train(c, B.c3, a2, bn_running));
             if (B.ds) {
-                LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-                LCHECK(run_bn_finalize(c, B.cd, bn_running));
-                LCHECK(run_bn_apply(c, B.c3, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+                LCHECK(run_conv_train(c, B.cd, cur, bn_running));
+                LCHECK(run_bn_fwd(c, B.c3, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
             } else {
-                LCHECK(run_bn_apply(c, B.c3, 1, cur, nullptr, outp, 1));
+                LCHECK(run_bn_fwd(c, B.c3, bn_running, 1, cur, nullptr, outp, 1));
             }
             cur = outp;
             continue;
         }
-        LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-        LCHECK(run_bn_finalize(c, B.c2, bn_running));
+        LCHECK(run_conv_train(c, B.c2, a1, bn_running));
         if (B.ds) {
-            LCHECK(run_conv_fwd(c, B.cd, cur, c.b16(B.cd.z_off), 0, true, nullptr, nullptr, nullptr, 0));
-            LCHECK(run_bn_finalize(c, B.cd, bn_running));
-            LCHECK(run_bn_apply(c, B.c2, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+            LCHECK(run_conv_train(c, B.cd, cur, bn_running));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
         } else {
-            LCHECK(run_bn_apply(c, B.c2, 1, cur, nullptr, outp, 1));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 1, cur, nullptr, outp, 1));
         }
         cur = outp;
     }
@@ -910,6 +965,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     ZeroRanges zr;
     memset(&zr, 0, sizeof zr);
     zr.ptr[0] = c.f32(p->partial_off); zr.n4[0] = (long)p->partial_bytes / 16; zr.count = 1;
+    if (p->fused_bn) { zr.ptr[1] = c.f32(p->fused_off); zr.n4[1] = (long)p->fused_bytes / 16; zr.count = 2; }
     bool prezeroed = true;
     {
         auto dry = [&](const ConvInfo& cv, int dzpad) {
@@ -918,7 +974,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         for (auto& B : p->blocks) { dry(B.c1, 1); dry(B.c2, 1); if (p->bottleneck) dry(B.c3, 1); if (B.ds) dry(B.cd, 1); }
         dry(p->stem, 0);
         if (zr.count >= ZR_MAX) {      // too many ranges (Bottleneck nets: 30-100 1x1 convs): zero the whole scratch in one range
-            zr.ptr[1] = c.f32(p->wg_off); zr.n4[1] = (long)(p->wg_elems + 3) / 4; zr.count = 2;
+            const int k = p->fused_bn ? 2 : 1;
+            zr.ptr[k] = c.f32(p->wg_off); zr.n4[k] = (long)(p->wg_elems + 3) / 4; zr.count = k + 1;
         }
     }
     LCHECK(vpd_launch_zero_ranges(zr, s));
@@ -1144,6 +1201,17 @@ extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* gr
         LCHECK(vpd_launch_adamw(params + p->nparam_padded, grads + p->nparam_padded, adam_m + p->nparam_padded,
                                 adam_v + p->nparam_padded, (long)(numel - p->nparam_padded), lr, beta1, beta2, eps,
                                 weight_decay, step, s));
+    return 0;
+}
+
+extern "C" int vpd_plan_sync_errors(vpd_plan_t* p, void* workspace, void* stream, unsigned* count_out) {
+    if (!p || !workspace || !count_out) return fail("null argument");
+    if (p->bound_ws != workspace) return fail("workspace not initialised with vpd_plan_init_workspace");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned v = 0;
+    HCHECK(hipMemcpyAsync(&v, (char*)workspace + p->syncerr_off, sizeof v, hipMemcpyDeviceToHost, s));
+    HCHECK(hipStreamSynchronize(s));
+    *count_out = v;
     return 0;
 }
 

@@ -293,6 +293,18 @@ class StudentEngine:
         pl.graph_sizes.add(n)
         return pl
 
+    def sync_errors(self):
+        """Grid-barrier time-outs counted by the train plans since their workspaces were initialised (host sync).
+        Non-zero = a fused BatchNorm launch gave up waiting for its grid: results are not to be trusted."""
+        total = 0
+        out = C.c_uint(0)
+        for pl in self._plans.values():
+            if pl.train and pl.handle:
+                check(lib().vpd_plan_sync_errors(pl.handle, _ptr(pl.workspace), self._stream(), C.byref(out)),
+                      "vpd_plan_sync_errors")
+                total += out.value
+        return total
+
     def set_timing(self, pl, enable):
         check(lib().vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
 

@@ -127,6 +127,9 @@ class ModelTrainer:
             if progress_cb is not None:
                 progress_cb(n)
         epoch_emb_loss = float(eng.loss_accum.item())   # ONE host sync per epoch
+        if optimizer is not None and eng.sync_errors():
+            raise RuntimeError("a fused BatchNorm launch timed out at its in-launch grid barrier (the grid was not "
+                               "resident): this epoch's results are invalid; set VPD_FUSED_BN=0 to use separate launches")
         if self._reducer is not None:
             epoch_emb_loss, epoch_emb_n = self._reducer.all_reduce_scalars(epoch_emb_loss, epoch_emb_n)
         return epoch_emb_loss / epoch_emb_n
