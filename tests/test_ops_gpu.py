@@ -117,6 +117,10 @@ CONV_CASES = [
     ("l3_3x3_s1_ragged", 5, 256, 256, 4, 4, 3, 1, 1),
     ("l4_3x3_s1_tiny", 2, 512, 512, 2, 2, 3, 1, 1),
     ("l2_3x3_s1_big", 9, 128, 128, 16, 16, 3, 1, 1),
+    # stride-2 3x3 at the three ResNet stage boundaries (halo-form weight gradient: 4 rows x 16, 8 x 8, four whole 4 x 4 images
+    # per 64-pixel chunk), the last one with a ragged final chunk
+    ("l2_3x3_s2_32to16", 2, 64, 128, 32, 32, 3, 2, 1),
+    ("l4_3x3_s2_8to4_ragged", 5, 256, 512, 8, 8, 3, 2, 1),
 ]
 
 

@@ -964,7 +964,7 @@ bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g) {
     static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
     if (off || C % 8 || C < 64 || C > 1024 || 1024 % (C / 8)) return false;
     if (mask_act && !write_g) return false;             // (no caller: the masked g could not be recovered in phase 2)
-    return M >= 1024 / (C / 8);
+    return M >= 1;
 }
 
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, hipStream_t s) {

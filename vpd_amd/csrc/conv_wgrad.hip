@@ -200,11 +200,12 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
 }
 
 // MFMA-wave body of conv_wgrad_halo_kernel for taps [T0, T1): ci columns 16*ctile .. +15, all 64 co.
-template <int T0, int T1>
+template <int T0, int T1, int NS>
 static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, const WgHaloGeom& g, const bf16_t* ring,
                                                        int STAGE, int nch, int ctile, int lane, int bx, int by) {
     constexpr int NT = T1 - T0;
-    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    // W, H: OUTPUT dims; the x halo is rows of the padded INPUT (stride S = 1 or 2: input pixel S*y + r, S*x + t)
+    const int W = p.Ws, H = p.Hs, Wp = p.xWp, S = p.istr;
     f32x4 acc[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -232,8 +233,8 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
                 const int pk = 32 * ks + 8 * gq + 4 * h + q;      // pixel of the chunk this lane addresses
                 const int lr = pk / W;
                 const int xx = pk - lr * W;
-                const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
-                const int hmv = hrow * Wp + xx;
+                const int hrow = g.multi ? (lr / H) * p.xHp + S * (lr % H) : S * lr;
+                const int hmv = hrow * Wp + S * xx;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int tt = T0 + t;
@@ -256,7 +257,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
     for (int c = 0; c < nch; ++c) {
         __builtin_amdgcn_s_barrier();                             // READY_c
         if (VPD_ABL(p, 2)) continue;
-        const bf16_t* st = ring + (c % 3) * STAGE;
+        const bf16_t* st = ring + (c % NS) * STAGE;
         if constexpr (NT == 4) {
             // the 4-tap wave of a SIMD reads BOTH k-steps up front and then issues its 32 MFMAs in one run, so that
             // the 5-tap wave's second read phase falls into this wave's MFMAs instead of coinciding with a read
@@ -317,7 +318,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #define WG_NS 3            // ring stages
 
 // NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS).  (bx, by) = (output tile, pixel split) of this block.
-template <int NPASS>
+template <int NPASS, int NS = WG_NS>
 static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, const WgHaloGeom& g, int bx, int by) {
     constexpr int HROWS = 32 * NPASS;
     constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile then halo
@@ -330,7 +331,7 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
     // waves 0..7: MFMA (ci tile = wave & 3, tap half = wave >> 2: two MFMA waves share each SIMD so one computes
     // while the other waits for its LDS reads); waves 8..11: loaders
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int W = p.Ws, H = p.Hs, Wp = p.xWp, S = p.istr;
     const int kct = p.Kc >> 6;
     const int co0 = (bx / kct) * 64;
     const int ci0 = (bx % kct) * 64;
@@ -347,7 +348,7 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
         const int lrow = lane >> 3;                               // row within an 8-row wave instruction
         auto issue = [&](int c) __attribute__((always_inline)) {
             const int ch = chunk_begin + c;
-            bf16_t* st = ring + (c % WG_NS) * STAGE;
+            bf16_t* st = ring + (c % NS) * STAGE;
             // dz tile: 8 wave-instructions of 8 pixel rows; two per loader wave
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -367,8 +368,8 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
             // x halo: 4*NPASS wave-instructions; NPASS per loader wave
             const int gr0 = ch * g.TR;
             int prow0;
-            if (g.multi) prow0 = (gr0 / H) * (H + 2);
-            else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+            if (g.multi) prow0 = (gr0 / H) * p.xHp;
+            else { const int b = gr0 / H; prow0 = b * p.xHp + S * (gr0 - b * H); }
             const int gp0 = prow0 * Wp;
 #pragma unroll
             for (int i = 0; i < NPASS; ++i) {
@@ -385,26 +386,26 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
             return;
         }
         issue(0);
-        if (nch > 1) issue(1);
+        if (NS > 2 && nch > 1) issue(1);
         for (int c = 0; c < nch; ++c) {
-            // chunk c has landed when at most the instructions of chunk c+1 are still outstanding
-            if (c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+            // chunk c has landed when at most the instructions of the NS - 2 younger chunks are still outstanding
+            if (NS > 2 && c + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // READY_c (MFMA waves have finished chunk c-1)
-            if (c + 2 < nch) issue(c + 2);                        // into the stage chunk c-1 used
+            if (c + NS - 1 < nch) issue(c + NS - 1);              // into the stage chunk c-1 used
         }
         return;
     }
 
     // ------------------------- MFMA waves -------------------------
     const int ctile = wave & 3;
-    if (wave < 4) wgrad_mfma_half<0, 5>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
-    else wgrad_mfma_half<5, 9>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
+    if (wave < 4) wgrad_mfma_half<0, 5, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
+    else wgrad_mfma_half<5, 9, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
 }
 
-template <int NPASS>
+template <int NPASS, int NS = WG_NS>
 __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
-    wgrad_halo_body<NPASS>(p, g, blockIdx.x, blockIdx.y);
+    wgrad_halo_body<NPASS, NS>(p, g, blockIdx.x, blockIdx.y);
 }
 
 // Grouped launch: the weight gradients of SEVERAL convolutions of one ResNet stage in one grid.  A weight gradient
@@ -655,27 +656,31 @@ __global__ __launch_bounds__(1024) void wgrad_slab_reduce_kernel(const float4* s
     }
 }
 
+// halo of a 64-output-pixel chunk: rows of the padded INPUT plane(s); stride 1 or 2 (3x3, pad 1)
 static bool wg_halo_geom(const WgradParams& p, WgHaloGeom* g) {
-    const int W = p.Ws, H = p.Hs;
-    if (WG_CH % W != 0) return false;
+    const int W = p.Ws, H = p.Hs, S = p.istr;
+    if (W <= 0 || WG_CH % W != 0 || (S != 1 && S != 2)) return false;
     const int TR = WG_CH / W;
-    if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
-    else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
+    if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = S * (TR - 1) + 3; }
+    else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * p.xHp; }
     g->TR = TR;
-    g->NHP = g->HR * (W + 2);
-    g->total_pix = p.N * (H + 2) * (W + 2);
-    return g->NHP <= 160;
+    g->NHP = g->HR * p.xWp;
+    g->total_pix = p.N * p.xHp * p.xWp;
+    return g->NHP <= (S == 1 ? 160 : 416);
 }
 
 // shape test of the halo kernel for a 3x3 stride-1 conv with Hout x Wout outputs (independent of the batch size)
-bool vpd_wgrad_halo_shape_ok(int H, int W) {
+bool vpd_wgrad_halo_shape_ok(int H, int W, int stride, int Hin, int Win) {
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
+    static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
     if (force_v1 || W <= 0 || WG_CH % W != 0) return false;
+    if (stride == 2 && (no_s2 || Hin != 2 * H || Win != 2 * W)) return false;
+    if (stride != 1 && stride != 2) return false;
     const int TR = WG_CH / W;
     int HR;
-    if (TR <= H) { if (H % TR != 0) return false; HR = TR + 2; }
-    else { if (TR % H != 0) return false; HR = (TR / H) * (H + 2); }
-    return HR * (W + 2) <= 160;
+    if (TR <= H) { if (H % TR != 0) return false; HR = stride * (TR - 1) + 3; }
+    else { if (TR % H != 0) return false; HR = (TR / H) * (Hin + 2); }
+    return HR * (Win + 2) <= (stride == 1 ? 160 : 416);
 }
 
 // true when vpd_launch_wgrad will take the halo + slab path, which OVERWRITES dw (no pre-zeroing needed)
@@ -685,8 +690,12 @@ bool vpd_wgrad_overwrites(const WgradParams& p) {
     if (wg_stem_eligible(p, &tr_stem)) return true;
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
     WgHaloGeom g;
-    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && p.istr == 1 && p.xC == p.Kc && p.xHp == p.Hs + 2 &&
-           p.xWp == p.Ws + 2 && p.taps.dy0 >= 0 && p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
+    static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
+    const bool s1 = p.istr == 1 && p.xHp == p.Hs + 2 && p.xWp == p.Ws + 2;
+    // stride 2 (3x3, pad 1, even input): taps 0..2 in padded input coordinates, forward order only
+    const bool s2 = !no_s2 && p.istr == 2 && p.xHp == 2 * p.Hs + 2 && p.xWp == 2 * p.Ws + 2 && p.taps.dy0 == 0 &&
+                    p.taps.dys == 1 && p.taps.dx0 == 0 && p.taps.dxs == 1;
+    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && (s1 || s2) && p.xC == p.Kc && p.taps.dy0 >= 0 && p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
            p.taps.dy0 + 2 * p.taps.dys <= 2 && p.taps.dx0 >= 0 && p.taps.dx0 + 2 * p.taps.dxs >= 0 && p.taps.dx0 <= 2 &&
            p.taps.dx0 + 2 * p.taps.dxs <= 2 && wg_halo_geom(p, &g);
 }
@@ -846,11 +855,14 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
         const int tiles = (p.Co / 64) * (p.Kc / 64);
         g.ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, &g.cpb);
-        const int npass = (g.NHP + 31) / 32;            // 3..5
-        const size_t lds = (size_t)WG_NS * (WG_CH + 32 * npass) * 64 * sizeof(bf16_t);
+        const int npass = (g.NHP + 31) / 32;            // 3..5 (stride 1), up to 10 / 13 (stride 2)
+        const int ns = npass > 10 ? 2 : WG_NS;          // the 13-pass halo (layer4.0: four whole input planes) leaves room for two stages
+        const size_t lds = (size_t)ns * (WG_CH + 32 * (npass <= 5 ? npass : (npass <= 10 ? 10 : 13))) * 64 * sizeof(bf16_t);
         if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
-        else VPD_LAUNCH(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else if (npass == 5) VPD_LAUNCH(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 3>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
         return vpd_launch_wgrad_reduce(p, stream);
     }

@@ -68,7 +68,7 @@ bool vpd_wgrad_group_eligible(const WgradParams& p);
 size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc);
 hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
 bool vpd_wgrad_overwrites(const WgradParams& p);
-bool vpd_wgrad_halo_shape_ok(int Hout, int Wout);
+bool vpd_wgrad_halo_shape_ok(int Hout, int Wout, int stride = 1, int Hin = 0, int Win = 0);
 
 hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,
                                   const float* beta, float* rm, float* rv, float momentum, float eps,

@@ -177,7 +177,8 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     p->wg_elems += (long long)c.ntaps * Co * c.Kc;
     if (stem && p->train && p->slab_elems == 0)      // the stem wgrad's split slab (shared region, summed at once)
         p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
-    if (!stem && k == 3 && stride == 1 && p->train && vpd_wgrad_halo_shape_ok(c.Hout, c.Wout)) {
+    if (!stem && k == 3 && (stride == 1 || stride == 2) && p->train &&
+        vpd_wgrad_halo_shape_ok(c.Hout, c.Wout, stride, Hin, Win)) {
         // halo wgrad conv: ONE shared slab, summed right after each wgrad launch while it is still in the Infinity
         // Cache (per-conv slabs summed once per bucket were measured 4 % slower: 490 MB fall out of the cache)
         c.slab_off = 0;
@@ -446,7 +447,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             size_t stage_slab[4] = {0, 0, 0, 0};
             for (auto& B : p->blocks)
                 for (ConvInfo* cv : {&B.c1, &B.c2}) {
-                    if (cv->slab_off < 0) continue;
+                    if (cv->slab_off < 0 || cv->stride != 1) continue;      // (stride-2 halo wgrads: their own launch)
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
                     cv->gslab_off = (long long)stage_slab[B.stage];
                     stage_slab[B.stage] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
