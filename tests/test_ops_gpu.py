@@ -121,6 +121,10 @@ CONV_CASES = [
     # per 64-pixel chunk), the last one with a ragged final chunk
     ("l2_3x3_s2_32to16", 2, 64, 128, 32, 32, 3, 2, 1),
     ("l4_3x3_s2_8to4_ragged", 5, 256, 512, 8, 8, 3, 2, 1),
+    # 1x1 convolutions (Bottleneck blocks, down-sampling branches): the weight gradient runs as the centre tap of the halo kernel
+    ("b1_1x1_s1_256to64", 3, 256, 64, 16, 16, 1, 1, 0),
+    ("b3_1x1_s1_128to512_ragged", 5, 128, 512, 4, 4, 1, 1, 0),
+    ("ds_1x1_s2_32to16", 2, 64, 128, 32, 32, 1, 2, 0),
 ]
 
 

@@ -977,6 +977,15 @@ hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, 
     }
     const int cv = p.C / 8, ppi = 1024 / cv;
     int G = ncu;                                        // one 1024-thread block per CU: the whole grid is resident
+    {
+        // small tensors: fewer blocks (fewer barrier arrivals and row atomics) as long as a block keeps >= `min_elems`
+        static const long min_elems = getenv("VPD_BNF_MINELEMS") ? atol(getenv("VPD_BNF_MINELEMS")) : 0;
+        if (min_elems > 0) {
+            long g2 = ((long)p.M * p.C + min_elems - 1) / min_elems;
+            if (g2 < 16) g2 = 16;
+            if (g2 < G) G = (int)g2;
+        }
+    }
     int ppb = (p.M + G - 1) / G;
     ppb = ((ppb + ppi - 1) / ppi) * ppi;
     G = (p.M + ppb - 1) / ppb;

@@ -148,6 +148,9 @@ struct WgradParams {
     int M;
     int chunks_per_block;                       // 128-pixel chunks handled by one block
     TapSet taps;                                // w0 + ir*wrs + ic*wcs indexes the dw slice
+    // halo kernel, set by its launchers: a 1x1 (pad 0) convolution runs as the CENTRE tap of the 3x3 halo form -- taps
+    // holds the 3x3 geometry, only tap 4 is accumulated and dw / the slab have ONE slice
+    int one_by_one;
 };
 
 // ---------------------------------------------------------------------------

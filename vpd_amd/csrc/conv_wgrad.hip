@@ -301,11 +301,11 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
     const int kct = p.Kc >> 6;
     const int co0 = (bx / kct) * 64;
     const int ci0 = (bx % kct) * 64;
-    float* slab = p.slab + (size_t)by * 9 * p.Co * p.Kc;
+    float* slab = p.slab + (size_t)by * (p.one_by_one ? 1 : 9) * p.Co * p.Kc;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int tt = T0 + t;
-        const int wsl = p.taps.w0 + (tt / 3) * p.taps.wrs + (tt % 3) * p.taps.wcs;
+        const int wsl = p.one_by_one ? 0 : p.taps.w0 + (tt / 3) * p.taps.wrs + (tt % 3) * p.taps.wcs;
         float* o = slab + ((size_t)wsl * p.Co + co0) * p.Kc + ci0 + 16 * ctile + i16;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -399,6 +399,14 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
 
     // ------------------------- MFMA waves -------------------------
     const int ctile = wave & 3;
+    if (p.one_by_one) {
+        // 1x1 convolution = the centre tap alone: waves 0..3 carry it (8 MFMAs per chunk: the launch is bound by the
+        // operand stream), waves 4..7 only keep the barrier count
+        if (wave < 4) wgrad_mfma_half<4, 5, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
+        else
+            for (int c = 0; c < nch; ++c) __builtin_amdgcn_s_barrier();
+        return;
+    }
     if (wave < 4) wgrad_mfma_half<0, 5, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
     else wgrad_mfma_half<5, 9, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
 }
@@ -685,17 +693,34 @@ bool vpd_wgrad_halo_shape_ok(int H, int W, int stride, int Hin, int Win) {
 
 // true when vpd_launch_wgrad will take the halo + slab path, which OVERWRITES dw (no pre-zeroing needed)
 static bool wg_stem_eligible(const WgradParams& p, int* TR);
-bool vpd_wgrad_overwrites(const WgradParams& p) {
+// A 1x1 pad-0 convolution in the caller's terms (one tap at padded offset (1, 1)) rewritten as the centre tap of the
+// 3x3 halo form; false when `p` is not such a conv.
+static bool wg_as_one_by_one(const WgradParams& p, WgradParams* q) {
+    if (!(p.taps.nr == 1 && p.taps.nc == 1 && p.taps.dy0 == 1 && p.taps.dx0 == 1 && !p.one_by_one)) return false;
+    *q = p;
+    q->taps.nr = 3; q->taps.nc = 3; q->taps.dy0 = 0; q->taps.dys = 1; q->taps.dx0 = 0; q->taps.dxs = 1;
+    q->taps.w0 = 0; q->taps.wrs = 0; q->taps.wcs = 0;
+    q->one_by_one = 1;
+    return true;
+}
+bool vpd_wgrad_overwrites(const WgradParams& p0) {
     int tr_stem;
-    if (wg_stem_eligible(p, &tr_stem)) return true;
+    if (wg_stem_eligible(p0, &tr_stem)) return true;
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
-    WgHaloGeom g;
     static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
+    // 1x1 convolutions on the halo kernel (centre tap): OFF by default -- as ONE launch per conv it is no faster than the
+    // atomics kernel (ResNet-50 step 9.90 vs 9.55 ms, ResNet-34 +-0: profiles/r02_negative_results.txt); both run at the
+    // ~4 TB/s their operand streams allow.  VPD_WGRAD_1X1=1 enables it (tests/test_ops_gpu.py covers it).
+    static const int no_1x1 = getenv("VPD_WGRAD_1X1") ? !atoi(getenv("VPD_WGRAD_1X1")) : 1;
+    WgradParams p = p0;
+    if (wg_as_one_by_one(p0, &p) && no_1x1) return false;
+    WgHaloGeom g;
     const bool s1 = p.istr == 1 && p.xHp == p.Hs + 2 && p.xWp == p.Ws + 2;
-    // stride 2 (3x3, pad 1, even input): taps 0..2 in padded input coordinates, forward order only
+    // stride 2 (3x3 pad 1 / 1x1 pad 0, even input): taps 0..2 in padded input coordinates, forward order only
     const bool s2 = !no_s2 && p.istr == 2 && p.xHp == 2 * p.Hs + 2 && p.xWp == 2 * p.Ws + 2 && p.taps.dy0 == 0 &&
                     p.taps.dys == 1 && p.taps.dx0 == 0 && p.taps.dxs == 1;
-    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && (s1 || s2) && p.xC == p.Kc && p.taps.dy0 >= 0 && p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
+    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && (s1 || s2) && p.xC == p.Kc && p.taps.dy0 >= 0 &&
+           p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
            p.taps.dy0 + 2 * p.taps.dys <= 2 && p.taps.dx0 >= 0 && p.taps.dx0 + 2 * p.taps.dxs >= 0 && p.taps.dx0 <= 2 &&
            p.taps.dx0 + 2 * p.taps.dxs <= 2 && wg_halo_geom(p, &g);
 }
@@ -704,7 +729,7 @@ size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float)
 
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
     const int ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, nullptr);
-    const long n4 = (long)9 * p.Co * p.Kc / 4;
+    const long n4 = (long)(p.taps.nr == 1 ? 1 : 9) * p.Co * p.Kc / 4;
     const int groups = ksplit < 16 ? ksplit : 16;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(64 * groups), 0, stream,
                        (const float4*)p.slab, (float4*)p.dw, n4, ksplit, groups);
@@ -852,7 +877,11 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         return hipGetLastError();
     }
     WgHaloGeom g;
-    if (vpd_wgrad_overwrites(p) && wg_halo_geom(p, &g)) {
+    if (vpd_wgrad_overwrites(p)) {
+        WgradParams q1;
+        if (wg_as_one_by_one(p, &q1)) p = q1;
+    }
+    if (vpd_wgrad_overwrites(p0) && wg_halo_geom(p, &g)) {
         const int tiles = (p.Co / 64) * (p.Kc / 64);
         g.ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, &g.cpb);
         const int npass = (g.NHP + 31) / 32;            // 3..5 (stride 1), up to 10 / 13 (stride 2)
@@ -864,7 +893,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         else if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 3>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
-        return vpd_launch_wgrad_reduce(p, stream);
+        return vpd_launch_wgrad_reduce(p0, stream);
     }
     const int tiles = (p.Co / 64) * (p.Kc / 64) * p.taps.nr * p.taps.nc;
     const int nchunks = (p.M + 127) / 128;

@@ -5,28 +5,38 @@
 
 // f32 [N][C][H][W] -> bf16 [N][Hp][Wp][Cp] interior (zero border is pre-set and never written).
 // A thread converts 4 consecutive pixels of a row: one float4 per channel plane in, four 16-byte pixels out.
+// CT: the channel count as a compile-time constant (3, 5, 6), or 0 = run-time C with CLAMPED unconditional loads -- a
+// per-channel "load or zero" on a run-time condition makes hipcc branch around every load and wait for each one
+// (54 us for 84 MB; /opt/skills/guides/cdna_hip_programming.md, "three .s-level traps" (c))
+template <int CT>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* x, int N, int C, int H, int W, bf16_t* out,
                                                          int Hp, int Wp, int pad, int Cp) {
     const int W4 = W >> 2;
     const long total = (long)N * H * W4;
     const long plane = (long)H * W;
+    const int Cn = CT ? CT : C;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
         const int b = (int)(it / ((long)H * W4));
         const long r4 = it - (long)b * H * W4;
         const int y = (int)(r4 / W4);
         const int x0 = (int)(r4 - (long)y * W4) << 2;
-        float v[4][8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[q][c] = 0.f;
-        // unrolled over the 8 channel slots (C <= 8 is a run-time value: a rolled loop indexes v[][c] dynamically, which
-        // sends it through scratch and serialises the plane loads -- 51 us for 84 MB); all loads go out before the packs
+        const float* src = x + (size_t)b * Cn * plane + (size_t)y * W + x0;
         float4 f[8];
+        if (CT) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            f[c] = c < C ? *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * plane + (size_t)y * W + x0)
-                         : float4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 8; ++c)
+                f[c] = c < CT ? *reinterpret_cast<const float4*>(src + (size_t)c * plane) : float4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int cc = c < Cn ? c : Cn - 1;
+                f[c] = *reinterpret_cast<const float4*>(src + (size_t)cc * plane);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c >= Cn) f[c] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+        float v[4][8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) { v[0][c] = f[c].x; v[1][c] = f[c].y; v[2][c] = f[c].z; v[3][c] = f[c].w; }
         bf16_t* dst = out + ((size_t)(b * Hp + y + pad) * Wp + x0 + pad) * Cp;
@@ -53,7 +63,8 @@ __global__ __launch_bounds__(256) void pack_input_px_kernel(const float* x, int 
 hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
                                  int Cp, hipStream_t s) {
     if (Cp != 8 || C > 8) return hipErrorInvalidValue;
-    const bool quad = (W & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+    static const int force_px = getenv("VPD_PACK_PX") ? atoi(getenv("VPD_PACK_PX")) : 0;
+    const bool quad = !force_px && (W & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
     long items = quad ? (long)N * H * (W / 4) : (long)N * H * W;
     long g = (items + 255) / 256;
     if (g > 8192) g = 8192;
@@ -61,7 +72,11 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
         hipLaunchKernelGGL(pack_input_px_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(pack_input_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+    const dim3 grid(g < 1 ? 1 : (int)g);
+    if (C == 5) hipLaunchKernelGGL(pack_input_kernel<5>, grid, dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+    else if (C == 3) hipLaunchKernelGGL(pack_input_kernel<3>, grid, dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+    else if (C == 6) hipLaunchKernelGGL(pack_input_kernel<6>, grid, dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+    else hipLaunchKernelGGL(pack_input_kernel<0>, grid, dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
     return hipGetLastError();
 }
 

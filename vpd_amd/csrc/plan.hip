@@ -177,7 +177,7 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     p->wg_elems += (long long)c.ntaps * Co * c.Kc;
     if (stem && p->train && p->slab_elems == 0)      // the stem wgrad's split slab (shared region, summed at once)
         p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
-    if (!stem && k == 3 && (stride == 1 || stride == 2) && p->train &&
+    if (!stem && ((k == 3 && pad == 1) || (k == 1 && pad == 0)) && (stride == 1 || stride == 2) && p->train &&
         vpd_wgrad_halo_shape_ok(c.Hout, c.Wout, stride, Hin, Win)) {
         // halo wgrad conv: ONE shared slab, summed right after each wgrad launch while it is still in the Infinity
         // Cache (per-conv slabs summed once per bucket were measured 4 % slower: 490 MB fall out of the cache)
@@ -447,7 +447,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             size_t stage_slab[4] = {0, 0, 0, 0};
             for (auto& B : p->blocks)
                 for (ConvInfo* cv : {&B.c1, &B.c2}) {
-                    if (cv->slab_off < 0 || cv->stride != 1) continue;      // (stride-2 halo wgrads: their own launch)
+                    if (cv->slab_off < 0 || cv->stride != 1 || cv->k != 3) continue;      // (stride-2 and 1x1 halo wgrads: their own launch)
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
                     cv->gslab_off = (long long)stage_slab[B.stage];
                     stage_slab[B.stage] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
@@ -673,7 +673,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
-    if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) return hipErrorInvalidValue;   // plan and launcher must agree
+    if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) q.slab = nullptr;      // (an A/B switch turned the halo form off: generic kernel)
     if (collect_zero) {                  // dry run at the start of backward: which ranges need zeroing
         if (!vpd_wgrad_overwrites(q) && collect_zero->count < ZR_MAX) {
             collect_zero->ptr[collect_zero->count] = q.dw;
@@ -688,7 +688,9 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     if (vpd_wgrad_overwrites(q) && !q.defer_reduce && !cv.stem) {      // time the MFMA kernel alone, then sum its slab
         hipError_t e;
         {
-            TimeScope ts(c.p, st, 5, conv_flops(cv, c.n));
+            // class 5 = the grouped per-stage launches (and single stride-1 halo launches); a stride-2 conv's own halo
+            // launch (two output tiles, 128 splits) is a different regime: class 6 with the other per-conv launches
+            TimeScope ts(c.p, st, cv.stride == 1 ? 5 : 6, conv_flops(cv, c.n));
             q.defer_reduce = 1;
             e = vpd_launch_wgrad(q, st);
         }
