@@ -290,6 +290,53 @@ def test_reset_parameters_matches_reference_init_statistics():
     assert enc6.embed(np.zeros((6, 64, 64), np.float32)).shape == (1, 32)
 
 
+_STEP_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r})
+from oracle import vpd_oracle as O
+from vpd_amd.models.rgb import RGBF_EmbeddingModel
+from vpd_amd.trainer import ModelTrainer
+sd = O.reference_init_state_dict("resnet34", 5, 32, 3)
+enc = RGBF_EmbeddingModel("resnet34", 32, True, "cuda")
+enc.load_state_dict(sd)
+tr = ModelTrainer(enc, False)
+g = torch.Generator(device="cuda").manual_seed(4)
+img = torch.randn((256, 5, 128, 128), generator=g, device="cuda")
+tgt = torch.randn((256, 32), generator=g, device="cuda")
+enc.train()
+loss = tr._forward_loss(img, tgt, train=True)
+loss.backward()
+torch.cuda.synchronize()
+assert enc.engine.sync_errors() == 0
+np.save({out!r}, enc.engine.grads.cpu().numpy())
+print("LOSS", loss.item())
+"""
+
+
+def test_dgrad_with_batchnorm_backward_in_its_epilogue(tmp_path):
+    """VPD_DGRAD_BN=1: the data-gradient launches of layers 3 / 4 carry the BatchNorm backward of their output in the
+    epilogue behind the in-launch grid barrier (ConvBnBwd; needs the full 256-crop batch: one block per CU).  Same
+    rounding points and formulas as the separate bn_bwd_fused_kernel, so the gradients of a whole ResNet-34 step must
+    agree with the default path to the level of summation order in the fp32 block sums (measured ~1e-6)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("g%s.npy" % flag))
+        env = dict(os.environ, VPD_DGRAD_BN=flag)
+        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
+    (g0, l0), (g1, l1) = outs
+    assert l0 == l1
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    # the untrained network amplifies last-bit differences (DESIGN.md, "Run-to-run reproducibility"): a direction + norm gate
+    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
+    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
+
+
 def _group_of(name):
     return "fc" if ".fc." in name else (name.split(".")[1] if name.split(".")[1].startswith("layer") else "stem")
 

@@ -907,7 +907,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
         for (int w = w0; w < 16; w += wstep) tot += red[(size_t)(w * 2 + which) * C + ch];
         atomicAdd(&f.rows[((size_t)(blockIdx.x & (VPD_FUSED_ROWS - 1)) * 2 + which) * C + ch], (double)tot);
     }
-    vpd_grid_barrier(f.sync, false, f.err);
+    vpd_grid_barrier(f.sync, false, f.err, blockIdx.x, gridDim.x);
     // ---- finalize: every block sums the rows of all channels (2*C*VPD_FUSED_ROWS doubles) ----
     for (int t = tid; t < 2 * C; t += T) {
         const int which = t / C;

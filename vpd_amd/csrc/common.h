@@ -95,6 +95,26 @@ struct ConvClass {
     TapSet taps;
 };
 
+// BatchNorm backward fused into the EPILOGUE of the data-gradient convolution that produces its input gradient
+// (conv3x3_ws_kernel only, grids of at most one block per CU): the accumulators hold d(activation); the epilogue masks
+// it (g), adds the per-channel sums of g and g * xhat to the BatchNorm's accumulator rows, crosses an in-launch grid
+// barrier (sync.h), finalizes its own channels and writes dz = c1 * (g - c2 - xhat * c3) straight into the padded dz
+// buffer -- d(activation) is never stored, and the separate BatchNorm-backward launch (13-24 us) disappears.
+//   mode 1: g = da * [scale * z + shift > 0]           (conv-BN-ReLU: the block's first BatchNorm)
+//   mode 2: da += old (read-modify-write of y, the identity path), g = da * [act > 0], g is written back to y
+//           (the block-output BatchNorm of the PREVIOUS block, whose ReLU follows the residual add)
+struct ConvBnBwd {
+    int mode;
+    const bf16_t* z;                            // dense [M][Co]: forward output of the BatchNorm's convolution
+    const float* mean; const float* rstd; const float* mscale; const float* mshift;
+    const bf16_t* act; int aHp, aWp, apad;      // mode 2: padded post-ReLU activation
+    const float* gamma; float* dgamma; float* dbeta;
+    double* rows;                               // [VPD_FUSED_ROWS][2][Co], zeroed
+    void* sync; unsigned* err;                  // GridSync (zeroed), sticky time-out counter
+    float count;
+    bf16_t* dz; int dzHp, dzWp, dzpad;          // output
+};
+
 // One implicit-GEMM convolution launch (forward conv, or data-gradient conv).
 // Output pixels are enumerated on a sub-grid (Hs x Ws per image); output pixel
 // (y, x) of the sub-grid lands at (y*osub+oph, x*osub+opw) of tensor Y and
@@ -116,6 +136,7 @@ struct ConvParams {
     int accumulate;                             // y += result
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
+    ConvBnBwd bnb;                              // conv3x3_ws_kernel only
     // gather kernel only: extra parity classes of a stride-2 data gradient, selected by blockIdx.z (class 0 is
     // described by the fields above); ncls == 0 or 1 means a single class
     int ncls;

@@ -408,7 +408,12 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
         __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
-        if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_epilogue
+        if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
+        if (EPM >= 4) {                                           // conv_epilogue_bnbwd: grid barrier (2) + coefficients (1)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
         return;
     }
 
@@ -464,13 +469,17 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         }
     }
     __builtin_amdgcn_s_barrier();                                 // END
-    float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
+    if constexpr (EPM >= 4) {
+        conv_epilogue_bnbwd<BM, BN, WM, WN, EPM == 5>(p, acc, mtile, n0, geo, smem);
+    } else {
+        float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
 #pragma unroll
-    for (int a = 0; a < BN / WN / 16; ++a)
+        for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-    conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
-    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
+            for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+        conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+        if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -770,6 +779,8 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
         case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 4: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 4, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 5: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 5, NS>), grid, dim3(512), lds, stream, q, g); break;
         default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3, NS>), grid, dim3(512), lds, stream, q, g); break;
     }
     return hipGetLastError();
@@ -863,8 +874,25 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
 }
 int vpd_conv_kernel_class(const ConvParams& p) { HaloGeom g; return vpd_conv_kernel_class(p, &g); }
 
+// true when `p` (with bnb.mode set) can run the fused data-gradient + BatchNorm-backward epilogue: a warp-specialised
+// kernel whose whole grid is resident (one block per CU)
+bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu) {
+    HaloGeom g;
+    const int kc = vpd_conv_kernel_class(p, &g);
+    // (the 256-pixel tile keeps 128 accumulator registers: the epilogue's kept g / z fragments spill there)
+    if (kc < 2 || kc > 3) return false;
+    const int bm = kc == 1 ? 256 : 128, bn = kc == 3 ? 64 : 128;
+    const long blocks = (long)((p.M + bm - 1) / bm) * (p.Co / bn);
+    return blocks <= ncu;
+}
+
 hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
+    if (p0.bnb.mode) {
+        HaloGeom gg;
+        const int kc = vpd_conv_kernel_class(p0, &gg);
+        if (kc < 2 || kc > 3) return hipErrorInvalidValue;        // the caller asks vpd_conv_bnbwd_ok first
+    }
     ConvParams p = p0;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     p.ablate = ablate;

@@ -59,6 +59,7 @@ struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
+bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu);     // fused dgrad + BatchNorm-backward epilogue (ConvBnBwd) possible
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);

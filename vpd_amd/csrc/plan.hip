@@ -609,7 +609,50 @@ hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) 
 }
 
 // data-gradient of a conv: dz (padded, border 1) -> dx (dense [n][Hin][Win][Ci])
-hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
+int device_cu_count() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 1;
+    }
+    return ncu;
+}
+
+// stride-1 data-gradient launch descriptor
+ConvParams conv_dgrad_s1_params(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
+    q.w = c.b16(c.p->arena_off) + cv.dgr_off;
+    q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
+    q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
+    // dx[y][x] = sum_{r,t} dz[y + pad - r][x + pad - t] W[r][t]; padded coord adds 1
+    q.Hs = cv.Hin; q.Ws = cv.Win; q.osub = 1; q.oph = 0; q.opw = 0;
+    q.M = c.n * q.Hs * q.Ws;
+    q.taps.nr = cv.k; q.taps.nc = cv.k;
+    q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
+    q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
+    return q;
+}
+
+// can the data gradient of `cv` carry a BatchNorm backward in its epilogue (ConvBnBwd) at this batch size?
+bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
+    // OFF by default: measured +0.4 % on the step (4.27 -> 4.25 ms, inside the box-to-box noise) -- a fused launch gets
+    // ~17 us longer where the separate bn_bwd_fused_kernel costs 15.5-17 us: the chain rows-atomics -> barrier arrival
+    // (two atomic hops) -> flag -> acquire -> row loads is ~8-10 us of dependent memory round trips wherever it runs, and
+    // only the launch itself (~3 us) and the store + load of d(activation) are saved.  VPD_DGRAD_BN=1 enables it;
+    // tests/test_model_gpu.py runs a step both ways.
+    static const bool on = getenv("VPD_DGRAD_BN") && atoi(getenv("VPD_DGRAD_BN"));
+    if (!on || !c.p->fused_bn || cv.stride != 1 || cv.k != 3 || cv.Ci > 1024) return false;
+    ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), 0);
+    q.bnb.mode = 1;
+    return vpd_conv_bnbwd_ok(q, device_cu_count());
+}
+
+// bnb: BatchNorm backward fused into this launch's epilogue (the caller has checked dgrad_takes_bn)
+hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
+                          const ConvBnBwd* bnb = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
@@ -618,15 +661,15 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
     hipError_t e = hipSuccess;
     if (cv.stride == 1) {
-        // dx[y][x] = sum_{r,t} dz[y + pad - r][x + pad - t] W[r][t]; padded coord adds 1
-        q.Hs = cv.Hin; q.Ws = cv.Win; q.osub = 1; q.oph = 0; q.opw = 0;
-        q.M = c.n * q.Hs * q.Ws;
-        q.taps.nr = cv.k; q.taps.nc = cv.k;
-        q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
-        q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
+        q = conv_dgrad_s1_params(c, cv, dz, dx, accumulate);
+        if (bnb) {
+            q.bnb = *bnb;
+            q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
+        }
         TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
+    if (bnb) return hipErrorInvalidValue;
     // stride 2: the four input-pixel parity classes are ONE launch (grid.z = class).  Only taps r with
     // (ph + pad - r) even contribute: r = rf, rf+2, ... reading dz row  y + (ph + pad - r)/2  (+1 for the border).
     TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
@@ -771,6 +814,24 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     }
     return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s,
                              reduce_done);
+}
+
+// ConvBnBwd of BatchNorm `bncv.bn` for a data-gradient launch whose output gradient is the BatchNorm's dy.
+// mode 1: ReLU mask recomputed from z; mode 2: mask from the padded activation `act` (residual block output).
+ConvBnBwd make_bnb(const Ctx& c, const ConvInfo& bncv, int mode, const bf16_t* act, bf16_t* dz, float* grads) {
+    ConvBnBwd f;
+    memset(&f, 0, sizeof f);
+    f.mode = mode;
+    f.z = c.b16(bncv.z_off);
+    f.mean = c.bn_mean(bncv.bn); f.rstd = c.bn_rstd(bncv.bn);
+    f.mscale = c.bn_scale(bncv.bn); f.mshift = c.bn_shift(bncv.bn);
+    f.act = act; f.aHp = bncv.Hout + 2; f.aWp = bncv.Wout + 2; f.apad = 1;
+    f.gamma = c.params + bncv.bn.w_off; f.dgamma = grads + bncv.bn.w_off; f.dbeta = grads + bncv.bn.b_off;
+    f.rows = c.bn_rows(bncv.bn); f.sync = c.ws + bncv.bn.sync_off;
+    f.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
+    f.count = (float)(c.n * bncv.Hout * bncv.Wout);
+    f.dz = dz; f.dzHp = bncv.Hout + 2; f.dzWp = bncv.Wout + 2; f.dzpad = 1;
+    return f;
 }
 
 #define LCHECK(expr)                                   \
@@ -1067,6 +1128,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         return 0;
     };
 
+    std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
         const StageInfo& S = p->stages[B.stage];
@@ -1106,13 +1168,18 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             }
             continue;
         }
-        // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout
-        LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
+        // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout.  Already done when the NEXT block's conv1
+        // data gradient (the previous iteration of this loop) carried it in its epilogue.
+        if (!bn2_fused_for[bi]) LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-        // (a variant that fused bn1's backward reduction into this dgrad's epilogue was measured 6 % SLOWER end to
-        //  end -- the extra epilogue code bloats every conv kernel -- and was removed)
-        LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
-        LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
+        if (dgrad_takes_bn(c, B.c2)) {
+            // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
+            const ConvBnBwd f = make_bnb(c, B.c1, 1, nullptr, dz1, grads);
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, nullptr, 0, &f));
+        } else {
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
+            LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
+        }
         LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
@@ -1121,6 +1188,14 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
             LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
             gi = (gi + 2) % 3;
+        } else if (bi > 0 && dgrad_takes_bn(c, B.c1)) {
+            // dout holds g: identity path + conv path = d(out) of the previous block, whose bn2 backward (ReLU mask from its
+            // stored output, g written back for ITS identity path) rides in this launch's epilogue
+            BlockInfo& Bp = p->blocks[bi - 1];
+            bf16_t* dz2p = c.b16(grouped && Bp.c2.dz_own_off ? Bp.c2.dz_own_off : S.dz2_off[(bi - 1) & 1]);
+            const ConvBnBwd f = make_bnb(c, Bp.c2, 2, c.b16(Bp.out_off), dz2p, grads);
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, &f));
+            bn2_fused_for[bi - 1] = true;
         } else {
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
         }

@@ -34,10 +34,11 @@ static __device__ __forceinline__ bool vpd_spin_until_nonzero(const unsigned* wo
     return true;
 }
 
-// Call from ALL threads of ALL blocks of a 1-D grid, exactly once per GridSync.  `release`: the block wrote data with
+// Call from ALL threads of ALL blocks of the grid, exactly once per GridSync.  `release`: the block wrote data with
 // plain stores that other blocks read after the barrier (agent-scope release = L2 write-back); atomics need none.
 // `err`: a sticky word (never re-zeroed by the launch sequence) that time-outs increment; read by vpd_plan_sync_errors.
-static __device__ __forceinline__ void vpd_grid_barrier(GridSync* gs, bool release, unsigned* err) {
+// `bid` / `nb`: this block's linear index and the number of blocks of the grid (any grid shape).
+static __device__ __forceinline__ void vpd_grid_barrier(GridSync* gs, bool release, unsigned* err, unsigned bid, unsigned nb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's stores / atomics have been performed
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -45,8 +46,7 @@ static __device__ __forceinline__ void vpd_grid_barrier(GridSync* gs, bool relea
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const unsigned nb = gridDim.x;
-        const unsigned g = blockIdx.x & 7u;
+        const unsigned g = bid & 7u;
         const unsigned in_group = (nb + 7u - g) >> 3;       // blocks b with b % 8 == g
         const unsigned ngroups = nb < 8u ? nb : 8u;
         const unsigned t = __hip_atomic_fetch_add(&gs->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
