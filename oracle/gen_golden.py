@@ -164,6 +164,9 @@ CASES = [
     ("wr50_c3_d32_m1_n6", "wide_resnet50_2", 3, 32, True, 6, 128, 5e-4),
     # BASELINE configs[2]: --motion two-stream, 6-channel input (SURVEY 8d runs C=6 in addition to C=5)
     ("r34_c6_d128_m1_n6", "resnet34", 6, 128, True, 6, 128, 5e-4),
+    # BASELINE configs[0] at its full size: 64 crops of 5x128x128, 128-d teacher embeddings (+ motion: 256-d targets), one
+    # (here: three) train step(s) of the reference on the CPU
+    ("c1_r34_c5_d128_m1_n64", "resnet34", 5, 128, True, 64, 128, 5e-4),
 ]
 TAP_BNS = ["resnet.bn1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1",
            "resnet.layer3.1.bn2", "resnet.layer4.1.bn2"]

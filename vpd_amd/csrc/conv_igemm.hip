@@ -846,7 +846,8 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 extern "C" int vpd_conv_bm(int M, int Co) {
     const int bn = (Co % 128 == 0) ? 128 : 64;
     if (bn == 128) {
-        if ((long)((M + 127) / 128) * (Co / 128) >= 384) return 128;
+        static const long thr = getenv("VPD_IGEMM_T128") ? atol(getenv("VPD_IGEMM_T128")) : 384;
+        if ((long)((M + 127) / 128) * (Co / 128) >= thr) return 128;
         return 64;
     }
     return 128;
