@@ -225,3 +225,46 @@ def test_stem_conv_and_wgrad():
         torch.cuda.synchronize()
         got = dw.cpu().view(7, co, 8, 8)[:, :, :7, :c].permute(1, 3, 0, 2)   # -> [co][c][r][t]
         assert rel_l2(got, wr.grad) < REL_TOL, use_slab
+
+
+WG128_GROUPS = {
+    # one launch each: (n, H, W, Co, Ci) per problem.  Different halo geometries share a launch (layer3 + layer4 shapes),
+    # ragged final chunks (n * H * W not a multiple of 64), several tiles per problem, pixel splits with a slab
+    "layer2_like": [(9, 16, 16, 128, 128), (9, 16, 16, 128, 128)],
+    "layer3_and_layer4_ragged": [(5, 8, 8, 256, 256), (5, 4, 4, 512, 512), (7, 8, 8, 256, 128)],
+    "layer1_wide_rows": [(3, 32, 32, 128, 64)],
+    "many_chunks_split": [(40, 16, 16, 128, 64), (33, 8, 8, 128, 128)],
+}
+
+
+@pytest.mark.parametrize("name", list(WG128_GROUPS), ids=list(WG128_GROUPS))
+def test_wgrad128_group(name):
+    """conv_wgrad128_persistent_kernel (128 x 64 tiles, persistent blocks, host-built schedule): every problem of a grouped
+    launch against torch's conv2d weight gradient on the same bf16-rounded operands."""
+    L = _lib()
+    probs = WG128_GROUPS[name]
+    g = torch.Generator().manual_seed(len(name))
+    keep, refs = [], []
+    dzs, xs, dws, slabs, dims = [], [], [], [], []
+    for (n, h, w, co, ci) in probs:
+        x = bf16_round(torch.randn(n, ci, h, w, generator=g))
+        dz = bf16_round(torch.randn(n, co, h, w, generator=g))
+        wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
+        F.conv2d(x, wr, None, stride=1, padding=1).backward(dz)
+        refs.append(wr.grad)
+        xp, dzp = to_padded_nhwc(x, 1, 1, 1, 1), to_padded_nhwc(dz, 1, 1, 1, 1)
+        dw = torch.full((9, co, ci), float("nan"), dtype=torch.float32, device="cuda")      # the kernel OVERWRITES
+        slab = torch.empty(max(int(L.vpd_op_wgrad128_slab_floats(co, ci)), 4), dtype=torch.float32, device="cuda")
+        keep += [xp, dzp, dw, slab]
+        dzs.append(dzp.data_ptr()); xs.append(xp.data_ptr()); dws.append(dw.data_ptr()); slabs.append(slab.data_ptr())
+        dims += [n, h, w, co, ci]
+    k = len(probs)
+    arr = lambda v: (C.c_void_p * k)(*v)
+    table = torch.empty(int(L.vpd_op_wgrad128_table_bytes()), dtype=torch.uint8, device="cuda")
+    _check(L.vpd_op_wgrad128_group(k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (5 * k))(*dims), ptr(table),
+                                   stream()))
+    torch.cuda.synchronize()
+    for i, (n, h, w, co, ci) in enumerate(probs):
+        got = keep[4 * i + 2].cpu().view(3, 3, co, ci).permute(2, 3, 0, 1)
+        assert torch.isfinite(got).all(), (name, i)
+        assert rel_l2(got, refs[i]) < REL_TOL, (name, i, rel_l2(got, refs[i]))

@@ -54,6 +54,9 @@ SIGNATURES = {
     "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp, vp]),
     "vpd_op_wgrad_slab_bytes": (C.c_size_t, []),
     "vpd_op_tr_read_probe": (C.c_int, [vp, vp, vp]),
+    "vpd_op_wgrad128_table_bytes": (C.c_size_t, []),
+    "vpd_op_wgrad128_slab_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "vpd_op_wgrad128_group": (C.c_int, [C.c_int, vp, vp, vp, vp, c_int_p, vp, vp]),
 }
 
 _lib = None

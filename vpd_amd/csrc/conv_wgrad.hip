@@ -13,9 +13,13 @@
 // 128-pixel chunks; the 4 waves split every chunk's pixels (32 each) and their
 // 64x64 partial tiles are summed through LDS before one fp32 atomic per
 // element.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <string.h>
+#include <algorithm>
+#include <utility>
+#include <vector>
 #include "common.h"
 
 static __device__ __forceinline__ int wg_swz(int r, int c16) {
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams 
 // carries 6-12 problems, which (1) pays the ~10 us fixed cost of a launch once instead of per layer, (2) gives the
 // chip thousands of blocks, so each block can take 4x more pixels and the split-K slab shrinks 4x (layer4 needs none:
 // its blocks write the gradient itself), and (3) leaves no one-block-per-CU tail between layers.
-#define WG_GROUP_MAX 12
+#define WG_GROUP_MAX 18
 struct WgGroup {
     int nprob;
     int xcd_remap;                             // 1: blocks of one XCD take CONSECUTIVE tasks (see the kernel)
@@ -908,6 +912,500 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     dim3 grid(tiles, ksplit);
     const size_t lds = 64 * 1024;     // max(staging 2*2*16 KiB, reduction 64 KiB)
     VPD_LAUNCH(conv_wgrad_kernel, grid, dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// 128(co) x 64(ci) weight-gradient tiles, persistent blocks with a host-built schedule ("wg2").
+//
+// Why: the grouped 64 x 64 kernel above is bound by its operand stream, not by the matrix cores -- every launch moves
+// 24-28 KB of LDS-DMA per 64-pixel chunk and tile, and the chip delivers ~5.4 TB/s of such traffic however many CUs ask
+// (layer2's group: 1.2 us per chunk on 256 CUs; layer3's: 0.74 us on the 176 CUs it fills; 0.55 us is the MFMA time).
+// A 128 x 64 tile reads the x halo ONCE for twice the output channels: 16 KB of dz + 13-18 KB of halo per chunk for
+// twice the FLOPs (-35 % bytes per FLOP).  Its accumulators (9 taps x 128 x 64 fp32 = 288 KB) need all 512 registers of
+// every SIMD lane, so there are no loader waves: 8 waves (two per SIMD, 144 accumulator registers each: ci tile =
+// wave & 3, co half = wave >> 2) issue their own share of the LDS-DMA right after the chunk barrier and then run
+// 72 MFMAs per chunk; a 4-stage ring keeps two chunks in flight.
+// Scheduling: a launch takes the weight gradients of one or MORE ResNet stages (layer4's wait for layer3's: 160 + 176
+// tasks of equal length fill the 256 CUs exactly where each stage alone leaves a third of the chip idle).  The host
+// picks a uniform pixel split per problem with a cost model, orders the (problem, split, tile) tasks longest first and
+// deals them to the least loaded block (LPT), blocks of one XCD taking consecutive tasks (the tiles that share pixels
+// then stream from that XCD's L2); block b runs its list from a table in device memory.
+// ---------------------------------------------------------------------------
+#define WG2_NS 4
+#define WG2_MAX 18
+struct Wg2Group {
+    int nprob;
+    const int4* tasks;                         // device: (problem, tile, split, -)
+    const int* blk_begin;                      // device: [grid + 1] first task of each block
+    int stage_elems;                           // bf16 elements per ring stage (dz 128 x 64 + the largest halo)
+    int skew;                                  // see wg2_task
+    WgradParams p[WG2_MAX];
+    WgHaloGeom g[WG2_MAX];
+};
+
+template <int N>
+static __device__ __forceinline__ void wg2_waitcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+static __device__ __forceinline__ void wg2_wait_allow(int n) {      // n: wave-uniform, one of 0, k, 2k with k in 3..5
+    switch (n) {
+        case 0: wg2_waitcnt<0>(); break;
+        case 3: wg2_waitcnt<3>(); break;
+        case 4: wg2_waitcnt<4>(); break;
+        case 5: wg2_waitcnt<5>(); break;
+        case 6: wg2_waitcnt<6>(); break;
+        case 8: wg2_waitcnt<8>(); break;
+        case 10: wg2_waitcnt<10>(); break;
+        default: wg2_waitcnt<0>(); break;
+    }
+}
+
+// LDS-DMA of 16 bytes per lane (1 KiB per wave) as inline assembly.  The builtin would make hipcc's wait-count pass put
+// s_waitcnt vmcnt(0) in front of the first ds_read that follows it in program order -- a wave that both streams and
+// computes would then wait for the tile it has JUST requested before touching the one that landed two chunks ago.  The
+// assembly form is opaque to that pass; the kernel's own counted vmcnt waits + the chunk barrier order the ring.
+static __device__ __forceinline__ void wg2_lds_dma16(const void* gsrc, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+
+template <bool PIPE>
+static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHaloGeom& g, int tile, int split,
+                                                bf16_t* ring, int STAGE, int skew) {
+    constexpr int NS = WG2_NS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
+    const int ctile = wave & 3, cohalf = wave >> 2;
+    const int W = p.Ws, H = p.Hs, Wp = p.xWp;
+    const int kct = p.Kc >> 6;
+    const int co0 = (tile / kct) * 128;
+    const int ci0 = (tile % kct) * 64;
+    const int nchunks_total = (p.M + WG_CH - 1) / WG_CH;
+    const int chunk_begin = split * g.cpb;
+    int chunk_end = chunk_begin + g.cpb;
+    chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
+    const int nch = chunk_end - chunk_begin;
+    const int nhi = (g.NHP + 7) >> 3;                                 // halo LDS-DMA instructions per chunk (8 pixels each)
+    const int nh_mine = (nhi - wave + 7) >> 3;                        // this wave's: wave, wave + 8, ...
+    const int per = 2 + nh_mine;                                      // its LDS-DMA instructions per chunk (3..5)
+
+    // ---- LDS-DMA side: chunk-invariant per-lane element offsets (32-bit), the chunk's part is wave-uniform (64-bit) ----
+    const int piece = lane & 7, lrow = lane >> 3;
+    const int TR = g.TR;
+    const int cpi = g.multi ? 1 : H / TR;                             // chunks per image (non-multi)
+    const int ipc = g.multi ? TR / H : 1;                             // images per chunk (multi)
+    int zlane[2], zrow[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = wave * 2 + k;                                   // dz instruction: co half i >> 3 (= cohalf), rows (i & 7) * 8 ..
+        const int row = (i & 7) * 8 + lrow;
+        const int lr = row / W, xx = row - lr * W;
+        const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+        const int img = g.multi ? lr / H : 0, yy = g.multi ? lr % H : lr;
+        zlane[k] = ((img * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cohalf * 64 + cpc * 8;
+        zrow[k] = row;
+    }
+    int hlane[3];                                                     // (pixel << 8) | channel piece offset: hp < 2^8 * ..., cpc * 8 < 64
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int hp = (wave + 8 * k) * 8 + lrow;
+        const int cpc = (((piece >> 1) ^ wg_f(hp)) << 1) | (piece & 1);
+        hlane[k] = (hp << 8) | (cpc * 8);
+    }
+    // running position of the NEXT chunk to issue
+    int is_c = 0;                                                     // chunks issued so far
+    int is_b, is_y;                                                   // image index and first output row (non-multi) of that chunk
+    {
+        const int ch = chunk_begin;
+        if (g.multi) { is_b = ch * ipc; is_y = 0; }
+        else { is_b = ch / cpi; is_y = (ch - is_b * cpi) * TR; }
+    }
+    const unsigned ring_lds = (unsigned)(size_t)(wg_lptr_t)ring;      // LDS byte address of the ring
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int ch = chunk_begin + is_c;
+        const unsigned st_lds = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((is_c & (NS - 1)) * STAGE * 2));
+        const bf16_t* zb = p.dz + ((size_t)is_b * p.dzHp + is_y) * p.dzWp * p.dzC;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wave * 2 + k;
+            const bf16_t* src = (ch * WG_CH + zrow[k] < p.M) ? zb + zlane[k]
+                                                             : p.dz + (zlane[k] & 63);      // zero border pixel (0, 0) of image 0
+            wg2_lds_dma16(src, st_lds + (unsigned)(i * 8 * 64 * 2));
+        }
+        const int gp0 = (is_b * p.xHp + is_y) * Wp;
+        const bf16_t* xb = p.x + ci0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k < nh_mine) {
+                int gp = gp0 + (hlane[k] >> 8);
+                gp = gp < g.total_pix ? gp : g.total_pix - 1;
+                const bf16_t* src = xb + (size_t)gp * p.xC + (hlane[k] & 255);
+                wg2_lds_dma16(src, st_lds + (unsigned)((128 + (wave + 8 * k) * 8) * 64 * 2));
+            }
+        }
+        ++is_c;
+        if (g.multi) is_b += ipc;
+        else { is_y += TR; if (is_y >= H) { is_y = 0; ++is_b; } }
+    };
+
+    // ---- MFMA side: chunk-invariant LDS BYTE offsets (within a stage) of this lane's transposed reads.  A (dz) operand:
+    // co tile a only changes the 32-byte granule, offA(a) = offA(0) ^ (a << 5); B (x halo) operand: one offset per k-step,
+    // tap and 4-row half, two 16-bit values per register (a stage is < 64 KiB). ----
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    int offA0[2];
+    unsigned offB[2][9];                                              // [ks][tap]: low half h = 0, high half h = 1
+    {
+        const int ra = 8 * gq + q;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = ra + 4 * h;
+            offA0[h] = 2 * (cohalf * 64 * 64 + r * 64 + ((wg_f(r) << 4) | (4 * pp)));
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            int hmv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pk = 32 * ks + 8 * gq + 4 * h + q;
+                const int lr = pk / W;
+                const int xx = pk - lr * W;
+                const int hrow = g.multi ? (lr / H) * p.xHp + (lr % H) : lr;
+                hmv[h] = hrow * Wp + xx;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                unsigned v = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = hmv[h] + (p.taps.dy0 + (t / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (t % 3) * p.taps.dxs);
+                    const unsigned o = 2u * (unsigned)(128 * 64 + r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));
+                    v |= o << (16 * h);
+                }
+                offB[ks][t] = v;
+            }
+        }
+    }
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    typedef const char __attribute__((address_space(3))) * lds_cp;
+    auto frag2 = [&](lds_cp a0, lds_cp a1) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // every wave is done with the previous task's ring (and its stores are on their way) before new tiles land in it
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (k < nch) issue();
+    for (int c = 0; c < nch; ++c) {
+        // this wave's share of chunk c has landed when at most its instructions of the younger chunks are outstanding
+        int ahead = nch - 1 - c;
+        ahead = ahead < NS - 2 ? ahead : NS - 2;
+        wg2_wait_allow(ahead * per);
+        __builtin_amdgcn_s_barrier();                                 // READY_c: all shares landed; everyone finished chunk c-1
+        // chunk c + NS - 1 goes into the stage chunk c - 1 used.  skew: the second wave of every SIMD requests its share
+        // between the two k-steps instead, so that the two waves stop running their read / MFMA phases in lockstep
+        const bool do_issue = is_c < nch;
+        if (do_issue && !(skew && cohalf)) issue();
+        const lds_cp sb = (lds_cp)(const char*)(ring + (c & (NS - 1)) * STAGE);
+        // Explicit software pipeline of the LDS reads (pinned with sched_barrier: left alone, hipcc waits for every B
+        // fragment right before its four MFMAs): the A fragments of both k-steps are resident (the second set is read
+        // during the first k-step's last taps), the B fragment of tap t + 2 is requested before the MFMAs of tap t.
+        auto ldA = [&](int ks, int a) __attribute__((always_inline)) {
+            const lds_cp a0 = sb + ks * 32 * 128 + offA0[0], a1 = sb + ks * 32 * 128 + offA0[1];
+            return frag2((lds_cp)((unsigned)(size_t)a0 ^ (unsigned)(a << 5)), (lds_cp)((unsigned)(size_t)a1 ^ (unsigned)(a << 5)));
+        };
+        auto ldB = [&](int ks, int t) __attribute__((always_inline)) {
+            const unsigned v = offB[ks][t];
+            return frag2(sb + (v & 0xffffu), sb + (v >> 16));
+        };
+        if constexpr (PIPE) {
+            bf16x8 az[2][4], bx[3];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) az[0][a] = ldA(0, a);
+            bx[0] = ldB(0, 0);
+            bx[1] = ldB(0, 1);
+#pragma unroll
+            for (int s18 = 0; s18 < 18; ++s18) {                      // (k-step, tap) pairs in order
+                const int ks = s18 / 9, t = s18 - ks * 9;
+                if (s18 == 9 && do_issue && skew && cohalf) issue();
+                if (s18 + 2 < 18) bx[(s18 + 2) % 3] = ldB((s18 + 2) / 9, (s18 + 2) % 9);
+                if (ks == 0 && t >= 5) az[1][t - 5] = ldA(1, t - 5);  // taps 5..8 of the first k-step: one A fragment each
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[s18 % 3], acc[t][a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // hipcc's own schedule of the same work
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && do_issue && skew && cohalf) issue();
+                bf16x8 az[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) az[a] = ldA(ks, a);
+#pragma unroll
+                for (int tg = 0; tg < 3; ++tg) {
+                    bf16x8 bx[3];
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) bx[u] = ldB(ks, tg * 3 + u);
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+                            acc[tg * 3 + u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[tg * 3 + u][a], 0, 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (already true after the last chunk's wait: belt and braces)
+    // acc[t][a][j] = partial dW[tap t][co0 + 64*cohalf + a*16 + 4*gq + j][ci0 + 16*ctile + i16]
+    float* out = g.ksplit > 1 ? p.slab + (size_t)split * 9 * p.Co * p.Kc : p.dw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
+        float* o = out + ((size_t)wsl * p.Co + co0 + cohalf * 64) * p.Kc + ci0 + 16 * ctile + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
+    }
+}
+
+template <bool PIPE>
+__global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2Group grp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
+    const int t0 = grp.blk_begin[blockIdx.x], t1 = grp.blk_begin[blockIdx.x + 1];
+    for (int t = t0; t < t1; ++t) {
+        const int4 tk = grp.tasks[t];
+        const int pi = __builtin_amdgcn_readfirstlane(tk.x);
+        wg2_task<PIPE>(grp.p[pi], grp.g[pi], __builtin_amdgcn_readfirstlane(tk.y), __builtin_amdgcn_readfirstlane(tk.z), ring,
+                 grp.stage_elems, grp.skew);
+    }
+}
+
+// ---- host side: eligibility, split choice, LPT schedule ----
+bool vpd_wgrad128_eligible(const WgradParams& p) {
+    static const int off = getenv("VPD_WG2") ? !atoi(getenv("VPD_WG2")) : 0;
+    WgHaloGeom g;
+    WgradParams q = p;
+    if (!q.slab) q.slab = reinterpret_cast<float*>(16);
+    if (off || p.Co % 128 != 0 || p.Kc % 64 != 0 || p.istr != 1 || p.one_by_one || p.dzpad < 1 || p.dzC % 128 != 0) return false;
+    if (!(vpd_wgrad_overwrites(q) && wg_halo_geom(q, &g))) return false;
+    return (g.NHP + 7) / 8 <= 24;
+}
+
+struct Wg2Schedule {
+    std::vector<int> tasks;        // 4 ints per task
+    std::vector<int> blk_begin;    // grid + 1
+    int ksplit[WG2_MAX];
+    int grid = 0;
+    double est_us = 0.0;
+};
+
+// makespan of the LPT deal of `len` (task lengths, any order) over G blocks; optionally the assignment
+static double wg2_lpt(const std::vector<std::pair<double, int>>& sorted, int G, const std::vector<int>& order,
+                      std::vector<int>* owner) {
+    std::vector<double> load(G, 0.0);
+    if (owner) owner->assign(sorted.size(), 0);
+    for (size_t i = 0; i < sorted.size(); ++i) {
+        int best = order[0];
+        for (int k = 1; k < G; ++k) {
+            const int b = order[k];
+            if (load[b] < load[best] - 1e-9) best = b;
+        }
+        load[best] += sorted[i].first;
+        if (owner) (*owner)[i] = best;
+    }
+    double mx = 0.0;
+    for (double v : load) mx = v > mx ? v : mx;
+    return mx;
+}
+
+static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G, Wg2Schedule* out) {
+    // block order: the blocks of XCD 0 first (b = 0, 8, 16, ...), then XCD 1, ...: equal-length tasks are dealt in task order
+    // to equally loaded blocks, so consecutive tasks (the tiles of one pixel range) land on one XCD
+    std::vector<int> order;
+    for (int x = 0; x < 8; ++x)
+        for (int b = x; b < G; b += 8) order.push_back(b);
+    int nch[WG2_MAX], tiles[WG2_MAX], cap[WG2_MAX];
+    for (int i = 0; i < n; ++i) {
+        nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
+        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / 64);
+        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc);
+        if (cap[i] > nch[i]) cap[i] = nch[i];
+    }
+    // per-chunk time of a 128 x 64 task: the larger of the MFMA time (1.15 us) and the stream (16 KB + halo at ~21 GB/s
+    // per CU when every CU streams); per-task fixed cost; slab bytes written and read back at 4.5 TB/s
+    const double t_fixed = 5.0, bw = 4.5e6;
+    static const int cpb_env = getenv("VPD_WG2_CPB") ? atoi(getenv("VPD_WG2_CPB")) : 0;
+    double best = 1e30;
+    int best_ks[WG2_MAX];
+    auto tchunk = [&](int i) { const double st = (16.0 + (gs[i].NHP + 7) / 8) / 21.0; return st > 1.15 ? st : 1.15; };
+    auto eval = [&](double target) {
+        int ks[WG2_MAX];
+        std::vector<std::pair<double, int>> tl;
+        double slab = 0.0;
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            int k = (int)(nch[i] / target + 0.5);
+            k = k < 1 ? 1 : (k > cap[i] ? cap[i] : k);
+            const int cpb = (nch[i] + k - 1) / k;
+            k = (nch[i] + cpb - 1) / cpb;
+            ks[i] = k;
+            for (int s = 0; s < k; ++s) {
+                const int c1 = (s + 1) * cpb < nch[i] ? (s + 1) * cpb : nch[i];
+                for (int t = 0; t < tiles[i]; ++t) tl.push_back({(c1 - s * cpb) * tchunk(i) + t_fixed, 0});
+            }
+            if (k > 1) { slab += (double)k * 9 * ps[i].Co * ps[i].Kc * 4; any = true; }
+        }
+        std::stable_sort(tl.begin(), tl.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+        const double cost = wg2_lpt(tl, G, order, nullptr) + 2.0 * slab / bw + (any ? 3.0 : 0.0);
+        if (cost < best) { best = cost; for (int i = 0; i < n; ++i) best_ks[i] = ks[i]; }
+    };
+    if (cpb_env > 0) eval((double)cpb_env);
+    else for (int cpb = 8; cpb <= 1024; cpb += (cpb < 128 ? 2 : 8)) eval((double)cpb);
+    // final task list: problem-major, split-major, tile-fastest; stable sort by length (longest first); LPT deal
+    struct T { int prob, tile, split; };
+    std::vector<T> tv;
+    std::vector<std::pair<double, int>> tl;
+    for (int i = 0; i < n; ++i) {
+        const int k = best_ks[i];
+        const int cpb = (nch[i] + k - 1) / k;
+        out->ksplit[i] = k;
+        for (int s = 0; s < k; ++s) {
+            const int c1 = (s + 1) * cpb < nch[i] ? (s + 1) * cpb : nch[i];
+            for (int t = 0; t < tiles[i]; ++t) {
+                tl.push_back({(c1 - s * cpb) * tchunk(i) + t_fixed, (int)tv.size()});
+                tv.push_back({i, t, s});
+            }
+        }
+    }
+    std::stable_sort(tl.begin(), tl.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+    std::vector<int> owner;
+    out->est_us = wg2_lpt(tl, G, order, &owner);
+    std::vector<std::vector<int>> per(G);
+    for (size_t i = 0; i < tl.size(); ++i) per[owner[i]].push_back(tl[i].second);
+    out->tasks.clear();
+    out->blk_begin.assign(G + 1, 0);
+    for (int b = 0; b < G; ++b) {
+        out->blk_begin[b] = (int)out->tasks.size() / 4;
+        for (int id : per[b]) {
+            out->tasks.push_back(tv[id].prob); out->tasks.push_back(tv[id].tile);
+            out->tasks.push_back(tv[id].split); out->tasks.push_back(0);
+        }
+    }
+    out->blk_begin[G] = (int)out->tasks.size() / 4;
+    out->grid = G;
+}
+
+size_t vpd_wgrad128_table_bytes() { return (size_t)1 << 17; }       // device table of one launch: tasks + block index
+
+// One launch for `n` eligible problems (ps[i].slab: vpd_wgrad_group_slab_floats() floats of its own).  `cache` (may be
+// null) keeps the schedule between calls with the same shapes; `dev_table` is vpd_wgrad128_table_bytes() of device
+// memory owned by the caller for THIS group (re-uploaded, stream-ordered, only when the shapes change).
+struct Wg2Cache {
+    int n = 0;
+    int sig[WG2_MAX][4];
+    const void* uploaded_to = nullptr;
+    Wg2Schedule sch;
+};
+void* vpd_wgrad128_cache_new() { return new Wg2Cache(); }
+void vpd_wgrad128_cache_free(void* c) { delete static_cast<Wg2Cache*>(c); }
+
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream) {
+    if (n < 1 || n > WG2_MAX || !dev_table) return hipErrorInvalidValue;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
+    }
+    Wg2Group grp = {};
+    WgReduceGroup red = {};
+    grp.nprob = n;
+    int nhi_max = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!vpd_wgrad128_eligible(ps[i])) return hipErrorInvalidValue;
+        grp.p[i] = ps[i];
+        if (!wg_halo_geom(ps[i], &grp.g[i])) return hipErrorInvalidValue;
+        const int nhi = (grp.g[i].NHP + 7) / 8;
+        nhi_max = nhi > nhi_max ? nhi : nhi_max;
+    }
+    Wg2Cache local;
+    Wg2Cache* c = cache_v ? static_cast<Wg2Cache*>(cache_v) : &local;
+    bool same = c->n == n && c->uploaded_to == dev_table;
+    for (int i = 0; i < n && same; ++i)
+        same = c->sig[i][0] == ps[i].M && c->sig[i][1] == ps[i].Co && c->sig[i][2] == ps[i].Kc && c->sig[i][3] == grp.g[i].NHP;
+    if (!same) {
+        wg2_build(ps, grp.g, n, ncu, &c->sch);
+        c->n = n;
+        if (getenv("VPD_WG2_DEBUG")) {
+            int mx = 0, mn = 1 << 30;
+            for (int b = 0; b < c->sch.grid; ++b) {
+                const int k = c->sch.blk_begin[b + 1] - c->sch.blk_begin[b];
+                mx = k > mx ? k : mx; mn = k < mn ? k : mn;
+            }
+            fprintf(stderr, "wg2 schedule: %d problems, %d tasks on %d blocks (%d..%d per block), est %.1f us; splits:", n,
+                    (int)c->sch.tasks.size() / 4, c->sch.grid, mn, mx, c->sch.est_us);
+            for (int i = 0; i < n; ++i) fprintf(stderr, " %d", c->sch.ksplit[i]);
+            fprintf(stderr, "\n");
+        }
+        for (int i = 0; i < n; ++i) { c->sig[i][0] = ps[i].M; c->sig[i][1] = ps[i].Co; c->sig[i][2] = ps[i].Kc; c->sig[i][3] = grp.g[i].NHP; }
+        const size_t tb = c->sch.tasks.size() * sizeof(int), bb = c->sch.blk_begin.size() * sizeof(int);
+        if (tb + bb + 64 > vpd_wgrad128_table_bytes()) return hipErrorInvalidValue;
+        hipError_t e = hipMemcpyAsync(dev_table, c->sch.tasks.data(), tb, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync((char*)dev_table + ((tb + 63) & ~(size_t)63), c->sch.blk_begin.data(), bb, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        if (!cache_v) { e = hipStreamSynchronize(stream); if (e != hipSuccess) return e; }      // `local` dies with this call
+        c->uploaded_to = dev_table;
+    }
+    const Wg2Schedule& sch = c->sch;
+    grp.tasks = reinterpret_cast<const int4*>(dev_table);
+    grp.blk_begin = reinterpret_cast<const int*>((char*)dev_table + ((sch.tasks.size() * sizeof(int) + 63) & ~(size_t)63));
+    grp.stage_elems = (128 + 8 * nhi_max) * 64;
+    // skew on: same-box A/B 490 -> 458 us per step for the class (profiles/r02_negative_results.txt has the variants)
+    static const int skew = getenv("VPD_WG2_SKEW") ? atoi(getenv("VPD_WG2_SKEW")) : 1;
+    grp.skew = skew;
+    int max_ks = 1;
+    long max_n4 = 0;
+    for (int i = 0; i < n; ++i) {
+        WgHaloGeom& g = grp.g[i];
+        const int nchunks = (ps[i].M + WG_CH - 1) / WG_CH;
+        g.ksplit = sch.ksplit[i];
+        g.cpb = (nchunks + g.ksplit - 1) / g.ksplit;
+        if (g.ksplit > 1) {
+            red.slab[red.nprob] = reinterpret_cast<const float4*>(ps[i].slab);
+            red.dw[red.nprob] = reinterpret_cast<float4*>(ps[i].dw);
+            red.n4[red.nprob] = (long)9 * ps[i].Co * ps[i].Kc / 4;
+            red.ksplit[red.nprob] = g.ksplit;
+            max_n4 = red.n4[red.nprob] > max_n4 ? red.n4[red.nprob] : max_n4;
+            max_ks = g.ksplit > max_ks ? g.ksplit : max_ks;
+            ++red.nprob;
+            if (red.nprob > WG_GROUP_MAX) return hipErrorInvalidValue;
+        }
+    }
+    const size_t lds = (size_t)WG2_NS * grp.stage_elems * sizeof(bf16_t);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static const int pipe = getenv("VPD_WG2_PIPE") ? atoi(getenv("VPD_WG2_PIPE")) : 0;
+    if (pipe) VPD_LAUNCH(conv_wgrad128_persistent_kernel<true>, dim3(sch.grid), dim3(512), lds, stream, grp);
+    else VPD_LAUNCH(conv_wgrad128_persistent_kernel<false>, dim3(sch.grid), dim3(512), lds, stream, grp);
+    if (red.nprob > 0) {
+        const int groups = max_ks < 16 ? max_ks : 16;
+        hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),
+                           0, stream, red, groups);
+    }
     return hipGetLastError();
 }
 

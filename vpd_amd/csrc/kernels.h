@@ -69,6 +69,12 @@ bool vpd_wgrad_group_eligible(const WgradParams& p);
 size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc);
 hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
 bool vpd_wgrad_overwrites(const WgradParams& p);
+// 128 x 64 tiles, persistent blocks, host-built schedule (conv_wgrad128_persistent_kernel in conv_wgrad.hip)
+bool vpd_wgrad128_eligible(const WgradParams& p);
+size_t vpd_wgrad128_table_bytes();
+void* vpd_wgrad128_cache_new();
+void vpd_wgrad128_cache_free(void* cache);
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache, void* dev_table, hipStream_t stream);
 bool vpd_wgrad_halo_shape_ok(int Hout, int Wout, int stride = 1, int Hin = 0, int Win = 0);
 
 hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,

@@ -123,7 +123,10 @@ struct vpd_plan {
     size_t fused_off = 0, fused_bytes = 0;      // rows + barrier words of every BatchNorm: zeroed at the start of each pass
     size_t syncerr_off = 0;                     // sticky counter of grid-barrier time-outs (zeroed by init_workspace only)
     bool wg_group = true;       // per-stage grouped weight gradients (VPD_WG_GROUP=0: one launch per conv)
-    size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest stage
+    size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest launch group
+    bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0: per stage)
+    size_t wg2_tbl_off[4] = {0, 0, 0, 0};      // task tables of the 128 x 64 persistent weight-gradient launches (one per stage)
+    void* wg2_cache[4] = {nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
     bool timing = false;
     struct TimedLaunch { int cls; double flops; hipEvent_t a, b; };
@@ -443,18 +446,22 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         // grouped weight gradients: every eligible 3x3 stride-1 conv keeps its own dz until the
         // stage's grouped launch; the stage's slab holds every problem's splits at once
         p->wg_group = !(getenv("VPD_WG_GROUP") && !atoi(getenv("VPD_WG_GROUP")));
+        p->wg_merge34 = !(getenv("VPD_WG_MERGE") && !atoi(getenv("VPD_WG_MERGE")));
         if (p->wg_group) {
+            // slabs of one LAUNCH live side by side: with wg_merge34 the stages 2 and 3 (layer3, layer4) share a launch
             size_t stage_slab[4] = {0, 0, 0, 0};
             for (auto& B : p->blocks)
                 for (ConvInfo* cv : {&B.c1, &B.c2}) {
                     if (cv->slab_off < 0 || cv->stride != 1 || cv->k != 3) continue;      // (stride-2 and 1x1 halo wgrads: their own launch)
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
-                    cv->gslab_off = (long long)stage_slab[B.stage];
-                    stage_slab[B.stage] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
+                    const int grp = (p->wg_merge34 && B.stage == 3) ? 2 : B.stage;
+                    cv->gslab_off = (long long)stage_slab[grp];
+                    stage_slab[grp] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
                 }
             size_t mx = 16;
             for (int s2 = 0; s2 < 4; ++s2) mx = stage_slab[s2] > mx ? stage_slab[s2] : mx;
             p->gslab_off = bp.take(mx * 4);
+            for (int s2 = 0; s2 < 4; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
@@ -479,6 +486,8 @@ extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
     }
     for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i)
+        if (p->wg2_cache[i]) vpd_wgrad128_cache_free(p->wg2_cache[i]);
     delete p;
 }
 
@@ -1077,35 +1086,57 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     const bool grouped = p->wg_group;
     struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
     std::vector<Pending> pending;
-    auto flush_group = [&]() -> hipError_t {
+    auto make_q = [&](const Pending& pd) {
+        const ConvInfo& cv = *pd.cv;
+        WgradParams q;
+        memset(&q, 0, sizeof q);
+        q.dz = pd.dz; q.dzHp = cv.Hout + 2; q.dzWp = cv.Wout + 2; q.dzC = cv.Co; q.dzpad = 1;
+        q.x = pd.x; q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci;
+        q.dw = c.f32(p->wg_off) + cv.wg_off;
+        q.slab = c.f32(p->gslab_off) + cv.gslab_off;
+        q.N = n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
+        q.M = n * cv.Hout * cv.Wout;
+        q.taps = conv_taps_fwd(cv);
+        return q;
+    };
+    // `slot`: the stage whose table / schedule cache the 128 x 64 launch uses
+    auto flush_group = [&](int slot) -> hipError_t {
         if (pending.empty()) return hipSuccess;
-        WgradParams qs[12];
-        double flops = 0.0;
-        size_t done = 0;
         hipError_t r = hipSuccess;
-        while (done < pending.size() && r == hipSuccess) {
-            const int cnt = (int)std::min<size_t>(12, pending.size() - done);
-            flops = 0.0;
+        // 128 x 64 tiles (conv_wgrad128_persistent_kernel) for every conv that has them: one launch
+        std::vector<Pending> rest;
+        {
+            WgradParams qs[18];
+            int cnt = 0;
+            double flops = 0.0;
+            for (const Pending& pd : pending) {
+                const WgradParams q = make_q(pd);
+                if (cnt < 18 && vpd_wgrad128_eligible(q)) { qs[cnt++] = q; flops += conv_flops(*pd.cv, n); }
+                else rest.push_back(pd);
+            }
+            if (cnt > 0) {
+                if (!p->wg2_cache[slot]) p->wg2_cache[slot] = vpd_wgrad128_cache_new();
+                TimeScope ts(p, s, 5, flops);
+                r = vpd_launch_wgrad128_group(qs, cnt, p->wg2_cache[slot], ws + p->wg2_tbl_off[slot], s);
+            }
+        }
+        size_t done = 0;
+        while (done < rest.size() && r == hipSuccess) {
+            WgradParams qs[12];
+            const int cnt = (int)std::min<size_t>(12, rest.size() - done);
+            double flops = 0.0;
+            // one launch of the 64 x 64 grouped kernel: one halo geometry (stage)
+            int take = 0;
             for (int i = 0; i < cnt; ++i) {
-                const Pending& pd = pending[done + i];
-                const ConvInfo& cv = *pd.cv;
-                WgradParams q;
-                memset(&q, 0, sizeof q);
-                q.dz = pd.dz; q.dzHp = cv.Hout + 2; q.dzWp = cv.Wout + 2; q.dzC = cv.Co; q.dzpad = 1;
-                q.x = pd.x; q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci;
-                q.dw = c.f32(p->wg_off) + cv.wg_off;
-                q.slab = c.f32(p->gslab_off) + cv.gslab_off;
-                q.N = n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
-                q.M = n * cv.Hout * cv.Wout;
-                q.taps = conv_taps_fwd(cv);
-                qs[i] = q;
-                flops += conv_flops(cv, n);
+                if (i > 0 && rest[done + i].cv->Hout != rest[done].cv->Hout) break;
+                qs[take++] = make_q(rest[done + i]);
+                flops += conv_flops(*rest[done + i].cv, n);
             }
             {
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad_group(qs, cnt, s);
+                r = vpd_launch_wgrad_group(qs, take, s);
             }
-            done += cnt;
+            done += take;
         }
         pending.clear();
         return r;
@@ -1128,6 +1159,23 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         return 0;
     };
 
+    // End of a stage's backward (called after every block): launch the stage's grouped weight gradients and hand its
+    // gradient bucket over -- except that layer4's (stage 3) wait for layer3's when wg_merge34: one launch then carries both
+    // stages (their tasks fill the chip together where each stage alone leaves CUs idle), and bucket 0 follows it.
+    std::vector<int> deferred_buckets;
+    auto stage_end = [&](int bi) -> int {
+        const BlockInfo& B = p->blocks[bi];
+        const bool last_of_stage = bi == 0 || p->blocks[bi - 1].stage != B.stage;
+        if (!last_of_stage) return 0;
+        const bool defer = grouped && p->wg_merge34 && B.stage == 3 && bi > 0;
+        if (defer) { deferred_buckets.push_back(3 - B.stage); return 0; }
+        LCHECK(flush_group(B.stage));
+        for (int b : deferred_buckets)
+            if (unpack_bucket(b)) return -1;
+        deferred_buckets.clear();
+        if (bi > 0) return unpack_bucket(3 - B.stage);
+        return 0;
+    };
     std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
@@ -1162,10 +1210,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             } else {
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
             }
-            if (bi == 0 || p->blocks[bi - 1].stage != B.stage) LCHECK(flush_group());      // the stage's weight gradients
-            if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
-                if (unpack_bucket(3 - B.stage)) return -1;
-            }
+            if (stage_end(bi)) return -1;
             continue;
         }
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout.  Already done when the NEXT block's conv1
@@ -1199,10 +1244,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         } else {
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
         }
-        if (bi == 0 || p->blocks[bi - 1].stage != B.stage) LCHECK(flush_group());      // the stage's weight gradients
-        if (bi > 0 && p->blocks[bi - 1].stage != B.stage) {
-            if (unpack_bucket(3 - B.stage)) return -1;
-        }
+        if (stage_end(bi)) return -1;
     }
     // ---- stem ----
     {
@@ -1386,5 +1428,33 @@ extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int
     q.taps = tapset_from(tapset9);
     if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
     LCHECK(vpd_launch_wgrad(q, (hipStream_t)stream));
+    return 0;
+}
+
+// Grouped 128 x 64 weight gradients (conv_wgrad128_persistent_kernel) of `nprob` 3x3 stride-1 pad-1 convolutions in ONE
+// launch.  dims: 5 ints per problem {n, H, W, Co, Ci}; dz[i]: padded bf16 [n][H+2][W+2][Co]; x[i]: padded bf16
+// [n][H+2][W+2][Ci]; dw[i]: fp32 [9][Co][Ci]; slab[i]: fp32 scratch of vpd_op_wgrad128_slab_floats(Co, Ci) floats;
+// dev_table: vpd_op_wgrad128_table_bytes() of device memory.
+extern "C" size_t vpd_op_wgrad128_table_bytes(void) { return vpd_wgrad128_table_bytes(); }
+extern "C" size_t vpd_op_wgrad128_slab_floats(int Co, int Ci) { return vpd_wgrad_group_slab_floats(0, Co, Ci); }
+extern "C" int vpd_op_wgrad128_group(int nprob, const void* const* dz, const void* const* x, float* const* dw,
+                                     float* const* slab, const int* dims, void* dev_table, void* stream) {
+    if (nprob < 1 || nprob > 18 || !dz || !x || !dw || !slab || !dims || !dev_table) return fail("bad argument");
+    WgradParams qs[18];
+    for (int i = 0; i < nprob; ++i) {
+        const int n = dims[5 * i], H = dims[5 * i + 1], W = dims[5 * i + 2], Co = dims[5 * i + 3], Ci = dims[5 * i + 4];
+        WgradParams q;
+        memset(&q, 0, sizeof q);
+        q.dz = (const bf16_t*)dz[i]; q.dzHp = H + 2; q.dzWp = W + 2; q.dzC = Co; q.dzpad = 1;
+        q.x = (const bf16_t*)x[i]; q.xHp = H + 2; q.xWp = W + 2; q.xC = Ci;
+        q.dw = dw[i]; q.slab = slab[i];
+        q.N = n; q.Hs = H; q.Ws = W; q.istr = 1; q.Kc = Ci; q.Co = Co; q.M = n * H * W;
+        q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
+        q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
+        if (!vpd_wgrad128_eligible(q)) return fail("shape not eligible for the 128 x 64 weight-gradient kernel");
+        qs[i] = q;
+    }
+    static void* cache = vpd_wgrad128_cache_new();      // one schedule cache for the op entry point (rebuilt when shapes change)
+    LCHECK(vpd_launch_wgrad128_group(qs, nprob, cache, dev_table, (hipStream_t)stream));
     return 0;
 }
