@@ -141,6 +141,14 @@ struct ConvParams {
     // described by the fields above); ncls == 0 or 1 means a single class
     int ncls;
     ConvClass cls[3];
+    // gather kernel only: a SECOND convolution of the same input with the same output geometry and channel count in the
+    // same launch (a BasicBlock's 1x1 down-sampling branch beside its first 3x3): the blocks with blockIdx.y >= alt_y0
+    // compute it -- own weights, taps, output, statistics rows and eval epilogue
+    const bf16_t* alt_w; bf16_t* alt_y; double* alt_stats; int alt_y0; TapSet alt_taps;
+    const float* alt_ep_scale; const float* alt_ep_shift; int alt_ep_relu;
+    // gather kernel only: extra K-steps of class 0 from a second input tensor of the same geometry and channel count
+    // (the data gradient of the down-sampling branch lands on the even-even pixels, i.e. on class 0 of the 3x3's)
+    const bf16_t* x2; const bf16_t* w2; int Kc2;
 };
 
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the

@@ -18,7 +18,7 @@
 #include "conv_epilogue.h"
 
 template <int BM, int BN, int WM, int WN, int EPM>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p0) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM;          // pixels per wave
     constexpr int WTN = BN / WN;          // channels per wave
@@ -37,14 +37,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     const int wm = wave % WM;
     const int wn = wave / WM;
     const int mtile = blockIdx.x;
-    const int n0 = blockIdx.y * BN;
+    // second convolution of the launch (ConvParams::alt_*): these blocks see it as THE convolution
+    ConvParams p = p0;
+    int by = blockIdx.y;
+    if (p0.alt_w && by >= p0.alt_y0) {
+        by -= p0.alt_y0;
+        p.w = p0.alt_w; p.y = p0.alt_y; p.stats = p0.alt_stats; p.taps = p0.alt_taps;
+        p.ep_scale = p0.alt_ep_scale; p.ep_shift = p0.alt_ep_shift; p.ep_relu = p0.alt_ep_relu; p.res = nullptr;
+    }
+    const int n0 = by * BN;
     const int m0 = mtile * BM;
     // parity class of a merged stride-2 data gradient (blockIdx.z); class 0 lives in the top-level fields
     ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     TapSet taps = p.taps;
     // heaviest class first: the classes come in ascending tap count (1, 2, 2, 4 taps for a 3x3 kernel) and blocks are
     // dispatched z-slowest, so walking them backwards keeps the 4-tap blocks out of the tail of the launch
-    switch ((int)gridDim.z - 1 - (int)blockIdx.z) {
+    const int cls = (int)gridDim.z - 1 - (int)blockIdx.z;
+    switch (cls) {
         case 1: geo = p.cls[0].geo; taps = p.cls[0].taps; break;
         case 2: geo = p.cls[1].geo; taps = p.cls[1].taps; break;
         case 3: geo = p.cls[2].geo; taps = p.cls[2].taps; break;
@@ -69,23 +78,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
         pixbase[i] = ((b * p.xHp + yy * p.istr) * p.xWp + xx * p.istr) * p.xC + piece * 8;
     }
     const int kchunks = p.Kc >> 6;
-    const int nsteps = taps.nr * taps.nc * kchunks;
+    const int nsteps1 = taps.nr * taps.nc * kchunks;
+    // class 0 only: extra K-steps from the second input tensor (same pixels, first tap's offset, its own weights)
+    const int nsteps = nsteps1 + ((p.x2 && cls == 0) ? (p.Kc2 >> 6) : 0);
 
     u32x4 rp[PR], rw[WR];
     auto load_step = [&](int s) __attribute__((always_inline)) {
-        const int tap = s / kchunks;
-        const int cc = s - tap * kchunks;
-        const int ir = tap / taps.nc;
-        const int ic = tap - ir * taps.nc;
-        const int toff = ((taps.dy0 + ir * taps.dys) * p.xWp + (taps.dx0 + ic * taps.dxs)) * p.xC + cc * 64;
-        const int wsl = taps.w0 + ir * taps.wrs + ic * taps.wcs;
+        const bf16_t* xs = p.x;
+        const bf16_t* wb;
+        int toff, wstride;
+        if (s < nsteps1) {
+            const int tap = s / kchunks;
+            const int cc = s - tap * kchunks;
+            const int ir = tap / taps.nc;
+            const int ic = tap - ir * taps.nc;
+            toff = ((taps.dy0 + ir * taps.dys) * p.xWp + (taps.dx0 + ic * taps.dxs)) * p.xC + cc * 64;
+            const int wsl = taps.w0 + ir * taps.wrs + ic * taps.wcs;
+            wb = p.w + ((size_t)wsl * p.Co + n0) * p.Kc + cc * 64 + piece * 8;
+            wstride = p.Kc;
+        } else {
+            const int cc = s - nsteps1;
+            xs = p.x2;
+            toff = (taps.dy0 * p.xWp + taps.dx0) * p.xC + cc * 64;
+            wb = p.w2 + (size_t)n0 * p.Kc2 + cc * 64 + piece * 8;
+            wstride = p.Kc2;
+        }
 #pragma unroll
         for (int i = 0; i < PR; ++i)
-            rp[i] = *reinterpret_cast<const u32x4*>(p.x + pixbase[i] + toff);
-        const bf16_t* wb = p.w + ((size_t)wsl * p.Co + n0) * p.Kc + cc * 64 + piece * 8;
+            rp[i] = *reinterpret_cast<const u32x4*>(xs + pixbase[i] + toff);
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            rw[i] = *reinterpret_cast<const u32x4*>(wb + (size_t)(row0 + 32 * i) * p.Kc);
+            rw[i] = *reinterpret_cast<const u32x4*>(wb + (size_t)(row0 + 32 * i) * wstride);
     };
     auto store_step = [&](int buf) __attribute__((always_inline)) {
         bf16_t* dP = sP + buf * BM * 64;
@@ -830,9 +853,10 @@ template <int BM, int BN, int WM, int WN>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     int maxM = p.M;
     for (int k = 1; k < p.ncls; ++k) maxM = p.cls[k - 1].geo.M > maxM ? p.cls[k - 1].geo.M : maxM;
-    dim3 grid((maxM + BM - 1) / BM, p.Co / BN, p.ncls > 1 ? p.ncls : 1);
-    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
     ConvParams q = p;
+    if (q.alt_w) q.alt_y0 = p.Co / BN;      // the second convolution's blocks follow the first's
+    dim3 grid((maxM + BM - 1) / BM, (p.Co / BN) * (q.alt_w ? 2 : 1), p.ncls > 1 ? p.ncls : 1);
+    const size_t lds = (size_t)2 * (BM + BN) * 64 * sizeof(bf16_t);
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
         case 1: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
@@ -860,6 +884,7 @@ extern "C" int vpd_conv_bm(int M, int Co) {
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
     static const int no_ws = getenv("VPD_NO_WS") ? atoi(getenv("VPD_NO_WS")) : 0;
     int tr_stem;
+    if (p.alt_w || p.x2) return 4;                             // two convolutions / two inputs in one launch: gather kernel only
     if (!no_ws && stem_eligible(p, &tr_stem)) return 5;        // conv_stem_persistent_kernel
     if (halo_eligible(p) && !no_ws) {
         if (p.Co % 128 == 0) {
@@ -910,7 +935,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     }
     // the statistics accumulator rows only depend on the block index, so the tile choice is free
     const int bm = vpd_conv_bm(p.M, p.Co);
-    if (halo_eligible(p)) {
+    if (halo_eligible(p) && !p.alt_w && !p.x2) {
         if (p.Co % 128 == 0) {
             if (bm == 128 && halo_geom(p, 128, 224, &g))
                 return p.Kc > 128 ? launch_halo<128, 128, 224, true>(p, g, stream)

@@ -585,8 +585,21 @@ inline double conv_flops(const ConvInfo& cv, int n) {      // algorithmic: real 
 }
 
 // forward convolution launch; input padded activation `x` (border 1; stem: xin), output `y`
+// second convolution of the same launch (ConvParams::alt_*): a BasicBlock's 1x1 down-sampling branch beside its first 3x3
+struct AltConv { const ConvInfo* cv; bf16_t* y; const float* ep_scale; const float* ep_shift; int ep_relu; };
+// can `cd` ride in `c1`'s launch?  Same input, same output geometry and channel count; train mode needs per-BatchNorm
+// statistics rows (the shared rows serve one conv at a time).  VPD_DS_MERGE=0 keeps the two launches.
+bool conv_pair_ok(const Ctx& c, const ConvInfo& c1, const ConvInfo& cd, bool train) {
+    static const bool off = getenv("VPD_DS_MERGE") && !atoi(getenv("VPD_DS_MERGE"));
+    if (off || c.p->bottleneck || c1.k != 3 || cd.k != 1 || c1.stride != 2 || cd.stride != 2) return false;
+    if (c1.Hin != cd.Hin || c1.Win != cd.Win || c1.Hout != cd.Hout || c1.Wout != cd.Wout || c1.Ci != cd.Ci || c1.Co != cd.Co)
+        return false;
+    return !train || (c.fused(c1) && c.fused(cd));
+}
+
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
-                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu) {
+                        const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
+                        const AltConv* alt = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -601,8 +614,16 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
+    double flops = conv_flops(cv, c.n);
+    if (alt) {
+        const ConvInfo& av = *alt->cv;
+        q.alt_w = c.b16(c.p->arena_off) + av.fwd_off; q.alt_y = alt->y; q.alt_taps = conv_taps_fwd(av);
+        q.alt_stats = stats ? c.bn_rows(av.bn) : nullptr;
+        q.alt_ep_scale = alt->ep_scale; q.alt_ep_shift = alt->ep_shift; q.alt_ep_relu = alt->ep_relu;
+        flops += conv_flops(av, c.n);
+    }
     const int kc = vpd_conv_kernel_class(q);
-    TimeScope ts(c.p, c.s, kc == 5 ? 7 : kc, conv_flops(cv, c.n));      // slot 7: stem kernel (5, 6 are the wgrads)
+    TimeScope ts(c.p, c.s, kc == 5 ? 7 : kc, flops);      // slot 7: stem kernel (5, 6 are the wgrads)
     return vpd_launch_conv(q, c.s);
 }
 
@@ -660,8 +681,10 @@ bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
 }
 
 // bnb: BatchNorm backward fused into this launch's epilogue (the caller has checked dgrad_takes_bn)
+// ds / dzd: the block's 1x1 stride-2 down-sampling conv and its dz -- its data gradient lands on the even-even input pixels,
+// which are class 0 of the 3x3's: extra K-steps of those blocks instead of a read-modify-write launch of its own
 hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
-                          const ConvBnBwd* bnb = nullptr) {
+                          const ConvBnBwd* bnb = nullptr, const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
@@ -681,7 +704,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     if (bnb) return hipErrorInvalidValue;
     // stride 2: the four input-pixel parity classes are ONE launch (grid.z = class).  Only taps r with
     // (ph + pad - r) even contribute: r = rf, rf+2, ... reading dz row  y + (ph + pad - r)/2  (+1 for the border).
-    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n) + (ds ? conv_flops(*ds, c.n) : 0.0));
     q.osub = 2;
     int ncls = 0;
     for (int ph = 0; ph < 2; ++ph)
@@ -707,6 +730,10 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         }
     if (ncls == 0) return hipSuccess;
     q.ncls = ncls;
+    if (ds) {
+        if (q.oph != 0 || q.opw != 0 || q.taps.nr != 1 || q.taps.nc != 1 || ds->Co != cv.Co) return hipErrorInvalidValue;
+        q.x2 = dzd; q.w2 = c.b16(c.p->arena_off) + ds->dgr_off; q.Kc2 = ds->Co;
+    }
     return vpd_launch_conv(q, c.s);
 }
 
@@ -903,7 +930,13 @@ int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, fl
     for (auto& B : p->blocks) {
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
-        LCHECK(run_conv_fwd(c, B.c1, cur, a1, 1, false, c.bn_escale(B.c1.bn), c.bn_eshift(B.c1.bn), nullptr, 1));
+        const bool pair = B.ds && conv_pair_ok(c, B.c1, B.cd, false);
+        if (pair) {      // the down-sampling 1x1 rides in conv1's launch
+            const AltConv alt{&B.cd, c.b16(p->stages[B.stage].idn_off), c.bn_escale(B.cd.bn), c.bn_eshift(B.cd.bn), 0};
+            LCHECK(run_conv_fwd(c, B.c1, cur, a1, 1, false, c.bn_escale(B.c1.bn), c.bn_eshift(B.c1.bn), nullptr, 1, &alt));
+        } else {
+            LCHECK(run_conv_fwd(c, B.c1, cur, a1, 1, false, c.bn_escale(B.c1.bn), c.bn_eshift(B.c1.bn), nullptr, 1));
+        }
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_fwd(c, B.c2, a1, a2, 1, false, c.bn_escale(B.c2.bn), c.bn_eshift(B.c2.bn), nullptr, 1));
@@ -920,7 +953,7 @@ int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, fl
         const bf16_t* idn = cur;
         if (B.ds) {
             bf16_t* idb = c.b16(p->stages[B.stage].idn_off);
-            LCHECK(run_conv_fwd(c, B.cd, cur, idb, 1, false, c.bn_escale(B.cd.bn), c.bn_eshift(B.cd.bn), nullptr, 0));
+            if (!pair) LCHECK(run_conv_fwd(c, B.cd, cur, idb, 1, false, c.bn_escale(B.cd.bn), c.bn_eshift(B.cd.bn), nullptr, 0));
             idn = idb;
         }
         LCHECK(run_conv_fwd(c, B.c2, a1, outp, 1, false, c.bn_escale(B.c2.bn), c.bn_eshift(B.c2.bn), idn, 1));
@@ -993,7 +1026,13 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
     for (auto& B : p->blocks) {
         bf16_t* a1 = c.b16(B.a1_off);
         bf16_t* outp = c.b16(B.out_off);
-        LCHECK(run_conv_train(c, B.c1, cur, bn_running));
+        const bool pair = B.ds && conv_pair_ok(c, B.c1, B.cd, true);
+        if (pair) {      // conv1 and the down-sampling 1x1 in one launch (both read `cur`; statistics to their own rows)
+            const AltConv alt{&B.cd, c.b16(B.cd.z_off), nullptr, nullptr, 0};
+            LCHECK(run_conv_fwd(c, B.c1, cur, c.b16(B.c1.z_off), 0, true, nullptr, nullptr, nullptr, 0, &alt));
+        } else {
+            LCHECK(run_conv_train(c, B.c1, cur, bn_running));
+        }
         LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
@@ -1011,7 +1050,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         }
         LCHECK(run_conv_train(c, B.c2, a1, bn_running));
         if (B.ds) {
-            LCHECK(run_conv_train(c, B.cd, cur, bn_running));
+            if (!pair) LCHECK(run_conv_train(c, B.cd, cur, bn_running));
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
         } else {
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 1, cur, nullptr, outp, 1));
@@ -1230,8 +1269,13 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
             LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
             LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
-            LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
-            LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
+            if (conv_pair_ok(c, B.c1, B.cd, true)) {
+                // one launch: the 1x1 branch's data gradient is extra K-steps of the even-even class
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0, nullptr, &B.cd, dzd));
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
+                LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
+            }
             gi = (gi + 2) % 3;
         } else if (bi > 0 && dgrad_takes_bn(c, B.c1)) {
             // dout holds g: identity path + conv path = d(out) of the previous block, whose bn2 backward (ReLU mask from its
