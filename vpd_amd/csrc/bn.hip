@@ -959,6 +959,190 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
 #undef LD8
 }
 
+// Two BatchNorm backwards that share their output gradient in one launch: the block-output BatchNorm of a down-sampling
+// BasicBlock (A: conv2's, ReLU mask from the stored block output) and the BatchNorm of its 1x1 branch (B: no ReLU of its
+// own, fed with the same masked gradient g).  One read of dy / act, three sums per channel (sum g shared), one grid
+// barrier, two dz outputs; g itself is not needed afterwards (both paths continue through convolutions).
+struct BnFusedBwd2Args {
+    double* rowsA; double* rowsB;              // [VPD_FUSED_ROWS][2][C] each, zeroed: A = (sum g, sum g xhatA), B = (-, sum g xhatB)
+    GridSync* sync; unsigned* err;
+    const bf16_t* zB; const float* meanB; const float* rstdB;
+    const float* gammaA; float* dgammaA; float* dbetaA;
+    const float* gammaB; float* dgammaB; float* dbetaB;
+    bf16_t* dzB;                               // same padded geometry as p.dz
+    float count;
+    int keep_g, keep_zA, keep_zB, iters;
+};
+
+__global__ __launch_bounds__(1024) void bn_bwd_fused2_kernel(const BnBwdParams p, const BnFusedBwd2Args f) {
+    extern __shared__ uint4 smem4[];
+    const int T = 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = p.C, cv = C >> 3;
+    const int ppi = T / cv;
+    const int c8 = tid % cv, pl = tid / cv, c = c8 << 3;
+    const int HW = p.H * p.W;
+    uint4* sG = smem4;
+    uint4* sZA = sG + (f.keep_g ? (size_t)f.iters * T : 0);
+    uint4* sZB = sZA + (f.keep_zA ? (size_t)f.iters * T : 0);
+    float* red = reinterpret_cast<float*>(sZB + (f.keep_zB ? (size_t)f.iters * T : 0));      // [16 waves][3][C], then coef [3][C]
+
+    float muA[8], rsA[8], muB[8], rsB[8], a1[8], a2[8], a3[8];
+#define LD8(dst, src) \
+    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src); \
+    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(src + 4);
+    LD8(muA, p.mean + c) LD8(rsA, p.rstd + c) LD8(muB, f.meanB + c) LD8(rsB, f.rstdB + c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; a3[j] = 0.f; }
+    const int mbeg = blockIdx.x * p.ppb;
+    int mend = mbeg + p.ppb;
+    mend = mend < p.M ? mend : p.M;
+    int it = 0;
+    for (int m = mbeg + pl; m < mend; m += ppi, ++it) {
+        float g[8], zA[8], zB[8], a[8];
+        const uint4 zAr = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c);
+        const uint4 zBr = *reinterpret_cast<const uint4*>(f.zB + (size_t)m * C + c);
+        uint4 gr = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c);
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        unpack8(*reinterpret_cast<const uint4*>(p.act + ((size_t)(b * p.aHp + y + p.apad) * p.aWp + x + p.apad) * C + c), a);
+        unpack8(gr, g); unpack8(zAr, zA); unpack8(zBr, zB);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+        gr = pack8(g);                                      // exact: g is dy or 0
+        if (f.keep_g) sG[(size_t)it * T + tid] = gr;
+        else *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * C + c) = gr;      // parked in dy itself (this thread re-reads it)
+        if (f.keep_zA) sZA[(size_t)it * T + tid] = zAr;
+        if (f.keep_zB) sZB[(size_t)it * T + tid] = zBr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a1[j] += g[j];
+            a2[j] += g[j] * ((zA[j] - muA[j]) * rsA[j]);
+            a3[j] += g[j] * ((zB[j] - muB[j]) * rsB[j]);
+        }
+    }
+    if (cv < 64) {
+        for (int o = cv; o < 64; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); a3[j] += __shfl_xor(a3[j], o, 64);
+            }
+        }
+    }
+    if (lane < cv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(size_t)(wave * 3 + 0) * C + c + j] = a1[j];
+            red[(size_t)(wave * 3 + 1) * C + c + j] = a2[j];
+            red[(size_t)(wave * 3 + 2) * C + c + j] = a3[j];
+        }
+    }
+    __syncthreads();
+    const int wstep = cv <= 64 ? 1 : cv / 64;
+    for (int t = tid; t < 3 * C; t += T) {
+        const int which = t / C;
+        const int ch = t - which * C;
+        const int w0 = cv <= 64 ? 0 : (ch >> 3) / 64;
+        float tot = 0.f;
+        for (int w = w0; w < 16; w += wstep) tot += red[(size_t)(w * 3 + which) * C + ch];
+        double* rows = which == 2 ? f.rowsB : f.rowsA;
+        const int slot = which == 2 ? 1 : which;
+        atomicAdd(&rows[((size_t)(blockIdx.x & (VPD_FUSED_ROWS - 1)) * 2 + slot) * C + ch], (double)tot);
+    }
+    vpd_grid_barrier(f.sync, false, f.err, blockIdx.x, gridDim.x);
+    for (int t = tid; t < 3 * C; t += T) {
+        const int which = t / C;
+        const int ch = t - which * C;
+        const double* rows = which == 2 ? f.rowsB : f.rowsA;
+        const int slot = which == 2 ? 1 : which;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < VPD_FUSED_ROWS; ++r)
+            s += __hip_atomic_load(&rows[((size_t)r * 2 + slot) * C + ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[t] = (float)(s / (double)f.count);
+        if (blockIdx.x == 0) {
+            if (which == 0) { f.dbetaA[ch] = (float)s; f.dbetaB[ch] = (float)s; }
+            else if (which == 1) f.dgammaA[ch] = (float)s;
+            else f.dgammaB[ch] = (float)s;
+        }
+    }
+    __syncthreads();
+    float c1A[8], c1B[8], c2[8], c3A[8], c3B[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        c1A[j] = f.gammaA[c + j] * rsA[j];
+        c1B[j] = f.gammaB[c + j] * rsB[j];
+        c2[j] = red[c + j];
+        c3A[j] = red[C + c + j];
+        c3B[j] = red[2 * C + c + j];
+    }
+    it = 0;
+    for (int m = mbeg + pl; m < mend; m += ppi, ++it) {
+        float g[8], zA[8], zB[8];
+        unpack8(f.keep_zA ? sZA[(size_t)it * T + tid] : *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c), zA);
+        unpack8(f.keep_zB ? sZB[(size_t)it * T + tid] : *reinterpret_cast<const uint4*>(f.zB + (size_t)m * C + c), zB);
+        unpack8(f.keep_g ? sG[(size_t)it * T + tid] : *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c), g);
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float oA[8], oB[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            oA[j] = c1A[j] * (g[j] - c2[j] - (zA[j] - muA[j]) * rsA[j] * c3A[j]);
+            oB[j] = c1B[j] * (g[j] - c2[j] - (zB[j] - muB[j]) * rsB[j] * c3B[j]);
+        }
+        const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
+        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(oA);
+        *reinterpret_cast<uint4*>(f.dzB + oo) = pack8(oB);
+    }
+#undef LD8
+}
+
+bool vpd_bn_bwd_fused2_ok(int M, int C) {
+    static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
+    static const int off2 = getenv("VPD_BN_PAIR") ? !atoi(getenv("VPD_BN_PAIR")) : 0;
+    return !(off || off2 || C % 8 || C < 64 || C > 1024 || 1024 % (C / 8)) && M >= 1;
+}
+
+// p: BatchNorm A as for vpd_launch_bn_bwd_fused (dy, act, z, mean, rstd, dz + geometry); fA / fB: rows, gamma, dgamma, dbeta
+// of the two BatchNorms (fA.sync / err / count are used); zB / meanB / rstdB / dzB: BatchNorm B's tensors
+hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p0, const BnFusedBwd& fA, const BnFusedBwd& fB, const bf16_t* zB,
+                                    const float* meanB, const float* rstdB, bf16_t* dzB, hipStream_t s) {
+    BnBwdParams p = p0;
+    if (!p.act) return hipErrorInvalidValue;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
+    }
+    const int cv = p.C / 8, ppi = 1024 / cv;
+    int G = ncu;
+    int ppb = (p.M + G - 1) / G;
+    ppb = ((ppb + ppi - 1) / ppi) * ppi;
+    G = (p.M + ppb - 1) / ppb;
+    p.ppb = ppb;
+    BnFusedBwd2Args f;
+    f.rowsA = fA.rows; f.rowsB = fB.rows; f.sync = reinterpret_cast<GridSync*>(fA.sync); f.err = fA.err;
+    f.zB = zB; f.meanB = meanB; f.rstdB = rstdB;
+    f.gammaA = fA.gamma; f.dgammaA = fA.dgamma; f.dbetaA = fA.dbeta;
+    f.gammaB = fB.gamma; f.dgammaB = fB.dgamma; f.dbetaB = fB.dbeta;
+    f.dzB = dzB; f.count = fA.count;
+    f.iters = ppb / ppi;
+    const size_t red_bytes = (size_t)16 * 3 * p.C * sizeof(float);
+    const size_t tile = (size_t)f.iters * 1024 * 16;
+    const size_t cap = 160 * 1024;
+    f.keep_g = red_bytes + tile <= cap;
+    f.keep_zA = f.keep_g && red_bytes + 2 * tile <= cap;
+    f.keep_zB = f.keep_zA && red_bytes + 3 * tile <= cap;
+    const size_t lds = red_bytes + (f.keep_g ? tile : 0) + (f.keep_zA ? tile : 0) + (f.keep_zB ? tile : 0);
+    hipLaunchKernelGGL(bn_bwd_fused2_kernel, dim3(G), dim3(1024), lds, s, p, f);
+    return hipGetLastError();
+}
+
 // false: this shape has to take the three-launch path (vpd_launch_bn_bwd)
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g) {
     static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;

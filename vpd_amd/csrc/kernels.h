@@ -106,6 +106,10 @@ struct BnFusedBwd {
 hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f, hipStream_t s);
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
+// two BatchNorm backwards sharing dy and the ReLU mask (a down-sampling block's conv2 BN + its 1x1 branch's BN) in one launch
+bool vpd_bn_bwd_fused2_ok(int M, int C);
+hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p, const BnFusedBwd& fA, const BnFusedBwd& fB, const bf16_t* zB,
+                                    const float* meanB, const float* rstdB, bf16_t* dzB, hipStream_t s);
 
 // head.hip
 hipError_t vpd_launch_avgpool(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, float* pooled,

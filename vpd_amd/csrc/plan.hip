@@ -1254,7 +1254,29 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         }
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout.  Already done when the NEXT block's conv1
         // data gradient (the previous iteration of this loop) carried it in its epilogue.
-        if (!bn2_fused_for[bi]) LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
+        bool bn_pair = false;      // conv2's BatchNorm and the 1x1 branch's BatchNorm in one launch (same dy, same ReLU mask)
+        if (B.ds && !bn2_fused_for[bi] && c.fused(B.c2) && c.fused(B.cd) && B.c2.Co == B.cd.Co &&
+            vpd_bn_bwd_fused2_ok(n * B.c2.Hout * B.c2.Wout, B.c2.Co)) {
+            BnBwdParams b;
+            memset(&b, 0, sizeof b);
+            b.dy = dout; b.dy_rw = dout; b.z = c.b16(B.c2.z_off);
+            b.act = c.b16(B.out_off); b.aHp = B.c2.Hout + 2; b.aWp = B.c2.Wout + 2; b.apad = 1;
+            b.mean = c.bn_mean(B.c2.bn); b.rstd = c.bn_rstd(B.c2.bn);
+            b.dz = dz2; b.dzHp = B.c2.Hout + 2; b.dzWp = B.c2.Wout + 2; b.dzpad = 1;
+            b.M = n * B.c2.Hout * B.c2.Wout; b.H = B.c2.Hout; b.W = B.c2.Wout; b.C = B.c2.Co;
+            BnFusedBwd fA, fB;
+            fA.rows = c.bn_rows(B.c2.bn); fA.sync = c.ws + B.c2.bn.sync_off;
+            fA.err = reinterpret_cast<unsigned*>(c.ws + p->syncerr_off);
+            fA.gamma = params + B.c2.bn.w_off; fA.dgamma = grads + B.c2.bn.w_off; fA.dbeta = grads + B.c2.bn.b_off;
+            fA.count = (float)b.M;
+            fB = fA;
+            fB.rows = c.bn_rows(B.cd.bn);
+            fB.gamma = params + B.cd.bn.w_off; fB.dgamma = grads + B.cd.bn.w_off; fB.dbeta = grads + B.cd.bn.b_off;
+            LCHECK(vpd_launch_bn_bwd_fused2(b, fA, fB, c.b16(B.cd.z_off), c.bn_mean(B.cd.bn), c.bn_rstd(B.cd.bn),
+                                            c.b16(S.dzd_off), s));
+            bn_pair = true;
+        }
+        if (!bn2_fused_for[bi] && !bn_pair) LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         if (dgrad_takes_bn(c, B.c2)) {
             // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
@@ -1267,7 +1289,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
-            LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
+            if (!bn_pair) LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
             LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
             if (conv_pair_ok(c, B.c1, B.cd, true)) {
                 // one launch: the 1x1 branch's data gradient is extra K-steps of the even-even class
