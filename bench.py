@@ -204,11 +204,13 @@ def main():
     eng = enc.engine
     enc.train()
 
+    from vpd_amd.models.util import step
+
     def one_step():
+        # the body of ModelTrainer.epoch for one batch (train_vpd_model.py:79-91): forward + loss, then step() =
+        # loss.backward() [with the bucketed RCCL all-reduce when world > 1]; optimizer.step(); optimizer.zero_grad()
         loss = trainer._forward_loss(img, emb, train=True)
-        loss.backward()          # includes the bucketed RCCL all-reduce when world > 1
-        optimizer.step()
-        optimizer.zero_grad()
+        step(optimizer, scaler, loss)
 
     def sync():
         if world > 1:

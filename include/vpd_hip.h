@@ -114,6 +114,16 @@ int vpd_plan_adamw_step(vpd_plan_t* plan, float* params, const float* grads, flo
                         long long numel, double lr, double beta1, double beta2, double eps, double weight_decay,
                         int step, void* workspace, void* stream);
 
+/* Lazy gradients for the fused train step (reference: models/util.py:50-58, where nothing looks at .grad between
+ * loss.backward() and optimizer.step()).  vpd_plan_set_lazy_grads(plan, 1) arms the NEXT vpd_backward (ignored when it is
+ * given bucket events, i.e. under data parallelism): the conv weight gradients then stay in the kernels' own fp32 scratch
+ * layout and vpd_plan_adamw_step reads them there, so the layout pass into `grads` (170 MB of traffic per step) is skipped;
+ * every other tensor's gradient, and the stem's, is in `grads` as usual.  vpd_plan_grads_pending() tells whether `grads` is
+ * incomplete; vpd_plan_materialize_grads() completes it on demand (no-op otherwise). */
+int vpd_plan_set_lazy_grads(vpd_plan_t* plan, int on);
+int vpd_plan_grads_pending(const vpd_plan_t* plan);
+int vpd_plan_materialize_grads(vpd_plan_t* plan, float* grads, void* workspace, void* stream);
+
 /* hipGraph-captured eval forward for a fixed batch size (apply_vpd_model.py:152-168 inner
  * loop at BATCH_SIZE crops per call).  Capture binds the pointers given here. */
 /* ---- train-time input pipeline on the device (the step right before the hot path) ----

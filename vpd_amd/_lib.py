@@ -47,6 +47,9 @@ SIGNATURES = {
     "vpd_graph_capture_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "vpd_graph_launch_eval": (C.c_int, [vp, C.c_int, vp]),
     "vpd_plan_sync_errors": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint)]),
+    "vpd_plan_set_lazy_grads": (C.c_int, [vp, C.c_int]),
+    "vpd_plan_grads_pending": (C.c_int, [vp]),
+    "vpd_plan_materialize_grads": (C.c_int, [vp, vp, vp, vp]),
     "vpd_plan_set_timing": (C.c_int, [vp, C.c_int]),
     "vpd_plan_read_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
     "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),

@@ -131,7 +131,7 @@ hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int
                                    const float* master, bf16_t* arena, hipStream_t s);
 hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
                                  float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
-                                 int step, hipStream_t s);
+                                 int step, hipStream_t s, const float* wg = nullptr);      // wg: conv gradients still in the scratch
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* wg, float* grads, hipStream_t s);
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,

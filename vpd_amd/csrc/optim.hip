@@ -232,9 +232,23 @@ hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n
 // `stem == 2` descriptors updated element-wise; so is the stem conv, whose row-tap packing gathers across the whole
 // tensor and is done by a 28-block pack_weights_kernel launch afterwards.
 #define ADAM_PLAIN_CHUNK 2048
+// wg != null: the conv weight gradients are read where the weight-gradient kernels left them -- the fp32 scratch in
+// [tap][Co][Ci] order (PackDesc::wg_off) -- instead of from the OIHW gradient buffer: the unpack pass in between (170 MB of
+// traffic, 67 us per step) disappears.  The stem and every non-conv tensor still come from `g`.
+template <int KHW>
+static __device__ __forceinline__ float4 adamw_gather_g(const float* wgc, int Co, int Kc, int co, int ci0, int k) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = k + j;
+        const int ci = kk / KHW, tap = kk - ci * KHW;
+        v[j] = wgc[((size_t)tap * Co + co) * Kc + ci0 + ci];
+    }
+    return float4{v[0], v[1], v[2], v[3]};
+}
 __global__ __launch_bounds__(256) void adamw_pack_kernel(const PackDesc* descs, const int* blockmap, float* p,
                                                          const float* g, float* m, float* v, bf16_t* arena,
-                                                         const AdamHyper h) {
+                                                         const AdamHyper h, const float* wg) {
     __shared__ unsigned short tile[32][32 * 9 + 2];      // the new weights, already rounded to bf16 (18 KB: 8 blocks per CU)
     const PackDesc d = descs[blockmap[2 * blockIdx.x]];
     const int chunk = blockmap[2 * blockIdx.x + 1];
@@ -252,13 +266,26 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const PackDesc* descs, 
     const int tci = d.Ci >> 5;
     const int co0 = (chunk / tci) * 32, ci0 = (chunk % tci) * 32;
     const int run4 = (32 * khw) >> 2;
+    const float* wgc = wg ? wg + d.wg_off : nullptr;
     for (int i = threadIdx.x; i < 32 * run4; i += 256) {
         const int r = i / run4, k = (i - r * run4) << 2;
         const size_t e = d.src_off + ((size_t)(co0 + r) * d.Ci + ci0) * khw + k;
         float4 pp = *reinterpret_cast<const float4*>(p + e);
         float4 mm = *reinterpret_cast<const float4*>(m + e);
         float4 vv = *reinterpret_cast<const float4*>(v + e);
-        adamw4(pp, *reinterpret_cast<const float4*>(g + e), mm, vv, h);
+        float4 gg;
+        if (!wgc) gg = *reinterpret_cast<const float4*>(g + e);
+        else if (khw == 9) gg = adamw_gather_g<9>(wgc, d.Co, d.Kc, co0 + r, ci0, k);
+        else if (khw == 1) gg = *reinterpret_cast<const float4*>(wgc + (size_t)(co0 + r) * d.Kc + ci0 + k);
+        else {
+            float t4[4];
+            for (int j = 0; j < 4; ++j) {
+                const int ci = (k + j) / khw, tap = (k + j) - ci * khw;
+                t4[j] = wgc[((size_t)tap * d.Co + co0 + r) * d.Kc + ci0 + ci];
+            }
+            gg = float4{t4[0], t4[1], t4[2], t4[3]};
+        }
+        adamw4(pp, gg, mm, vv, h);
         *reinterpret_cast<float4*>(p + e) = pp;
         *reinterpret_cast<float4*>(m + e) = mm;
         *reinterpret_cast<float4*>(v + e) = vv;
@@ -288,12 +315,12 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const PackDesc* descs, 
 }
 hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
                                  float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
-                                 int step, hipStream_t s) {
+                                 int step, hipStream_t s, const float* wg) {
     if ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) |
          reinterpret_cast<size_t>(v)) & 15)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(adamw_pack_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, p, g, m, v, arena,
-                       adam_hyper(lr, b1, b2, eps, wd, step));
+                       adam_hyper(lr, b1, b2, eps, wd, step), wg);
     return hipGetLastError();
 }
 

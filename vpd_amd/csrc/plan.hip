@@ -124,6 +124,10 @@ struct vpd_plan {
     size_t syncerr_off = 0;                     // sticky counter of grid-barrier time-outs (zeroed by init_workspace only)
     bool wg_group = true;       // per-stage grouped weight gradients (VPD_WG_GROUP=0: one launch per conv)
     size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest launch group
+    // lazy gradients (vpd_plan_set_lazy_grads): the next vpd_backward leaves the conv weight gradients in the scratch
+    // (only the stem's are unpacked), vpd_plan_adamw_step reads them there; vpd_plan_materialize_grads unpacks on demand
+    bool lazy_next = false, grads_in_scratch = false;
+    int nstem_unpack_blocks = 0;           // leading entries of bmap_unpack[3] that belong to the stem
     bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0: per stage)
     size_t wg2_tbl_off[4] = {0, 0, 0, 0};      // task tables of the 128 x 64 persistent weight-gradient launches (one per stage)
     void* wg2_cache[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -310,6 +314,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         }
     };
     push_desc(p->stem, 3);
+    p->nstem_unpack_blocks = (int)p->bmap_unpack[3].size() / 2;
     for (auto& B : p->blocks) {
         const int bucket = 3 - B.stage;
         push_desc(B.c1, bucket);
@@ -1067,6 +1072,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     if (n == 0) {      // empty shard: the gradient of a sum over no crops is zero; every bucket is "ready" at once
+        p->lazy_next = false; p->grads_in_scratch = false;
         HCHECK(hipMemsetAsync(grads, 0, (size_t)p->nparam_padded * sizeof(float), s));
         for (int b = 0; b < 4; ++b)
             if (bucket_events && bucket_events[b]) HCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
@@ -1188,8 +1194,13 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         }
         return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed);
     };
+    // lazy: no bucket hand-over to a reducer in this call, and the caller asked for it (vpd_plan_set_lazy_grads)
+    const bool lazy = p->lazy_next && !bucket_events;
+    p->lazy_next = false;
+    p->grads_in_scratch = lazy;
     auto unpack_bucket = [&](int b) -> int {
-        const int nb = (int)p->bmap_unpack[b].size() / 2;
+        int nb = (int)p->bmap_unpack[b].size() / 2;
+        if (lazy) nb = b == 3 ? p->nstem_unpack_blocks : 0;      // the stem's row-tap packing is undone here either way
         if (nb > 0)
             LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
                                            reinterpret_cast<const int*>(ws + p->bmap_unpack_off[b]), nb,
@@ -1379,7 +1390,9 @@ extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* gr
     LCHECK(vpd_launch_adamw_pack(reinterpret_cast<const PackDesc*>(ws + p->desc_off),
                                  reinterpret_cast<const int*>(ws + p->bmap_adam_off), (int)p->bmap_adam.size() / 2, params,
                                  grads, adam_m, adam_v, reinterpret_cast<bf16_t*>(ws + p->arena_off), lr, beta1, beta2,
-                                 eps, weight_decay, step, s));
+                                 eps, weight_decay, step, s,
+                                 p->grads_in_scratch ? reinterpret_cast<const float*>(ws + p->wg_off) : nullptr));
+    p->grads_in_scratch = false;      // consumed (the scratch is rewritten by the next backward)
     LCHECK(vpd_launch_pack_weights(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
                                    reinterpret_cast<const int*>(ws + p->bmap_pack_off), p->nstem_pack_blocks, params,
                                    reinterpret_cast<bf16_t*>(ws + p->arena_off), s));
@@ -1387,6 +1400,29 @@ extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* gr
         LCHECK(vpd_launch_adamw(params + p->nparam_padded, grads + p->nparam_padded, adam_m + p->nparam_padded,
                                 adam_v + p->nparam_padded, (long)(numel - p->nparam_padded), lr, beta1, beta2, eps,
                                 weight_decay, step, s));
+    return 0;
+}
+
+extern "C" int vpd_plan_set_lazy_grads(vpd_plan_t* p, int on) {
+    if (!p) return fail("null plan");
+    p->lazy_next = on != 0;
+    return 0;
+}
+extern "C" int vpd_plan_grads_pending(const vpd_plan_t* p) { return p && p->grads_in_scratch ? 1 : 0; }
+extern "C" int vpd_plan_materialize_grads(vpd_plan_t* p, float* grads, void* workspace, void* stream) {
+    if (!p || !grads || !workspace) return fail("null argument");
+    if (p->bound_ws != workspace) return fail("workspace not initialised with vpd_plan_init_workspace");
+    if (!p->grads_in_scratch) return 0;
+    char* ws = (char*)workspace;
+    for (int b = 0; b < 4; ++b) {
+        const int nb = (int)p->bmap_unpack[b].size() / 2;
+        const int skip = b == 3 ? p->nstem_unpack_blocks : 0;      // the stem was unpacked by the backward itself
+        if (nb > skip)
+            LCHECK(vpd_launch_unpack_grads(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
+                                           reinterpret_cast<const int*>(ws + p->bmap_unpack_off[b]) + 2 * skip, nb - skip,
+                                           reinterpret_cast<const float*>(ws + p->wg_off), grads, (hipStream_t)stream));
+    }
+    p->grads_in_scratch = false;
     return 0;
 }
 

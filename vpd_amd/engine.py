@@ -130,7 +130,7 @@ class StudentEngine:
 
         z = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(self.param_numel, **z)
-        self.grads = torch.zeros(self.param_numel, **z)
+        self._grads = torch.zeros(self.param_numel, **z)      # see the `grads` property
         self.bn_running = torch.zeros(max(self.bn_numel, 1), **z)
         self.num_batches_tracked = torch.zeros(len(self.bn_names), dtype=torch.int64, device=self.device)
         self.adam_m = None
@@ -145,6 +145,20 @@ class StudentEngine:
         self.bucket_events = None
 
     # -- helpers -------------------------------------------------------------
+    @property
+    def grads(self):
+        """The flat fp32 gradient buffer (reference layouts; every p.grad is a view of it).  After a LAZY backward -- the one
+        models.util.step() runs between forward and optimizer step, where the reference never looks at .grad either -- the
+        conv weight gradients are still in the kernels' own layout: reading this property completes the buffer first."""
+        self.materialize_grads()
+        return self._grads
+
+    def materialize_grads(self):
+        pl = self._step_plan
+        if pl is not None and pl.handle and lib().vpd_plan_grads_pending(pl.handle):
+            check(lib().vpd_plan_materialize_grads(pl.handle, _ptr(self._grads), _ptr(pl.workspace), self._stream()),
+                  "vpd_plan_materialize_grads")
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -245,7 +259,9 @@ class StudentEngine:
         self._last = (pl, n) if target is not None else None
         return emb
 
-    def backward(self, events=None):
+    def backward(self, events=None, lazy=False):
+        """lazy: leave the conv weight gradients in the weight-gradient kernels' scratch layout for the fused optimizer step
+        (ignored with bucket events, i.e. under data parallelism: the reducer works on the flat buffer)."""
         if self._last is None:
             raise RuntimeError("backward() without a preceding train-mode forward with a target")
         pl, n = self._last
@@ -254,7 +270,10 @@ class StudentEngine:
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
-        check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self.grads), n, ev, _ptr(pl.workspace),
+        self.materialize_grads()           # (a pending lazy backward of ANOTHER plan would otherwise be lost)
+        if lazy and ev is None:
+            check(lib().vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
+        check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
                                  self._stream()), "vpd_backward")
         return pl
 
@@ -266,7 +285,7 @@ class StudentEngine:
         pl = self._step_plan
         if pl is not None and pl.packed_version == self.weights_version() and os.environ.get("VPD_FUSED_ADAMW", "1") != "0":
             # the train plan of the last backward: AdamW + refresh of its packed bf16 weights in one pass
-            check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+            check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self._grads), _ptr(self.adam_m),
                                             _ptr(self.adam_v), self.param_numel, lr, betas[0], betas[1], eps,
                                             weight_decay, self.adam_step, _ptr(pl.workspace), self._stream()),
                   "vpd_plan_adamw_step")

@@ -20,6 +20,11 @@ class _Loss:
     def backward(self):
         self._t._backward()
 
+    def backward_for_step(self):
+        """backward() as models.util.step() runs it: the optimizer step follows immediately and nothing reads .grad in
+        between (reference models/util.py:52-58), so the conv weight gradients may stay in the kernels' layout."""
+        self._t._backward(lazy=True)
+
     def item(self):
         return float(self._t.encoder.engine.loss_step.item())   # host sync, as in the reference
 
@@ -97,14 +102,14 @@ class ModelTrainer:
             eng.forward_eval(None, gt, motion=self.motion, staged=staged)
         return _Loss(self)
 
-    def _backward(self):
+    def _backward(self, lazy=False):
         eng = self.encoder.engine
         if self._reducer is not None:
             nb = len(eng._last[0].buckets) if eng._last is not None else 0      # (backward() raises without a forward)
             pl = eng.backward(self._reducer.event_handles(nb))
             self._reducer.reduce(pl)
         else:
-            eng.backward()
+            eng.backward(lazy=lazy)
 
     def epoch(self, data_loader, optimizer=None, scaler=None, progress_cb=None):
         eng = self.encoder.engine
