@@ -14,10 +14,10 @@ from vpd_amd._lib import lib, check
 L = lib()
 N = int(os.environ.get("BENCH_N", "256"))
 GROUPS = {
-    "layer2": [(N, 16, 16, 128, 128)] * 7,
-    "layer3+4": [(N, 8, 8, 256, 256)] * 11 + [(N, 4, 4, 512, 512)] * 5,
-    "layer3": [(N, 8, 8, 256, 256)] * 11,
-    "layer4": [(N, 4, 4, 512, 512)] * 5,
+    "layer2": [(N, 16, 16, 128, 128, 1)] * 7 + [(N, 16, 16, 128, 64, 2)],
+    "layer3+4": [(N, 8, 8, 256, 256, 1)] * 11 + [(N, 4, 4, 512, 512, 1)] * 5 + [(N, 8, 8, 256, 128, 2), (N, 4, 4, 512, 256, 2)],
+    "layer3": [(N, 8, 8, 256, 256, 1)] * 11,
+    "layer4": [(N, 4, 4, 512, 512, 1)] * 5,
 }
 
 
@@ -25,22 +25,22 @@ def run(name, probs, reps=20):
     g = torch.Generator(device="cuda").manual_seed(1)
     keep, dzs, xs, dws, slabs, dims = [], [], [], [], [], []
     flops = 0.0
-    for (n, h, w, co, ci) in probs:
-        x = torch.zeros(n, h + 2, w + 2, ci, dtype=torch.bfloat16, device="cuda")
-        x[:, 1:-1, 1:-1, :] = torch.randn(n, h, w, ci, generator=g, device="cuda").clamp_min(0).to(torch.bfloat16)      # post-ReLU activations: half zeros, as in the step
+    for (n, h, w, co, ci, st) in probs:
+        x = torch.zeros(n, st * h + 2, st * w + 2, ci, dtype=torch.bfloat16, device="cuda")
+        x[:, 1:-1, 1:-1, :] = torch.randn(n, st * h, st * w, ci, generator=g, device="cuda").clamp_min(0).to(torch.bfloat16)      # post-ReLU activations: half zeros, as in the step
         dz = torch.zeros(n, h + 2, w + 2, co, dtype=torch.bfloat16, device="cuda")
         dz[:, 1:-1, 1:-1, :] = torch.randn(n, h, w, co, generator=g, device="cuda").to(torch.bfloat16)
         dw = torch.empty(9, co, ci, dtype=torch.float32, device="cuda")
         slab = torch.empty(max(int(L.vpd_op_wgrad128_slab_floats(co, ci)), 4), dtype=torch.float32, device="cuda")
         keep += [x, dz, dw, slab]
         dzs.append(dz.data_ptr()); xs.append(x.data_ptr()); dws.append(dw.data_ptr()); slabs.append(slab.data_ptr())
-        dims += [n, h, w, co, ci]
+        dims += [n, h, w, co, ci, st]
         flops += 2.0 * n * h * w * co * ci * 9
     k = len(probs)
     arr = lambda v: (C.c_void_p * k)(*v)
     table = torch.empty(int(L.vpd_op_wgrad128_table_bytes()), dtype=torch.uint8, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (5 * k))(*dims), C.c_void_p(table.data_ptr()), st)
+    args = (k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (6 * k))(*dims), C.c_void_p(table.data_ptr()), st)
     for _ in range(3):
         check(L.vpd_op_wgrad128_group(*args), "wgrad128")
     torch.cuda.synchronize()

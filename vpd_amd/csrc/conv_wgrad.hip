@@ -938,7 +938,7 @@ struct Wg2Group {
     int nprob;
     const int4* tasks;                         // device: (problem, tile, split, -)
     const int* blk_begin;                      // device: [grid + 1] first task of each block
-    int stage_elems;                           // bf16 elements per ring stage (dz 128 x 64 + the largest halo)
+    int stage_elems;                           // bf16 elements of the whole ring (the launch's dynamic LDS)
     int skew;                                  // see wg2_task
     WgradParams p[WG2_MAX];
     WgHaloGeom g[WG2_MAX];
@@ -969,13 +969,12 @@ static __device__ __forceinline__ void wg2_lds_dma16(const void* gsrc, unsigned 
 
 template <bool PIPE>
 static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHaloGeom& g, int tile, int split,
-                                                bf16_t* ring, int STAGE, int skew) {
-    constexpr int NS = WG2_NS;
+                                                bf16_t* ring, int lds_elems, int skew) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0..7
     const int ctile = wave & 3, cohalf = wave >> 2;
-    const int W = p.Ws, H = p.Hs, Wp = p.xWp;
+    const int W = p.Ws, H = p.Hs, Wp = p.xWp, S = p.istr;         // W, H: OUTPUT dims; S = 1 or 2 (3x3 pad 1: input pixel S*y + r)
     const int kct = p.Kc >> 6;
     const int co0 = (tile / kct) * 128;
     const int ci0 = (tile % kct) * 64;
@@ -986,7 +985,11 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
     const int nch = chunk_end - chunk_begin;
     const int nhi = (g.NHP + 7) >> 3;                                 // halo LDS-DMA instructions per chunk (8 pixels each)
     const int nh_mine = (nhi - wave + 7) >> 3;                        // this wave's: wave, wave + 8, ...
-    const int per = 2 + nh_mine;                                      // its LDS-DMA instructions per chunk (3..5)
+    const int per = 2 + nh_mine;                                      // its LDS-DMA instructions per chunk
+    // ring of THIS problem: four stages when they fit the launch's LDS (stride 1: 28-36 KB each), else two (stride 2: the
+    // halo of a 64-pixel chunk is 306-400 input pixels, 55-66 KB per stage); tasks run one after the other in a block
+    const int STAGE = (128 + 8 * nhi) * 64;
+    const int NS = 4 * STAGE <= lds_elems ? 4 : 2;
 
     // ---- LDS-DMA side: chunk-invariant per-lane element offsets (32-bit), the chunk's part is wave-uniform (64-bit) ----
     const int piece = lane & 7, lrow = lane >> 3;
@@ -1003,13 +1006,6 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
         const int img = g.multi ? lr / H : 0, yy = g.multi ? lr % H : lr;
         zlane[k] = ((img * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cohalf * 64 + cpc * 8;
         zrow[k] = row;
-    }
-    int hlane[3];                                                     // (pixel << 8) | channel piece offset: hp < 2^8 * ..., cpc * 8 < 64
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int hp = (wave + 8 * k) * 8 + lrow;
-        const int cpc = (((piece >> 1) ^ wg_f(hp)) << 1) | (piece & 1);
-        hlane[k] = (hp << 8) | (cpc * 8);
     }
     // running position of the NEXT chunk to issue
     int is_c = 0;                                                     // chunks issued so far
@@ -1031,16 +1027,15 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
                                                              : p.dz + (zlane[k] & 63);      // zero border pixel (0, 0) of image 0
             wg2_lds_dma16(src, st_lds + (unsigned)(i * 8 * 64 * 2));
         }
-        const int gp0 = (is_b * p.xHp + is_y) * Wp;
+        const int gp0 = (is_b * p.xHp + S * is_y) * Wp;
         const bf16_t* xb = p.x + ci0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (k < nh_mine) {
-                int gp = gp0 + (hlane[k] >> 8);
-                gp = gp < g.total_pix ? gp : g.total_pix - 1;
-                const bf16_t* src = xb + (size_t)gp * p.xC + (hlane[k] & 255);
-                wg2_lds_dma16(src, st_lds + (unsigned)((128 + (wave + 8 * k) * 8) * 64 * 2));
-            }
+        for (int k = 0; k < nh_mine; ++k) {
+            const int hp = (wave + 8 * k) * 8 + lrow;
+            const int cpc = (((piece >> 1) ^ wg_f(hp)) << 1) | (piece & 1);
+            int gp = gp0 + hp;
+            gp = gp < g.total_pix ? gp : g.total_pix - 1;
+            const bf16_t* src = xb + (size_t)gp * p.xC + cpc * 8;
+            wg2_lds_dma16(src, st_lds + (unsigned)((128 + (wave + 8 * k) * 8) * 64 * 2));
         }
         ++is_c;
         if (g.multi) is_b += ipc;
@@ -1052,7 +1047,7 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
     // tap and 4-row half, two 16-bit values per register (a stage is < 64 KiB). ----
     const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
     int offA0[2];
-    unsigned offB[2][9];                                              // [ks][tap]: low half h = 0, high half h = 1
+    unsigned offB[2][9];                                              // [ks][tap]: low half h = 0, high half h = 1 (bytes from the halo's base: < 64 KiB)
     {
         const int ra = 8 * gq + q;
 #pragma unroll
@@ -1068,8 +1063,8 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
                 const int pk = 32 * ks + 8 * gq + 4 * h + q;
                 const int lr = pk / W;
                 const int xx = pk - lr * W;
-                const int hrow = g.multi ? (lr / H) * p.xHp + (lr % H) : lr;
-                hmv[h] = hrow * Wp + xx;
+                const int hrow = g.multi ? (lr / H) * p.xHp + S * (lr % H) : S * lr;
+                hmv[h] = hrow * Wp + S * xx;
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -1077,7 +1072,7 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int r = hmv[h] + (p.taps.dy0 + (t / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (t % 3) * p.taps.dxs);
-                    const unsigned o = 2u * (unsigned)(128 * 64 + r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));
+                    const unsigned o = 2u * (unsigned)(r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));      // from the halo's base
                     v |= o << (16 * h);
                 }
                 offB[ks][t] = v;
@@ -1103,13 +1098,13 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
     // every wave is done with the previous task's ring (and its stores are on their way) before new tiles land in it
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int k = 0; k < NS - 1; ++k)
-        if (k < nch) issue();
+    for (int k = 0; k < 3; ++k)
+        if (k < NS - 1 && k < nch) issue();
     for (int c = 0; c < nch; ++c) {
         // this wave's share of chunk c has landed when at most its instructions of the younger chunks are outstanding
         int ahead = nch - 1 - c;
         ahead = ahead < NS - 2 ? ahead : NS - 2;
-        wg2_wait_allow(ahead * per);
+        wg2_wait_allow(ahead * per);                                  // (NS == 2: 0; NS == 4: per <= 5 by eligibility)
         __builtin_amdgcn_s_barrier();                                 // READY_c: all shares landed; everyone finished chunk c-1
         // chunk c + NS - 1 goes into the stage chunk c - 1 used.  skew: the second wave of every SIMD requests its share
         // between the two k-steps instead, so that the two waves stop running their read / MFMA phases in lockstep
@@ -1125,7 +1120,7 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
         };
         auto ldB = [&](int ks, int t) __attribute__((always_inline)) {
             const unsigned v = offB[ks][t];
-            return frag2(sb + (v & 0xffffu), sb + (v >> 16));
+            return frag2(sb + 128 * 128 + (v & 0xffffu), sb + 128 * 128 + (v >> 16));
         };
         if constexpr (PIPE) {
             bf16x8 az[2][4], bx[3];
@@ -1200,9 +1195,14 @@ bool vpd_wgrad128_eligible(const WgradParams& p) {
     WgHaloGeom g;
     WgradParams q = p;
     if (!q.slab) q.slab = reinterpret_cast<float*>(16);
-    if (off || p.Co % 128 != 0 || p.Kc % 64 != 0 || p.istr != 1 || p.one_by_one || p.dzpad < 1 || p.dzC % 128 != 0) return false;
+    if (off || p.Co % 128 != 0 || p.Kc % 64 != 0 || (p.istr != 1 && p.istr != 2) || p.one_by_one || p.dzpad < 1 || p.dzC % 128 != 0)
+        return false;
+    if (p.istr == 2 && p.taps.nr != 3) return false;
     if (!(vpd_wgrad_overwrites(q) && wg_halo_geom(q, &g))) return false;
-    return (g.NHP + 7) / 8 <= 24;
+    const int nhi = (g.NHP + 7) / 8;
+    // stride 1: four ring stages with at most 5 LDS-DMA instructions per wave and chunk (the counted vmcnt waits);
+    // stride 2: two stages that fit 160 KB
+    return p.istr == 1 ? nhi <= 24 : 2 * (128 + 8 * nhi) * 128 <= 160 * 1024;
 }
 
 struct Wg2Schedule {
@@ -1374,7 +1374,15 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     const Wg2Schedule& sch = c->sch;
     grp.tasks = reinterpret_cast<const int4*>(dev_table);
     grp.blk_begin = reinterpret_cast<const int*>((char*)dev_table + ((sch.tasks.size() * sizeof(int) + 63) & ~(size_t)63));
-    grp.stage_elems = (128 + 8 * nhi_max) * 64;
+    {
+        size_t need = 0;      // every problem's ring: 4 stages (stride 1) or 2 (stride 2)
+        for (int i = 0; i < n; ++i) {
+            const size_t st = (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
+            const size_t want = (ps[i].istr == 1 ? 4 : 2) * st;
+            need = want > need ? want : need;
+        }
+        grp.stage_elems = (int)need;
+    }
     // skew on: same-box A/B 490 -> 458 us per step for the class (profiles/r02_negative_results.txt has the variants)
     static const int skew = getenv("VPD_WG2_SKEW") ? atoi(getenv("VPD_WG2_SKEW")) : 1;
     grp.skew = skew;
@@ -1396,7 +1404,7 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
             if (red.nprob > WG_GROUP_MAX) return hipErrorInvalidValue;
         }
     }
-    const size_t lds = (size_t)WG2_NS * grp.stage_elems * sizeof(bf16_t);
+    const size_t lds = (size_t)grp.stage_elems * sizeof(bf16_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static const int pipe = getenv("VPD_WG2_PIPE") ? atoi(getenv("VPD_WG2_PIPE")) : 0;
     if (pipe) VPD_LAUNCH(conv_wgrad128_persistent_kernel<true>, dim3(sch.grid), dim3(512), lds, stream, grp);

@@ -457,7 +457,23 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             size_t stage_slab[4] = {0, 0, 0, 0};
             for (auto& B : p->blocks)
                 for (ConvInfo* cv : {&B.c1, &B.c2}) {
-                    if (cv->slab_off < 0 || cv->stride != 1 || cv->k != 3) continue;      // (stride-2 and 1x1 halo wgrads: their own launch)
+                    // stride-1 3x3 convs, and the stride-2 3x3 of a stage's first block when the 128 x 64 kernel takes it
+                    // (1x1 convs and the rest: their own launch)
+                    if (cv->slab_off < 0 || cv->k != 3) continue;
+                    if (cv->stride != 1) {
+                        // OFF by default (VPD_WG2_S2=1 enables): inside the stage's launch the three stride-2 problems cost
+                        // 86 us per step against 78 us as launches of their own -- their 55-66 KB per chunk leave room for a
+                        // two-stage ring only, one chunk of prefetch, and the tasks run at the DMA latency
+                        static const bool s2_grouped = getenv("VPD_WG2_S2") && atoi(getenv("VPD_WG2_S2"));
+                        if (!s2_grouped) continue;
+                        WgradParams q;
+                        memset(&q, 0, sizeof q);
+                        q.dzHp = cv->Hout + 2; q.dzWp = cv->Wout + 2; q.dzC = cv->Co; q.dzpad = 1;
+                        q.xHp = cv->Hin + 2; q.xWp = cv->Win + 2; q.xC = cv->Ci;
+                        q.N = NB; q.Hs = cv->Hout; q.Ws = cv->Wout; q.istr = cv->stride; q.Kc = cv->Kc; q.Co = cv->Co;
+                        q.M = NB * cv->Hout * cv->Wout; q.taps = conv_taps_fwd(*cv);
+                        if (!vpd_wgrad128_eligible(q)) continue;
+                    }
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
                     const int grp = (p->wg_merge34 && B.stage == 3) ? 2 : B.stage;
                     cv->gslab_off = (long long)stage_slab[grp];
@@ -1534,8 +1550,8 @@ extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int
 }
 
 // Grouped 128 x 64 weight gradients (conv_wgrad128_persistent_kernel) of `nprob` 3x3 stride-1 pad-1 convolutions in ONE
-// launch.  dims: 5 ints per problem {n, H, W, Co, Ci}; dz[i]: padded bf16 [n][H+2][W+2][Co]; x[i]: padded bf16
-// [n][H+2][W+2][Ci]; dw[i]: fp32 [9][Co][Ci]; slab[i]: fp32 scratch of vpd_op_wgrad128_slab_floats(Co, Ci) floats;
+// launch.  dims: 6 ints per problem {n, H, W, Co, Ci, stride} (H, W: OUTPUT size; stride 1 or 2, 3x3 pad 1); dz[i]: padded
+// bf16 [n][H+2][W+2][Co]; x[i]: padded bf16 [n][stride*H+2][stride*W+2][Ci]; dw[i]: fp32 [9][Co][Ci]; slab[i]: fp32 scratch of vpd_op_wgrad128_slab_floats(Co, Ci) floats;
 // dev_table: vpd_op_wgrad128_table_bytes() of device memory.
 extern "C" size_t vpd_op_wgrad128_table_bytes(void) { return vpd_wgrad128_table_bytes(); }
 extern "C" size_t vpd_op_wgrad128_slab_floats(int Co, int Ci) { return vpd_wgrad_group_slab_floats(0, Co, Ci); }
@@ -1544,13 +1560,15 @@ extern "C" int vpd_op_wgrad128_group(int nprob, const void* const* dz, const voi
     if (nprob < 1 || nprob > 18 || !dz || !x || !dw || !slab || !dims || !dev_table) return fail("bad argument");
     WgradParams qs[18];
     for (int i = 0; i < nprob; ++i) {
-        const int n = dims[5 * i], H = dims[5 * i + 1], W = dims[5 * i + 2], Co = dims[5 * i + 3], Ci = dims[5 * i + 4];
+        const int n = dims[6 * i], H = dims[6 * i + 1], W = dims[6 * i + 2], Co = dims[6 * i + 3], Ci = dims[6 * i + 4];
+        const int S = dims[6 * i + 5];
+        if (S != 1 && S != 2) return fail("stride must be 1 or 2");
         WgradParams q;
         memset(&q, 0, sizeof q);
         q.dz = (const bf16_t*)dz[i]; q.dzHp = H + 2; q.dzWp = W + 2; q.dzC = Co; q.dzpad = 1;
-        q.x = (const bf16_t*)x[i]; q.xHp = H + 2; q.xWp = W + 2; q.xC = Ci;
+        q.x = (const bf16_t*)x[i]; q.xHp = S * H + 2; q.xWp = S * W + 2; q.xC = Ci;
         q.dw = dw[i]; q.slab = slab[i];
-        q.N = n; q.Hs = H; q.Ws = W; q.istr = 1; q.Kc = Ci; q.Co = Co; q.M = n * H * W;
+        q.N = n; q.Hs = H; q.Ws = W; q.istr = S; q.Kc = Ci; q.Co = Co; q.M = n * H * W;
         q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
         q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
         if (!vpd_wgrad128_eligible(q)) return fail("shape not eligible for the 128 x 64 weight-gradient kernel");
