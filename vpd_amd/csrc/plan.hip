@@ -912,10 +912,12 @@ int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* 
     vpd_plan* p = c.p;
     const StageInfo& S = p->stages[3];
     LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.f32(p->pooled_off), c.s));
-    float* emb = c.f32(p->emb_off);
+    // without the motion head nothing re-reads the embedding (the fc backward uses the pooled features and d(emb)): the fc
+    // GEMM writes the caller's buffer directly; with it, the head's first layer and its weight gradient read the workspace copy
+    float* emb = (emb_out && !p->motion) ? emb_out : c.f32(p->emb_off);
     LCHECK(vpd_launch_sgemm(c.f32(p->pooled_off), c.params + p->fc.w_off, emb, c.params + p->fc.b_off, c.n, p->D, p->feat,
                             0, 1, 0, c.s));
-    if (emb_out) LCHECK(hipMemcpyAsync(emb_out, emb, (size_t)c.n * p->D * 4, hipMemcpyDeviceToDevice, c.s));
+    if (emb_out && emb != emb_out) LCHECK(hipMemcpyAsync(emb_out, emb, (size_t)c.n * p->D * 4, hipMemcpyDeviceToDevice, c.s));
     if (!target) return 0;
     const float* pred = emb;
     int pd = p->D;

@@ -277,7 +277,16 @@ class StudentEngine:
                                  self._stream()), "vpd_backward")
         return pl
 
-    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    @property
+    def encoder_numel(self):
+        """Elements of the flat buffers that belong to the encoder (a multiple of 4: the decoder's tensors follow)."""
+        off = self.layout["decoder." + DECODER_PARAM_NAMES[0]][2]
+        return (off + 3) & ~3
+
+    def adamw_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, numel=None):
+        """numel: leading elements of the flat buffers to update (default: all).  An optimizer built without the motion head's
+        parameters passes encoder_numel, as torch.optim.AdamW never touches tensors it was not given."""
+        numel = self.param_numel if numel is None else int(numel)
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
@@ -286,14 +295,14 @@ class StudentEngine:
         if pl is not None and pl.packed_version == self.weights_version() and os.environ.get("VPD_FUSED_ADAMW", "1") != "0":
             # the train plan of the last backward: AdamW + refresh of its packed bf16 weights in one pass
             check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self._grads), _ptr(self.adam_m),
-                                            _ptr(self.adam_v), self.param_numel, lr, betas[0], betas[1], eps,
+                                            _ptr(self.adam_v), max(numel, pl.param_numel), lr, betas[0], betas[1], eps,
                                             weight_decay, self.adam_step, _ptr(pl.workspace), self._stream()),
                   "vpd_plan_adamw_step")
             self._hip_version += 1
             pl.packed_version = self.weights_version()
         else:
             check(lib().vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
-                                       self.param_numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
+                                       numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
                                        self._stream()), "vpd_adamw_step")
             self._hip_version += 1
 

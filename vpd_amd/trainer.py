@@ -34,13 +34,20 @@ class FusedAdamW(torch.optim.Optimizer):
     HIP kernel over the engine's flat fp32 buffers (weight decay on every tensor)."""
 
     def __init__(self, params, engine, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._engine = engine
+        # like torch.optim.AdamW, touch only the tensors that were passed in: without the motion head's parameters the
+        # update stops where the encoder's tensors end in the flat buffers
+        enc_end = engine.encoder_numel
+        ptr0 = engine.params.data_ptr()
+        has_dec = any((q.data_ptr() - ptr0) // 4 >= enc_end for q in params)
+        self._numel = engine.param_numel if has_dec else enc_end
 
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
-        self._engine.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"])
+        self._engine.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], numel=self._numel)
 
     def zero_grad(self, set_to_none=False):
         # gradients live in the engine's flat buffer and are overwritten (not accumulated)
