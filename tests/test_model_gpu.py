@@ -664,7 +664,7 @@ def test_lazy_gradients_of_the_fused_step_match_the_eager_path():
         torch.cuda.synchronize()
         out.append((enc.engine.params.cpu().numpy(), grads.cpu().numpy(), enc.engine.adam_m.cpu().numpy()))
     (p0, g0, m0), (p1, g1, m1) = out
-    # the weight-gradient kernels and the BatchNorm statistics are deterministic run to run except for the fp32 atomics of
-    # the 1x1 down-sampling weight gradients: identical up to that noise, and exactly equal where no atomics are involved
-    assert rel_l2(g1, g0) < 1e-5, rel_l2(g1, g0)
-    assert rel_l2(m1, m0) < 1e-5 and rel_l2(p1, p0) < 1e-6, (rel_l2(m1, m0), rel_l2(p1, p0))
+    # every reduction of the BasicBlock step runs in a fixed order (fp64 statistic rows, slab sums; the 1x1 down-sampling
+    # weight gradients take the halo kernel, not the atomics kernel): two runs agree to the last bit
+    assert np.array_equal(g1, g0), rel_l2(g1, g0)
+    assert np.array_equal(m1, m0) and np.array_equal(p1, p0), (rel_l2(m1, m0), rel_l2(p1, p0))

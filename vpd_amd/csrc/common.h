@@ -180,6 +180,7 @@ struct WgradParams {
     // halo kernel, set by its launchers: a 1x1 (pad 0) convolution runs as the CENTRE tap of the 3x3 halo form -- taps
     // holds the 3x3 geometry, only tap 4 is accumulated and dw / the slab have ONE slice
     int one_by_one;
+    int prefer_halo_1x1;                        // caller's wish for a 1x1 conv: the halo kernel (no atomics) instead of conv_wgrad_kernel
 };
 
 // ---------------------------------------------------------------------------

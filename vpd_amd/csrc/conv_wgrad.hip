@@ -712,10 +712,13 @@ bool vpd_wgrad_overwrites(const WgradParams& p0) {
     if (wg_stem_eligible(p0, &tr_stem)) return true;
     static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
     static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
-    // 1x1 convolutions on the halo kernel (centre tap): OFF by default -- as ONE launch per conv it is no faster than the
-    // atomics kernel (ResNet-50 step 9.90 vs 9.55 ms, ResNet-34 +-0: profiles/r02_negative_results.txt); both run at the
-    // ~4 TB/s their operand streams allow.  VPD_WGRAD_1X1=1 enables it (tests/test_ops_gpu.py covers it).
-    static const int no_1x1 = getenv("VPD_WGRAD_1X1") ? !atoi(getenv("VPD_WGRAD_1X1")) : 1;
+    // 1x1 convolutions on the halo kernel (centre tap), no atomics.  As ONE launch per conv it is no faster than the atomics
+    // kernel (both run at the ~4 TB/s their operand streams allow; ResNet-50: 9.90 vs 9.55 ms per step, ResNet-34: +12 us),
+    // but it OVERWRITES its output and adds in a fixed order.  Default: ON where the caller asks for it (WgradParams::
+    // prefer_halo_1x1 -- the plan sets it for the BasicBlock students, whose three down-sampling convs were the last fp32
+    // atomics of the step: the ResNet-18/34 step is now reproducible bit for bit), otherwise off; VPD_WGRAD_1X1=0/1 forces.
+    static const int env_1x1 = getenv("VPD_WGRAD_1X1") ? atoi(getenv("VPD_WGRAD_1X1")) : -1;
+    const int no_1x1 = env_1x1 >= 0 ? !env_1x1 : !p0.prefer_halo_1x1;
     WgradParams p = p0;
     if (wg_as_one_by_one(p0, &p) && no_1x1) return false;
     WgHaloGeom g;

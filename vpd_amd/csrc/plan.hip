@@ -773,6 +773,7 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
     q.M = c.n * cv.Hout * cv.Wout;
     q.taps = conv_taps_fwd(cv);
+    q.prefer_halo_1x1 = !c.p->bottleneck;      // BasicBlock students: the three down-sampling 1x1 convs without atomics
     if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) q.slab = nullptr;      // (an A/B switch turned the halo form off: generic kernel)
     if (collect_zero) {                  // dry run at the start of backward: which ranges need zeroing
         if (!vpd_wgrad_overwrites(q) && collect_zero->count < ZR_MAX) {
