@@ -795,7 +795,18 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
             for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
         }
         const size_t oo = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + c;
-        *reinterpret_cast<uint4*>(p.out + oo) = pack8(v);
+        const uint4 ov = pack8(v);
+        *reinterpret_cast<uint4*>(p.out + oo) = ov;
+        if (p.mask_out) {      // bit j = the STORED bf16 value is > 0 (values are >= 0 after the ReLU: non-zero bits)
+            const unsigned w[4] = {ov.x, ov.y, ov.z, ov.w};
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bits |= ((w[j] & 0x7fffu) != 0u && !(w[j] & 0x8000u)) ? (1u << (2 * j)) : 0u;
+                bits |= ((w[j] & 0x7fff0000u) != 0u && !(w[j] & 0x80000000u)) ? (2u << (2 * j)) : 0u;
+            }
+            p.mask_out[it] = (unsigned char)bits;      // it = m * (C / 8) + c / 8
+        }
     }
 }
 
@@ -873,6 +884,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
             gr = pack8(g);
+        } else if (MASK == 3) {
+            const unsigned bits = p.mask_bits[(size_t)m * cv + c8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
+            gr = pack8(g);
         }
         if (f.keep_g) sG[(size_t)it * T + tid] = gr;
         if (f.keep_z) sZ[(size_t)it * T + tid] = zr;
@@ -944,6 +960,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
             if (MASK == 2) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] = (z[j] * msc[j] + msh[j]) > 0.f ? g[j] : 0.f;
+            } else if (MASK == 3) {
+                const unsigned bits = p.mask_bits[(size_t)m * cv + c8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
             }
         }
         const int b = m / HW;
@@ -1181,12 +1201,13 @@ hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, 
     const size_t red_bytes = (size_t)16 * 2 * p.C * sizeof(float);
     const size_t tile = (size_t)f.iters * 1024 * 16;    // bytes of one resident tensor slice
     const size_t cap = 160 * 1024;
-    const int mask = p.act ? 1 : (p.mscale ? 2 : 0);
+    const int mask = p.mask_bits ? 3 : (p.act ? 1 : (p.mscale ? 2 : 0));
     f.keep_g = red_bytes + tile <= cap;
     f.keep_z = f.keep_g && red_bytes + 2 * tile <= cap;
     if (!f.keep_g && mask == 1 && !p.write_g) return hipErrorInvalidValue;
     const size_t lds = red_bytes + (f.keep_g ? tile : 0) + (f.keep_z ? tile : 0);
-    if (mask == 1 && p.write_g) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 1>), dim3(G), dim3(1024), lds, s, p, f);
+    if (mask == 3) hipLaunchKernelGGL((bn_bwd_fused_kernel<3, 0>), dim3(G), dim3(1024), lds, s, p, f);
+    else if (mask == 1 && p.write_g) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 1>), dim3(G), dim3(1024), lds, s, p, f);
     else if (mask == 1) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 0>), dim3(G), dim3(1024), lds, s, p, f);
     else if (mask == 2) hipLaunchKernelGGL((bn_bwd_fused_kernel<2, 0>), dim3(G), dim3(1024), lds, s, p, f);
     else hipLaunchKernelGGL((bn_bwd_fused_kernel<0, 0>), dim3(G), dim3(1024), lds, s, p, f);

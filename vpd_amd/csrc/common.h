@@ -134,6 +134,9 @@ struct ConvParams {
     int Kc, Co;
     int M;                                      // N*Hs*Ws
     int accumulate;                             // y += result
+    // accumulate only: the old value of y is first multiplied by this ReLU mask ([M][yC/8] bytes, one bit per element; y dense):
+    // y holds d(block output) and the identity path carries d * [out > 0] -- the mask the BatchNorm backward used too
+    const unsigned char* acc_mask;
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
     ConvBnBwd bnb;                              // conv3x3_ws_kernel only

@@ -10,6 +10,7 @@ struct BnApplyParams {
     const float* rscale; const float* rshift;
     bf16_t* out; int oHp, oWp, opad;    // padded output
     int M, H, W, C, relu;
+    unsigned char* mask_out;            // fused forward only: [M][C/8] bytes, bit j of byte (m, c8) = out[m][8*c8 + j] > 0, or null
 };
 
 struct StemPoolParams {
@@ -31,6 +32,10 @@ struct BnBwdParams {
     bf16_t* dz; int dzHp, dzWp, dzpad;  // output (padded or dense)
     int M, H, W, C, write_g, ppb;
     const float* mscale; const float* mshift;   // when act == null and these are set: ReLU mask = (mscale*z + mshift > 0)
+    // fused backward only: the ReLU mask as ONE BIT per element ([M][C/8] bytes, written by the fused forward) instead of
+    // the stored activation; g is then neither read back from nor written to dy (the consumer of the identity path masks
+    // dy itself: ConvParams::acc_mask)
+    const unsigned char* mask_bits;
 };
 
 struct StemPoolBwdParams {

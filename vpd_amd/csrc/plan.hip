@@ -66,6 +66,7 @@ struct BlockInfo {
     bool ds = false;
     int stage = 0;
     size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
+    size_t mask_off = 0;                             // train, BasicBlock: [M][C/8] ReLU mask bits of the block output
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
@@ -126,6 +127,7 @@ struct vpd_plan {
     size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest launch group
     // lazy gradients (vpd_plan_set_lazy_grads): the next vpd_backward leaves the conv weight gradients in the scratch
     // (only the stem's are unpacked), vpd_plan_adamw_step reads them there; vpd_plan_materialize_grads unpacks on demand
+    bool relu_bits = true;      // block-output ReLU masks as bit maps (VPD_RELU_BITS=0: masks from the stored activation, g written back)
     bool lazy_next = false, grads_in_scratch = false;
     int nstem_unpack_blocks = 0;           // leading entries of bmap_unpack[3] that belong to the stem
     bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0: per stage)
@@ -484,6 +486,9 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             p->gslab_off = bp.take(mx * 4);
             for (int s2 = 0; s2 < 4; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
+        p->relu_bits = !bottleneck && !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
+        if (p->relu_bits)
+            for (auto& B : p->blocks) B.mask_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co / 8 + 16);
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -705,7 +710,8 @@ bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
 // ds / dzd: the block's 1x1 stride-2 down-sampling conv and its dz -- its data gradient lands on the even-even input pixels,
 // which are class 0 of the 3x3's: extra K-steps of those blocks instead of a read-modify-write launch of its own
 hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
-                          const ConvBnBwd* bnb = nullptr, const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr) {
+                          const ConvBnBwd* bnb = nullptr, const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr,
+                          const unsigned char* acc_mask = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
@@ -715,6 +721,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     hipError_t e = hipSuccess;
     if (cv.stride == 1) {
         q = conv_dgrad_s1_params(c, cv, dz, dx, accumulate);
+        q.acc_mask = accumulate ? acc_mask : nullptr;
         if (bnb) {
             q.bnb = *bnb;
             q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
@@ -825,7 +832,7 @@ hipError_t run_conv_train(const Ctx& c, const ConvInfo& cv, const bf16_t* x, flo
 // BatchNorm (+ residual, ReLU) of a train-mode forward: statistics -> normalised padded activation.  rcv: the
 // down-sampling branch's conv (res_kind 2), whose BatchNorm is finalized here too.  One launch when fused.
 hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int res_kind, const bf16_t* res,
-                      const ConvInfo* rcv, bf16_t* out, int relu) {
+                      const ConvInfo* rcv, bf16_t* out, int relu, unsigned char* mask_out = nullptr) {
     if (!c.fused(cv)) return run_bn_apply(c, cv, res_kind, res, rcv, out, relu);      // (finalized by run_conv_train)
     BnApplyParams a;
     memset(&a, 0, sizeof a);
@@ -833,6 +840,7 @@ hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int r
     a.res_kind = res_kind; a.res = res; a.rHp = cv.Hout + 2; a.rWp = cv.Wout + 2; a.rpad = 1;
     a.out = out; a.oHp = cv.Hout + 2; a.oWp = cv.Wout + 2; a.opad = 1;
     a.M = c.n * cv.Hout * cv.Wout; a.H = cv.Hout; a.W = cv.Wout; a.C = cv.Co; a.relu = relu;
+    a.mask_out = mask_out;
     BnFusedFwd f;
     memset(&f, 0, sizeof f);
     auto fill = [&](const ConvInfo& k, double** rows, float* count, const float** gamma, const float** beta, float** rm,
@@ -850,8 +858,13 @@ hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int r
 
 // act != null: ReLU mask from the stored activation (needed when a residual was added before the ReLU);
 // relu_from_z: mask recomputed as scale*z + shift > 0 (plain conv-BN-ReLU), which saves reading the activation
+// mask_bits: the ReLU mask as a bit map (fused launch only; the caller has checked relu_bits_ok): act and write_g are ignored
+bool relu_bits_ok(const Ctx& c, const ConvInfo& cv) {
+    return c.p->relu_bits && c.fused(cv) && vpd_bn_bwd_fused_ok(c.n * cv.Hout * cv.Wout, cv.Co, false, false);
+}
 hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
-                      int write_g, float* grads, bool relu_from_z = false, bool reduce_done = false) {
+                      int write_g, float* grads, bool relu_from_z = false, bool reduce_done = false,
+                      const unsigned char* mask_bits = nullptr) {
     BnBwdParams b;
     memset(&b, 0, sizeof b);
     b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
@@ -860,6 +873,7 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     b.partials = c.stat_rows();
     b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co; b.write_g = write_g;
+    if (mask_bits) { b.mask_bits = mask_bits; b.act = nullptr; b.write_g = 0; write_g = 0; }
     if (relu_from_z && !reduce_done) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
     if (reduce_done) b.act = nullptr;        // dy already holds g (masked by the producing dgrad kernel)
     if (c.fused(cv) && !reduce_done && vpd_bn_bwd_fused_ok(b.M, b.C, b.act != nullptr, write_g != 0)) {
@@ -1073,11 +1087,12 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             continue;
         }
         LCHECK(run_conv_train(c, B.c2, a1, bn_running));
+        unsigned char* mbits = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
         if (B.ds) {
             if (!pair) LCHECK(run_conv_train(c, B.cd, cur, bn_running));
-            LCHECK(run_bn_fwd(c, B.c2, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1, mbits));
         } else {
-            LCHECK(run_bn_fwd(c, B.c2, bn_running, 1, cur, nullptr, outp, 1));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 1, cur, nullptr, outp, 1, mbits));
         }
         cur = outp;
     }
@@ -1306,7 +1321,13 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                                             c.b16(S.dzd_off), s));
             bn_pair = true;
         }
-        if (!bn2_fused_for[bi] && !bn_pair) LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads));
+        // plain (identity) blocks: ReLU mask from the forward's bit map; g = dout * mask is neither written back nor re-read --
+        // conv1's data gradient, which adds the identity path, masks dout itself (ConvParams::acc_mask)
+        const unsigned char* mbits = nullptr;
+        if (!B.ds && !bn2_fused_for[bi] && relu_bits_ok(c, B.c2) && !(bi > 0 && dgrad_takes_bn(c, B.c1)))
+            mbits = reinterpret_cast<const unsigned char*>(ws + B.mask_off);
+        if (!bn2_fused_for[bi] && !bn_pair)
+            LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits));
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         if (dgrad_takes_bn(c, B.c2)) {
             // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
@@ -1338,7 +1359,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, &f));
             bn2_fused_for[bi - 1] = true;
         } else {
-            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
+            // dout holds g (or, with the bit map, d(out) and the mask is applied here): identity path + conv path
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mbits));
         }
         if (stage_end(bi)) return -1;
     }
