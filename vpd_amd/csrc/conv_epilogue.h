@@ -39,6 +39,16 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
 
+    // eval epilogue: this lane's 4 * NI scale / shift values once, not once per pixel group (the stores in between keep hipcc
+    // from merging the reloads)
+    float4 esc[NI], esh[NI];
+    if (do_eval) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            esc[a] = *reinterpret_cast<const float4*>(p.ep_scale + n0 + wn * WTN + a * 16 + 4 * fq);
+            esh[a] = *reinterpret_cast<const float4*>(p.ep_shift + n0 + wn * WTN + a * 16 + 4 * fq);
+        }
+    }
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = m0 + wm * WTM + b * 16 + fr;
@@ -66,8 +76,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
             const int n = n0 + wn * WTN + a * 16 + 4 * fq;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
             if (do_eval) {
-                const float4 sc = *reinterpret_cast<const float4*>(p.ep_scale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(p.ep_shift + n);
+                const float4 sc = esc[a];
+                const float4 sh = esh[a];
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (p.res) {
