@@ -20,14 +20,14 @@ static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p)
 template <int BM, int BN, int WM, int WN, int EPM = -1>
 static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
                                                      int mtile, int n0, float (&s1)[BN / WN / 16][4],
-                                                     float (&s2)[BN / WN / 16][4], const ConvGeo& geo) {
+                                                     float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base = 0) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
     constexpr int NI = WTN / 16;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = (tid >> 6) - wave_base;      // wave_base: first wave of this MFMA wave group (kernels with several groups)
     const int wm = wave % WM;
     const int wn = wave / WM;
     const int fr = lane & 15;

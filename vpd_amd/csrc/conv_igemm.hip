@@ -634,6 +634,154 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
 }
 
+// ---------------------------------------------------------------------------
+// Two MFMA wave groups per block for the 64 -> 64 channel convolutions of the INFERENCE forward (eval epilogue).
+// conv3x3_c64_persistent_kernel keeps ONE MFMA wave per SIMD: its 8 MFMAs per half K-step (128 cycles) sit behind ~150
+// cycles of exposed ds_read latency, and the eval epilogue (scale / shift, residual loads, ReLU, padded stores) runs with
+// the matrix cores idle.  Here a tile is 256 pixels: MFMA waves 0..3 take its first 128 pixels, waves 4..7 the second 128 --
+// two MFMA waves per SIMD, one computing while the other waits for LDS or stores -- on ONE shared halo (344 pixels instead of
+// 2 x 204).  LDS: 9 weight taps (72 KiB) + two halo buffers of 43 KiB = 158 KiB.  12 waves.
+// Train-mode launches stay on the single-group kernel: there this kernel made its own class 6 % faster and every OTHER class
+// of the step 3-5 % slower (the chip held a lower clock: profiles/r02_negative_results.txt).
+// ---------------------------------------------------------------------------
+#define C64X2_HPIX 344                           // halo pixels staged per tile (multiple of 8: one LDS-DMA instruction each)
+template <int EPM>
+__global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles) {
+    constexpr int BN = 64;
+    constexpr int MI = 2, NI = 4;                                 // per wave: 32 pixels x 64 channels
+    constexpr int HBUF = C64X2_HPIX * 64;
+    constexpr int NINSTR = C64X2_HPIX / 8;                        // 43 LDS-DMA instructions per halo
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                 // [9][64*64] resident weights
+    bf16_t* sH = sW + 9 * BN * 64;                                // [2][HBUF]
+
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = p.Ws, H = p.Hs, Wp = W + 2;
+    const int G = gridDim.x;
+
+    if (wave >= 8) {
+        const int lw = wave - 8;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        auto issue_halo = [&](int mtile, int buf) __attribute__((always_inline)) {
+            const int gr0 = mtile * g.TR;
+            int prow0;
+            if (g.multi) prow0 = (gr0 / H) * (H + 2);
+            else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+            const int gp0 = prow0 * Wp;
+            for (int k = lw; k < NINSTR; k += 4) {
+                const int hp = k * 8 + lrow;
+                int gp = gp0 + hp;
+                gp = gp < g.total_pix ? gp : g.total_pix - 1;
+                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ (hp & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HBUF + k * 8 * 64), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = (lw + 4 * i) * 8 + lrow;
+                const bf16_t* src = p.w + ((size_t)wsl * 64 + n) * 64 + ((piece ^ (n & 7)) << 3);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+            }
+        }
+        issue_halo(blockIdx.x, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // B_0
+        int i = 0;
+        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+            if (t + G < ntiles) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // B_{i+1}
+        }
+        return;
+    }
+
+    const int grp = wave >> 2;                                    // pixel half of the tile
+    const int wm = wave & 3;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    int hbase[MI];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = grp * 128 + wm * 32 + b * 16 + fr;
+        const int lr = m / W;
+        const int xx = m - lr * W;
+        const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
+        hbase[b] = hrow * Wp + xx;
+    }
+    float st1[NI][4], st2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    __builtin_amdgcn_s_barrier();                                 // B_0
+    int i = 0;
+    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+        const bf16_t* cH = sH + (i & 1) * HBUF;
+        f32x4 acc[NI][MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
+            const bf16_t* cW = sW + tap * BN * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[NI], bfm[MI];
+                const int chunk = kk * 4 + fq;
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int r = a * 16 + fr;
+                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int r = hbase[b] + toff;
+                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+                }
+#pragma unroll
+                for (int a = 0; a < NI; ++a)
+#pragma unroll
+                    for (int b = 0; b < MI; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        // this group's 128 pixels are output tile 2t + grp of the 128-pixel tiling
+        conv_epilogue<128, BN, 4, 1, EPM>(p, acc, 2 * t + grp, 0, st1, st2, geo, grp * 4);
+        __builtin_amdgcn_s_barrier();                             // B_{i+1}
+    }
+}
+
+// 256-pixel tiles of whole image rows whose halo fits C64X2_HPIX pixels; eval epilogue only (see the kernel's comment)
+static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
+    static const int off = getenv("VPD_C64X2") ? !atoi(getenv("VPD_C64X2")) : 0;
+    const int W = p.Ws, H = p.Hs;
+    if (off || conv_ep_mode(p) != 3 || W <= 0 || 256 % W != 0) return false;
+    const int TR = 256 / W;
+    if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
+    else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
+    g->TR = TR;
+    g->NHP = g->HR * (W + 2);
+    g->total_pix = p.N * (H + 2) * (W + 2);
+    return g->NHP <= C64X2_HPIX && p.M >= 256 * 256;      // at least one 256-pixel tile per CU
+}
+static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    const int ntiles = (p.M + 255) / 256;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    const size_t lds = ((size_t)9 * 64 + 2 * C64X2_HPIX) * 64 * sizeof(bf16_t);
+    ConvParams q = p;
+    VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<3>), dim3(grid), dim3(768), lds, stream, q, g, ntiles);
+    return hipGetLastError();
+}
+
 template <int HROWS>
 static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 127) / 128;
@@ -924,7 +1072,11 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {
-        case 0: return launch_c64<224>(p, g, stream);
+        case 0: {
+            HaloGeom g2;
+            if (c64x2_geom(p, &g2)) return launch_c64x2(p, g2, stream);      // inference: two MFMA wave groups on 256-pixel tiles
+            return launch_c64<224>(p, g, stream);
+        }
         case 1: return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
         // four ring stages (the loaders three weight tiles ahead): same-box A/B against 3 / 5 stages in
         // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
