@@ -699,6 +699,10 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
+        if (EPM == 1) {
+            __builtin_amdgcn_s_barrier();                         // halo buffers are free for the statistics scratch
+            __builtin_amdgcn_s_barrier();                         // matches the barrier inside conv_stats_flush
+        }
         return;
     }
 
@@ -758,27 +762,39 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
         conv_epilogue<128, BN, 4, 1, EPM>(p, acc, 2 * t + grp, 0, st1, st2, geo, grp * 4);
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
+    if (EPM == 1) {
+        __builtin_amdgcn_s_barrier();                             // (loaders too) nobody reads the halo buffers any more
+        conv_stats_flush<256, BN, 8, 1>(p, st1, st2, blockIdx.x, 0, reinterpret_cast<unsigned char*>(sH));
+    }
 }
 
 // 256-pixel tiles of whole image rows whose halo fits C64X2_HPIX pixels; eval epilogue only (see the kernel's comment)
 static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
     static const int off = getenv("VPD_C64X2") ? !atoi(getenv("VPD_C64X2")) : 0;
     const int W = p.Ws, H = p.Hs;
-    if (off || conv_ep_mode(p) != 3 || W <= 0 || 256 % W != 0) return false;
+    // VPD_C64X2_TRAIN: bit mask of the train-mode epilogue modes that also take this kernel (experiment; default none)
+    static const int train_modes = getenv("VPD_C64X2_TRAIN") ? atoi(getenv("VPD_C64X2_TRAIN")) : 0;
+    const int mode = conv_ep_mode(p);
+    if (off || !(mode == 3 || ((train_modes >> mode) & 1)) || W <= 0 || 256 % W != 0) return false;
     const int TR = 256 / W;
     if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
     else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
     g->TR = TR;
     g->NHP = g->HR * (W + 2);
     g->total_pix = p.N * (H + 2) * (W + 2);
-    return g->NHP <= C64X2_HPIX && p.M >= 256 * 256;      // at least one 256-pixel tile per CU
+    return g->NHP <= C64X2_HPIX && p.M >= 256 * 256;      // at least one 256-pixel tile per CU (256 crops of 32 x 32: 1024 tiles)
 }
 static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 255) / 256;
     const int grid = ntiles < 256 ? ntiles : 256;
     const size_t lds = ((size_t)9 * 64 + 2 * C64X2_HPIX) * 64 * sizeof(bf16_t);
     ConvParams q = p;
-    VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<3>), dim3(grid), dim3(768), lds, stream, q, g, ntiles);
+    switch (conv_ep_mode(q)) {
+        case 0: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<0>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
+        case 1: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<1>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
+        case 2: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<2>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
+        default: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<3>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
+    }
     return hipGetLastError();
 }
 
