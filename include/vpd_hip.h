@@ -203,6 +203,11 @@ size_t vpd_op_wgrad128_table_bytes(void);
 size_t vpd_op_wgrad128_slab_floats(int Co, int Ci);
 int vpd_op_wgrad128_group(int nprob, const void* const* dz, const void* const* x, float* const* dw, float* const* slab,
                           const int* dims, void* dev_table, void* stream);
+/* Host-only: the schedule vpd_op_wgrad128_group would build for `n` problems given as {M, Co, Ci, halo pixels} quadruples on
+ * a device of G compute units (pixel split per problem, LPT deal of the (problem, tile, split) tasks to G persistent blocks).
+ * Returns the number of tasks (-1: bad argument / more than `cap`); tasks: 4 ints each (problem, tile, split, 0). */
+int vpd_op_wgrad128_schedule(int n, const int* dims4, int G, int* ksplit, int* blk_begin, int* tasks, int cap,
+                             double* est_us);
 
 #ifdef __cplusplus
 }

@@ -226,3 +226,54 @@ def test_tennis_teacher_ingestion(tmp_path):
     assert {it[1] for it in items} == {101, 103} and all(it[0].endswith("/front") for it in items)
     assert all(it[2].shape == (2, 16) for it in items)          # [emb, emb - prev] along the feature axis
     assert len({it[0] for it in tr.data} & {it[0] for it in va.data}) == 0      # split over clips
+
+
+def test_wgrad128_schedule_covers_every_task_once_and_balances():
+    """Host scheduler of conv_wgrad128_persistent_kernel (no GPU): every (problem, tile, split) appears exactly once, the
+    splits cover all 64-pixel chunks, block lists are contiguous, and the LPT deal is within Graham's 4/3 bound of the
+    trivial lower bounds.  Shapes: the ResNet-34 launches of the 256-crop step (layer2; layer3 + layer4 together) and a
+    ragged mix on an odd number of compute units."""
+    import ctypes as C
+    from vpd_amd._lib import lib
+    L = lib()
+    cases = {
+        "layer2": ([(256 * 256, 128, 128, 108)] * 7, 256),
+        "layer3+4": ([(256 * 64, 256, 256, 100)] * 11 + [(256 * 16, 512, 512, 144)] * 5, 256),
+        "ragged": ([(5 * 64 + 16, 256, 128, 100), (77 * 256, 128, 64, 108), (3 * 16, 512, 512, 144)], 37),
+    }
+    for name, (probs, G) in cases.items():
+        n = len(probs)
+        dims = (C.c_int * (4 * n))(*[v for p in probs for v in p])
+        ks = (C.c_int * n)()
+        bb = (C.c_int * (G + 1))()
+        cap = 1 << 15
+        tk = (C.c_int * (4 * cap))()
+        est = C.c_double()
+        nt = L.vpd_op_wgrad128_schedule(n, dims, G, ks, bb, tk, cap, C.byref(est))
+        assert nt > 0, name
+        assert bb[0] == 0 and bb[G] == nt and all(bb[b] <= bb[b + 1] for b in range(G)), name
+        seen = set()
+        load = [0.0] * G
+        lens = []
+        for b in range(G):
+            for t in range(bb[b], bb[b + 1]):
+                pi, tile, split = tk[4 * t], tk[4 * t + 1], tk[4 * t + 2]
+                M, co, ci, _ = probs[pi]
+                nch = (M + 63) // 64
+                cpb = (nch + ks[pi] - 1) // ks[pi]
+                assert 0 <= tile < (co // 128) * (ci // 64) and 0 <= split < ks[pi], name
+                assert split * cpb < nch, (name, "empty split")
+                assert (pi, tile, split) not in seen, name
+                seen.add((pi, tile, split))
+                ln = min(cpb, nch - split * cpb)
+                load[b] += ln
+                lens.append(ln)
+        want = sum((co // 128) * (ci // 64) * ks[i] for i, (M, co, ci, _) in enumerate(probs))
+        assert len(seen) == nt == want, name
+        for i, (M, co, ci, _) in enumerate(probs):      # every chunk of every tile is covered by exactly one split
+            nch = (M + 63) // 64
+            cpb = (nch + ks[i] - 1) // ks[i]
+            assert (ks[i] - 1) * cpb < nch <= ks[i] * cpb, name
+        lower = max(sum(lens) / G, max(lens))
+        assert max(load) <= 4.0 / 3.0 * lower + max(lens) * 0.34 + 1e-9, (name, max(load), lower)
+        assert est.value > 0

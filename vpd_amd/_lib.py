@@ -60,6 +60,8 @@ SIGNATURES = {
     "vpd_op_wgrad128_table_bytes": (C.c_size_t, []),
     "vpd_op_wgrad128_slab_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "vpd_op_wgrad128_group": (C.c_int, [C.c_int, vp, vp, vp, vp, c_int_p, vp, vp]),
+    "vpd_op_wgrad128_schedule": (C.c_int, [C.c_int, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p, C.c_int,
+                                           C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -1312,6 +1312,30 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     out->grid = G;
 }
 
+// Host-only view of the schedule for the tests (no GPU needed): problems as {M, Co, Ci, NHP} quadruples; returns the number of
+// tasks and fills ksplit[n], blk_begin[G + 1] and tasks[4 * ntasks] (capacity `cap` tasks; -1 if it does not fit).
+extern "C" int vpd_op_wgrad128_schedule(int n, const int* dims4, int G, int* ksplit, int* blk_begin, int* tasks, int cap,
+                                        double* est_us) {
+    if (n < 1 || n > WG2_MAX || G < 1 || !dims4 || !ksplit || !blk_begin || !tasks) return -1;
+    WgradParams ps[WG2_MAX];
+    WgHaloGeom gs[WG2_MAX];
+    memset(ps, 0, sizeof ps);
+    memset(gs, 0, sizeof gs);
+    for (int i = 0; i < n; ++i) {
+        ps[i].M = dims4[4 * i]; ps[i].Co = dims4[4 * i + 1]; ps[i].Kc = dims4[4 * i + 2]; gs[i].NHP = dims4[4 * i + 3];
+        if (ps[i].M < 1 || ps[i].Co % 128 || ps[i].Kc % 64 || gs[i].NHP < 1) return -1;
+    }
+    Wg2Schedule sch;
+    wg2_build(ps, gs, n, G, &sch);
+    const int nt = (int)sch.tasks.size() / 4;
+    if (nt > cap) return -1;
+    for (int i = 0; i < n; ++i) ksplit[i] = sch.ksplit[i];
+    for (int b = 0; b <= G; ++b) blk_begin[b] = sch.blk_begin[b];
+    for (size_t i = 0; i < sch.tasks.size(); ++i) tasks[i] = sch.tasks[i];
+    if (est_us) *est_us = sch.est_us;
+    return nt;
+}
+
 size_t vpd_wgrad128_table_bytes() { return (size_t)1 << 17; }       // device table of one launch: tasks + block index
 
 // One launch for `n` eligible problems (ps[i].slab: vpd_wgrad_group_slab_floats() floats of its own).  `cache` (may be
