@@ -823,7 +823,7 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
 // taps (56 KiB) stay resident; structure as conv3x3_c64_persistent_kernel.
 // ---------------------------------------------------------------------------
 template <int HROWS, int EPM>
-__global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvParams p, int TR, int ntiles, long xelems) {
+__global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvParams p, int TR, int ntiles, long xelems, int lds_store) {
     constexpr int BM = 128, BN = 64, WM = 4, WN = 1;
     constexpr int WTM = BM / WM;
     constexpr int MI = WTM / 16, NI = 4;
@@ -927,7 +927,45 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-        conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        if (!lds_store) {
+            conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        } else {
+            // Coalesced store path: the accumulator layout gives a lane 4 channels of 16 different pixels (32-byte pieces of
+            // 16 rows per store instruction).  The wave parks its 32 pixels x 64 channels in LDS (136-byte pixel pitch) and
+            // reads them back pixel-major: 16 bytes per lane, 8 consecutive dense NHWC pixels = 1 KiB contiguous per
+            // instruction.  Only the wave's own pixels are involved: no block barrier.
+            bf16_t* sT = reinterpret_cast<bf16_t*>(red) + 1024 + wm * 32 * 68;
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int ml = b * 16 + fr;
+                const bool valid = t * BM + wm * WTM + ml < geo.M;
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    uint2 ov;
+                    ov.x = pack2bf(acc[a][b][0], acc[a][b][1]);
+                    ov.y = pack2bf(acc[a][b][2], acc[a][b][3]);
+                    *reinterpret_cast<uint2*>(sT + ml * 68 + a * 16 + 4 * fq) = ov;
+                    if (EPM == 1 && valid) {
+                        const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
+                        const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
+                        st1[a][0] += q0; st2[a][0] += q0 * q0;
+                        st1[a][1] += q1; st2[a][1] += q1 * q1;
+                        st1[a][2] += q2; st2[a][2] += q2 * q2;
+                        st1[a][3] += q3; st2[a][3] += q3 * q3;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int pl = lane >> 3, pc = (lane & 7) << 3;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int ml = it * 8 + pl;
+                const int m = t * BM + wm * WTM + ml;
+                const uint2 lo = *reinterpret_cast<const uint2*>(sT + ml * 68 + pc);
+                const uint2 hi = *reinterpret_cast<const uint2*>(sT + ml * 68 + pc + 4);
+                if (m < geo.M) *reinterpret_cast<uint4*>(p.y + (size_t)m * 64 + pc) = uint4{lo.x, lo.y, hi.x, hi.y};
+            }
+        }
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (EPM == 1) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
@@ -948,11 +986,15 @@ static bool stem_eligible(const ConvParams& p, int* TR) {
 static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const int ntiles = p.M / 128;
     const int grid = ntiles < 256 ? ntiles : 256;
-    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048;
+    // statistics scratch (2 KiB) + the coalesced-store staging of the four MFMA waves (4 x 32 pixels x 136 B)
+    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 + 4 * 32 * 68 * sizeof(bf16_t);
     const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
     ConvParams q = p;
-    if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
-    else VPD_LAUNCH((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems);
+    // dense 64-channel output (the stem's only use): stores through LDS, 1 KiB contiguous per instruction (VPD_STEM_LDS_STORE=0: direct)
+    static const int lds_store_on = getenv("VPD_STEM_LDS_STORE") ? atoi(getenv("VPD_STEM_LDS_STORE")) : 1;
+    const int lds_store = lds_store_on && p.ypad == 0 && p.yC == 64 && p.osub == 1 && p.yWp == p.Ws && p.yHp == p.Hs;
+    if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, lds_store);
+    else VPD_LAUNCH((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, lds_store);
     return hipGetLastError();
 }
 
