@@ -1097,6 +1097,11 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
             const long t128 = (long)((p.M + 127) / 128) * (p.Co / 128);
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
+            // 256 pixels x 64 channels: the FLOPs of a 128 x 128 tile for 30 % fewer staged bytes per K-step (8 KB of weights +
+            // 1/9 of a 52 KB halo instead of 16 KB + 1/9 of 36 KB) where 256-pixel tiles alone would leave half the chip idle
+            // (layer3 at 256 crops: 64 pixel tiles x 4 channel tiles)
+            static const int w64 = getenv("VPD_WS_256x64") ? atoi(getenv("VPD_WS_256x64")) : 1;
+            if (w64 && t128 >= 200 && (long)((p.M + 255) / 256) * (p.Co / 64) >= 200 && halo_geom(p, 256, 416, g)) return 6;
             if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 3;    // few pixel tiles: 64-channel tiles fill the chip
         } else if (p.Kc == 64 && p.Co == 64 && halo_geom(p, 128, 224, g)) {
             return 0;      // 64 -> 64 channels (layer1): persistent blocks with resident weights
@@ -1140,6 +1145,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
         case 2: return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
         case 3: return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
+        case 6: return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }

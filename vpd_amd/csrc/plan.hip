@@ -649,7 +649,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         flops += conv_flops(av, c.n);
     }
     const int kc = vpd_conv_kernel_class(q);
-    TimeScope ts(c.p, c.s, kc == 5 ? 7 : kc, flops);      // slot 7: stem kernel (5, 6 are the wgrads)
+    TimeScope ts(c.p, c.s, kc == 5 ? 7 : (kc == 6 ? 2 : kc), flops);      // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2
     return vpd_launch_conv(q, c.s);
 }
 
@@ -726,7 +726,8 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
             q.bnb = *bnb;
             q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
         }
-        TimeScope ts(c.p, c.s, vpd_conv_kernel_class(q), conv_flops(cv, c.n));
+        const int kcd = vpd_conv_kernel_class(q);
+        TimeScope ts(c.p, c.s, kcd == 6 ? 2 : kcd, conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
     if (bnb) return hipErrorInvalidValue;
