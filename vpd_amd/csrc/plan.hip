@@ -486,9 +486,12 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             p->gslab_off = bp.take(mx * 4);
             for (int s2 = 0; s2 < 4; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
-        p->relu_bits = !bottleneck && !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
+        p->relu_bits = !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
         if (p->relu_bits)
-            for (auto& B : p->blocks) B.mask_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co / 8 + 16);
+            for (auto& B : p->blocks) {
+                const ConvInfo& last = bottleneck ? B.c3 : B.c2;      // the conv whose BatchNorm feeds the block-output ReLU
+                B.mask_off = bp.take((size_t)NB * last.Hout * last.Wout * last.Co / 8 + 16);
+            }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -1078,11 +1081,12 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1));
             LCHECK(run_conv_train(c, B.c3, a2, bn_running));
+            unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
             if (B.ds) {
                 LCHECK(run_conv_train(c, B.cd, cur, bn_running));
-                LCHECK(run_bn_fwd(c, B.c3, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1));
+                LCHECK(run_bn_fwd(c, B.c3, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1, mb3));
             } else {
-                LCHECK(run_bn_fwd(c, B.c3, bn_running, 1, cur, nullptr, outp, 1));
+                LCHECK(run_bn_fwd(c, B.c3, bn_running, 1, cur, nullptr, outp, 1, mb3));
             }
             cur = outp;
             continue;
@@ -1276,8 +1280,10 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             bf16_t* dz3 = c.b16(S.dz3_off);
             bf16_t* da2 = c.b16(p->T_off[0]);
             bf16_t* da1b = c.b16(p->T_off[1]);
-            // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout
-            LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads));
+            // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout -- or, for identity blocks with the ReLU bit map,
+            // leaves dout alone: conv1's data gradient masks it when it adds the identity path (as in the BasicBlock path)
+            const unsigned char* mb3 = (!B.ds && relu_bits_ok(c, B.c3)) ? reinterpret_cast<const unsigned char*>(ws + B.mask_off) : nullptr;
+            LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
             LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
             LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
@@ -1293,7 +1299,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
                 gi = (gi + 2) % 3;
             } else {
-                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1));      // dout holds g: identity path + conv path
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mb3));      // identity path + conv path
             }
             if (stage_end(bi)) return -1;
             continue;
