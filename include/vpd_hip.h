@@ -195,10 +195,11 @@ int vpd_op_wgrad(const void* dz_bf16, const void* x_bf16, float* dw, int n, int 
 size_t vpd_op_wgrad_slab_bytes(void);
 /* dumps the ds_read_b64_tr_b16 fragments of one [128][64] bf16 tile: out [4][4][64][8] bf16 */
 int vpd_op_tr_read_probe(const void* tile_bf16, void* out_bf16, void* stream);
-/* Grouped 128(co) x 64(ci) weight gradients of `nprob` 3x3 pad-1 convolutions (stride 1 or 2) in ONE persistent launch (the
+/* Grouped weight gradients of `nprob` 3x3 pad-1 / 1x1 pad-0 convolutions (stride 1 or 2) on 128-channel-wide tiles in ONE persistent launch (the
  * form vpd_backward uses per ResNet stage; reference: the weight half of loss.backward(), models/util.py:52).
- * dims: 6 ints per problem {n, H, W, Co, Ci, stride} (H, W: output size; stride 1 or 2); dz[i]: zero-bordered bf16 NHWC
- * [n][H+2][W+2][Co]; x[i]: zero-bordered bf16 NHWC [n][stride*H+2][stride*W+2][Ci]; dw[i]: fp32 [9][Co][Ci]; slab[i]: vpd_op_wgrad128_slab_floats(Co, Ci) floats; dev_table: vpd_op_wgrad128_table_bytes() bytes. */
+ * dims: 7 ints per problem {n, H, W, Co, Ci, stride, k} (H, W: output size; stride 1 or 2; k = 3: 3x3 pad 1, k = 1: 1x1 pad 0);
+ * dz[i]: zero-bordered bf16 NHWC [n][H+2][W+2][Co]; x[i]: zero-bordered bf16 NHWC [n][stride*H+2][stride*W+2][Ci]; dw[i]: fp32
+ * [k*k][Co][Ci]; slab[i]: vpd_op_wgrad128_slab_floats(Co, Ci) floats; dev_table: vpd_op_wgrad128_table_bytes() bytes. */
 size_t vpd_op_wgrad128_table_bytes(void);
 size_t vpd_op_wgrad128_slab_floats(int Co, int Ci);
 int vpd_op_wgrad128_group(int nprob, const void* const* dz, const void* const* x, float* const* dw, float* const* slab,

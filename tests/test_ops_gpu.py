@@ -228,7 +228,7 @@ def test_stem_conv_and_wgrad():
 
 
 WG128_GROUPS = {
-    # one launch each: (n, H, W, Co, Ci, stride) per problem, H x W the OUTPUT size.  Different halo geometries share a launch
+    # one launch each: (n, H, W, Co, Ci, stride[, k]) per problem, H x W the OUTPUT size, k = 3 (default) or 1.  Different halo geometries share a launch
     # (layer3 + layer4 shapes), ragged final chunks (n * H * W not a multiple of 64), several tiles per problem, pixel splits
     # with a slab, and the stride-2 3x3 of a stage's first block (two-stage ring) beside stride-1 problems (four stages)
     "layer2_like": [(9, 16, 16, 128, 128, 1), (9, 16, 16, 128, 128, 1)],
@@ -237,6 +237,10 @@ WG128_GROUPS = {
     "many_chunks_split": [(40, 16, 16, 128, 64, 1), (33, 8, 8, 128, 128, 1)],
     "stride2_32to16_with_stride1": [(6, 16, 16, 128, 64, 2), (6, 16, 16, 128, 128, 1)],
     "stride2_16to8_and_8to4_ragged": [(5, 8, 8, 256, 128, 2), (5, 4, 4, 512, 256, 2), (5, 4, 4, 512, 512, 1)],
+    # 1x1 convolutions as tasks of the same launch: Bottleneck shapes (128 x 128 and 128 x 64 tiles, ragged chunks, splits),
+    # the stride-2 down-sampling branch, mixed with a 3x3 problem
+    "one_by_one_bottleneck": [(9, 16, 16, 128, 512, 1, 1), (9, 16, 16, 512, 128, 1, 1), (5, 8, 8, 256, 64, 1, 1)],
+    "one_by_one_stride2_with_3x3": [(6, 16, 16, 128, 64, 2, 1), (5, 4, 4, 512, 256, 2, 1), (6, 16, 16, 128, 128, 1, 3), (33, 8, 8, 1024, 256, 1, 1)],
 }
 
 
@@ -249,25 +253,26 @@ def test_wgrad128_group(name):
     g = torch.Generator().manual_seed(len(name))
     keep, refs = [], []
     dzs, xs, dws, slabs, dims = [], [], [], [], []
-    for (n, h, w, co, ci, st) in probs:
+    probs = [pr if len(pr) == 7 else pr + (3,) for pr in probs]
+    for (n, h, w, co, ci, st, ks) in probs:
         x = bf16_round(torch.randn(n, ci, st * h, st * w, generator=g))
         dz = bf16_round(torch.randn(n, co, h, w, generator=g))
-        wr = torch.zeros(co, ci, 3, 3, requires_grad=True)
-        F.conv2d(x, wr, None, stride=st, padding=1).backward(dz)
+        wr = torch.zeros(co, ci, ks, ks, requires_grad=True)
+        F.conv2d(x, wr, None, stride=st, padding=ks // 2).backward(dz)
         refs.append(wr.grad)
         xp, dzp = to_padded_nhwc(x, 1, 1, 1, 1), to_padded_nhwc(dz, 1, 1, 1, 1)
-        dw = torch.full((9, co, ci), float("nan"), dtype=torch.float32, device="cuda")      # the kernel OVERWRITES
+        dw = torch.full((ks * ks, co, ci), float("nan"), dtype=torch.float32, device="cuda")      # the kernel OVERWRITES
         slab = torch.empty(max(int(L.vpd_op_wgrad128_slab_floats(co, ci)), 4), dtype=torch.float32, device="cuda")
         keep += [xp, dzp, dw, slab]
         dzs.append(dzp.data_ptr()); xs.append(xp.data_ptr()); dws.append(dw.data_ptr()); slabs.append(slab.data_ptr())
-        dims += [n, h, w, co, ci, st]
+        dims += [n, h, w, co, ci, st, ks]
     k = len(probs)
     arr = lambda v: (C.c_void_p * k)(*v)
     table = torch.empty(int(L.vpd_op_wgrad128_table_bytes()), dtype=torch.uint8, device="cuda")
-    _check(L.vpd_op_wgrad128_group(k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (6 * k))(*dims), ptr(table),
+    _check(L.vpd_op_wgrad128_group(k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (7 * k))(*dims), ptr(table),
                                    stream()))
     torch.cuda.synchronize()
-    for i, (n, h, w, co, ci, st) in enumerate(probs):
-        got = keep[4 * i + 2].cpu().view(3, 3, co, ci).permute(2, 3, 0, 1)
+    for i, (n, h, w, co, ci, st, ks) in enumerate(probs):
+        got = keep[4 * i + 2].cpu().view(ks, ks, co, ci).permute(2, 3, 0, 1)
         assert torch.isfinite(got).all(), (name, i)
         assert rel_l2(got, refs[i]) < REL_TOL, (name, i, rel_l2(got, refs[i]))

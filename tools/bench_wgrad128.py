@@ -25,22 +25,24 @@ def run(name, probs, reps=20):
     g = torch.Generator(device="cuda").manual_seed(1)
     keep, dzs, xs, dws, slabs, dims = [], [], [], [], [], []
     flops = 0.0
-    for (n, h, w, co, ci, st) in probs:
+    for pr in probs:
+        n, h, w, co, ci, st = pr[:6]
+        ks = pr[6] if len(pr) > 6 else 3
         x = torch.zeros(n, st * h + 2, st * w + 2, ci, dtype=torch.bfloat16, device="cuda")
         x[:, 1:-1, 1:-1, :] = torch.randn(n, st * h, st * w, ci, generator=g, device="cuda").clamp_min(0).to(torch.bfloat16)      # post-ReLU activations: half zeros, as in the step
         dz = torch.zeros(n, h + 2, w + 2, co, dtype=torch.bfloat16, device="cuda")
         dz[:, 1:-1, 1:-1, :] = torch.randn(n, h, w, co, generator=g, device="cuda").to(torch.bfloat16)
-        dw = torch.empty(9, co, ci, dtype=torch.float32, device="cuda")
+        dw = torch.empty(ks * ks, co, ci, dtype=torch.float32, device="cuda")
         slab = torch.empty(max(int(L.vpd_op_wgrad128_slab_floats(co, ci)), 4), dtype=torch.float32, device="cuda")
         keep += [x, dz, dw, slab]
         dzs.append(dz.data_ptr()); xs.append(x.data_ptr()); dws.append(dw.data_ptr()); slabs.append(slab.data_ptr())
-        dims += [n, h, w, co, ci, st]
-        flops += 2.0 * n * h * w * co * ci * 9
+        dims += [n, h, w, co, ci, st, ks]
+        flops += 2.0 * n * h * w * co * ci * ks * ks
     k = len(probs)
     arr = lambda v: (C.c_void_p * k)(*v)
     table = torch.empty(int(L.vpd_op_wgrad128_table_bytes()), dtype=torch.uint8, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    args = (k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (6 * k))(*dims), C.c_void_p(table.data_ptr()), st)
+    args = (k, arr(dzs), arr(xs), arr(dws), arr(slabs), (C.c_int * (7 * k))(*dims), C.c_void_p(table.data_ptr()), st)
     for _ in range(3):
         check(L.vpd_op_wgrad128_group(*args), "wgrad128")
     torch.cuda.synchronize()

@@ -754,16 +754,16 @@ static int wg_group_cpb_env() {
     return v;
 }
 // splits a problem may use at most: its slab share is capped at 16 MB (plan-time allocation)
-int vpd_wgrad_group_max_splits(int Co, int Kc) {
-    const size_t per = (size_t)9 * Co * Kc * 4;
+int vpd_wgrad_group_max_splits(int Co, int Kc, int ntaps) {
+    const size_t per = (size_t)ntaps * Co * Kc * 4;
     size_t cap = ((size_t)16 << 20) / per;
     if (cap > 64) cap = 64;
     return cap < 2 ? 1 : (int)cap;
 }
-size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc) {
+size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc, int ntaps) {
     (void)M;
-    const int cap = vpd_wgrad_group_max_splits(Co, Kc);
-    return cap <= 1 ? 0 : (size_t)cap * 9 * Co * Kc;
+    const int cap = vpd_wgrad_group_max_splits(Co, Kc, ntaps);
+    return cap <= 1 ? 0 : (size_t)cap * ntaps * Co * Kc;
 }
 static void wg_group_choose(const WgradParams* ps, int n, int* ksplit) {
     int nch[WG_GROUP_MAX], tiles[WG_GROUP_MAX], cap[WG_GROUP_MAX];
@@ -771,7 +771,7 @@ static void wg_group_choose(const WgradParams* ps, int n, int* ksplit) {
     for (int i = 0; i < n; ++i) {
         nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
         tiles[i] = (ps[i].Co / 64) * (ps[i].Kc / 64);
-        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc);
+        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc, 9);
         if (cap[i] > nch[i]) cap[i] = nch[i];
         work += (double)nch[i] * tiles[i];
     }
@@ -943,6 +943,7 @@ struct Wg2Group {
     const int* blk_begin;                      // device: [grid + 1] first task of each block
     int stage_elems;                           // bf16 elements of the whole ring (the launch's dynamic LDS)
     int skew;                                  // see wg2_task
+    int kind[WG2_MAX];                         // 0: 3x3 (wg2_task); 1 / 2: 1x1 on 128 x 64 / 128 x 128 tiles (wg2_task_1x1)
     WgradParams p[WG2_MAX];
     WgHaloGeom g[WG2_MAX];
 };
@@ -1179,6 +1180,158 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
     }
 }
 
+// 1x1 convolutions (pad 0; stride 1 or 2) as tasks of the same persistent launch: dW[Co][Ci] = sum_m dz[m][Co]^T x[pix(m)][Ci],
+// a plain tall-K GEMM.  Tile 128(co) x TCI(ci), TCI = 64 or 128; per 64-pixel chunk the dz tile (two [64][64] halves) and the x
+// tile (TCI / 64 blocks of [64 px][64 ci], gathered pixel by pixel from the padded activation: (S*y + 1, S*x + 1)) come in by
+// LDS-DMA into a 4-stage ring; wave (ctile, cohalf) owns co 64*cohalf .. +63 and ci 16*ctile (+ 64 for the second block):
+// 8 or 16 MFMAs per chunk against 24-32 KB of operands -- these tasks are bound by the stream (51-65 FLOP per staged byte),
+// like the operator itself at small channel counts; what the launch buys over conv_wgrad_kernel is no atomics (fixed-order
+// slab sums), no launch of its own, and tiles that stream 2-4x fewer bytes per FLOP than its 64 x 64 ones.
+template <int TCI>
+static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const WgHaloGeom& g, int tile, int split, bf16_t* ring,
+                                                    int skew) {
+    constexpr int NB = TCI / 64;
+    constexpr int NS = 4;
+    constexpr int STAGE = (128 + 64 * NB) * 64;                       // bf16 elements
+    constexpr int PER = 2 + NB;                                       // LDS-DMA instructions per wave and chunk
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctile = wave & 3, cohalf = wave >> 2;
+    const int W = p.Ws, H = p.Hs, S = p.istr;
+    const int kct = p.Kc / TCI;
+    const int co0 = (tile / kct) * 128;
+    const int ci0 = (tile % kct) * TCI;
+    const int nchunks_total = (p.M + WG_CH - 1) / WG_CH;
+    const int chunk_begin = split * g.cpb;
+    int chunk_end = chunk_begin + g.cpb;
+    chunk_end = chunk_end < nchunks_total ? chunk_end : nchunks_total;
+    const int nch = chunk_end - chunk_begin;
+
+    const int piece = lane & 7, lrow = lane >> 3;
+    const int TR = g.TR;
+    const int cpi = g.multi ? 1 : H / TR;
+    const int ipc = g.multi ? TR / H : 1;
+    int zlane[2], zrow[2], xlane[NB];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = wave * 2 + k;
+        const int row = (i & 7) * 8 + lrow;
+        const int lr = row / W, xx = row - lr * W;
+        const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+        const int img = g.multi ? lr / H : 0, yy = g.multi ? lr % H : lr;
+        zlane[k] = ((img * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cohalf * 64 + cpc * 8;
+        zrow[k] = row;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int j = wave * NB + k;                                  // x instruction: block j >> 3, rows (j & 7) * 8 ..
+        const int row = (j & 7) * 8 + lrow;
+        const int lr = row / W, xx = row - lr * W;
+        const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+        const int img = g.multi ? lr / H : 0, yy = g.multi ? lr % H : lr;
+        xlane[k] = ((img * p.xHp + S * yy + 1) * p.xWp + S * xx + 1) * p.xC + ci0 + (j >> 3) * 64 + cpc * 8;
+    }
+    int is_c = 0, is_b, is_y;
+    {
+        const int ch = chunk_begin;
+        if (g.multi) { is_b = ch * ipc; is_y = 0; }
+        else { is_b = ch / cpi; is_y = (ch - is_b * cpi) * TR; }
+    }
+    const unsigned ring_lds = (unsigned)(size_t)(wg_lptr_t)ring;
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int ch = chunk_begin + is_c;
+        const unsigned st_lds = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((is_c & (NS - 1)) * STAGE * 2));
+        const bf16_t* zb = p.dz + ((size_t)is_b * p.dzHp + is_y) * p.dzWp * p.dzC;
+        const bf16_t* xb = p.x + ((size_t)is_b * p.xHp + S * is_y) * p.xWp * p.xC;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = wave * 2 + k;
+            const bf16_t* src = (ch * WG_CH + zrow[k] < p.M) ? zb + zlane[k] : p.dz + (zlane[k] & 63);      // zero border pixel
+            wg2_lds_dma16(src, st_lds + (unsigned)(i * 8 * 64 * 2));
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int j = wave * NB + k;
+            // rows past the end of a ragged last chunk meet zero dz rows: any finite x will do (the first pixels of the tensor)
+            const bf16_t* src = (ch * WG_CH + (j & 7) * 8 + lrow < p.M) ? xb + xlane[k] : p.x + (xlane[k] & 63);
+            wg2_lds_dma16(src, st_lds + (unsigned)((128 + j * 8) * 64 * 2));
+        }
+        ++is_c;
+        if (g.multi) is_b += ipc;
+        else { is_y += TR; if (is_y >= H) { is_y = 0; ++is_b; } }
+    };
+
+    const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    int offA0[2], offB0[2];                                           // byte offsets within a stage (k-step 0; +32 rows for k-step 1)
+    {
+        const int ra = 8 * gq + q;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = ra + 4 * h;
+            offA0[h] = 2 * (cohalf * 64 * 64 + r * 64 + ((wg_f(r) << 4) | (4 * pp)));
+            offB0[h] = 2 * (128 * 64 + r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));
+        }
+    }
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    typedef const char __attribute__((address_space(3))) * lds_cp;
+    auto frag2 = [&](lds_cp a0, lds_cp a1) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)a1);
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    f32x4 acc[NB][4];
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[u][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    __builtin_amdgcn_s_barrier();                                     // the previous task is done with the ring
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (k < nch) issue();
+    for (int c = 0; c < nch; ++c) {
+        int ahead = nch - 1 - c;
+        ahead = ahead < NS - 2 ? ahead : NS - 2;
+        wg2_wait_allow(ahead * PER);
+        __builtin_amdgcn_s_barrier();
+        const bool do_issue = is_c < nch;
+        if (do_issue && !(skew && cohalf)) issue();
+        const lds_cp sb = (lds_cp)(const char*)(ring + (c & (NS - 1)) * STAGE);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && do_issue && skew && cohalf) issue();
+            bf16x8 az[4], bx[NB];
+            const lds_cp a0 = sb + ks * 32 * 128 + offA0[0], a1 = sb + ks * 32 * 128 + offA0[1];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                az[a] = frag2((lds_cp)((unsigned)(size_t)a0 ^ (unsigned)(a << 5)), (lds_cp)((unsigned)(size_t)a1 ^ (unsigned)(a << 5)));
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                bx[u] = frag2(sb + u * 64 * 128 + ks * 32 * 128 + offB0[0], sb + u * 64 * 128 + ks * 32 * 128 + offB0[1]);
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[u][a], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // acc[u][a][j] = partial dW[co0 + 64*cohalf + a*16 + 4*gq + j][ci0 + 64*u + 16*ctile + i16]
+    float* out = g.ksplit > 1 ? p.slab + (size_t)split * p.Co * p.Kc : p.dw;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        float* o = out + (size_t)(co0 + cohalf * 64) * p.Kc + ci0 + 64 * u + 16 * ctile + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[u][a][j];
+    }
+}
+
 template <bool PIPE>
 __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2Group grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1187,14 +1340,36 @@ __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2
     for (int t = t0; t < t1; ++t) {
         const int4 tk = grp.tasks[t];
         const int pi = __builtin_amdgcn_readfirstlane(tk.x);
-        wg2_task<PIPE>(grp.p[pi], grp.g[pi], __builtin_amdgcn_readfirstlane(tk.y), __builtin_amdgcn_readfirstlane(tk.z), ring,
-                 grp.stage_elems, grp.skew);
+        const int tile = __builtin_amdgcn_readfirstlane(tk.y), split = __builtin_amdgcn_readfirstlane(tk.z);
+        const int kind = grp.kind[pi];
+        if (kind == 0) wg2_task<PIPE>(grp.p[pi], grp.g[pi], tile, split, ring, grp.stage_elems, grp.skew);
+        else if (kind == 1) wg2_task_1x1<64>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else wg2_task_1x1<128>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
     }
 }
 
 // ---- host side: eligibility, split choice, LPT schedule ----
+// kind of a problem for the persistent launch: -1 not eligible, 0 3x3, 1 / 2 1x1 (pad 0: one tap at padded offset (1, 1)) on
+// 128 x 64 / 128 x 128 tiles
+static int wg2_kind_1x1(const WgradParams& p) {
+    static const int off = getenv("VPD_WG2_1X1") ? !atoi(getenv("VPD_WG2_1X1")) : 0;
+    if (off || !(p.taps.nr == 1 && p.taps.nc == 1 && p.taps.dy0 == 1 && p.taps.dx0 == 1) || p.one_by_one) return -1;
+    if (p.Co % 128 || p.Kc % 64 || p.xC != p.Kc || p.dzC % 128 || p.dzpad < 1 || (p.istr != 1 && p.istr != 2)) return -1;
+    if (p.xHp != p.istr * p.Hs + 2 || p.xWp != p.istr * p.Ws + 2 || p.dzHp != p.Hs + 2 * p.dzpad || p.dzWp != p.Ws + 2 * p.dzpad) return -1;
+    const int W = p.Ws, H = p.Hs;
+    if (W <= 0 || WG_CH % W) return -1;
+    const int TR = WG_CH / W;
+    if (TR <= H ? H % TR != 0 : TR % H != 0) return -1;
+    return p.Kc % 128 == 0 ? 2 : 1;
+}
+static void wg2_geom_1x1(const WgradParams& p, WgHaloGeom* g) {
+    memset(g, 0, sizeof *g);
+    const int TR = WG_CH / p.Ws;
+    g->TR = TR; g->multi = TR > p.Hs ? 1 : 0; g->NHP = 64; g->HR = 0; g->total_pix = p.N * p.xHp * p.xWp;
+}
 bool vpd_wgrad128_eligible(const WgradParams& p) {
     static const int off = getenv("VPD_WG2") ? !atoi(getenv("VPD_WG2")) : 0;
+    if (!off && wg2_kind_1x1(p) > 0) return true;
     WgHaloGeom g;
     WgradParams q = p;
     if (!q.slab) q.slab = reinterpret_cast<float*>(16);
@@ -1235,17 +1410,19 @@ static double wg2_lpt(const std::vector<std::pair<double, int>>& sorted, int G, 
     return mx;
 }
 
-static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G, Wg2Schedule* out) {
+static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G, Wg2Schedule* out, const int* kinds = nullptr) {
     // block order: the blocks of XCD 0 first (b = 0, 8, 16, ...), then XCD 1, ...: equal-length tasks are dealt in task order
     // to equally loaded blocks, so consecutive tasks (the tiles of one pixel range) land on one XCD
     std::vector<int> order;
     for (int x = 0; x < 8; ++x)
         for (int b = x; b < G; b += 8) order.push_back(b);
-    int nch[WG2_MAX], tiles[WG2_MAX], cap[WG2_MAX];
+    int nch[WG2_MAX], tiles[WG2_MAX], cap[WG2_MAX], ntap[WG2_MAX];
     for (int i = 0; i < n; ++i) {
+        const int kind = kinds ? kinds[i] : 0;
         nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
-        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / 64);
-        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc);
+        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / (kind == 2 ? 128 : 64));
+        ntap[i] = kind ? 1 : 9;
+        cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc, ntap[i]);
         if (cap[i] > nch[i]) cap[i] = nch[i];
     }
     // per-chunk time of a 128 x 64 task: the larger of the MFMA time (1.15 us) and the stream (16 KB + halo at ~21 GB/s
@@ -1254,7 +1431,12 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     static const int cpb_env = getenv("VPD_WG2_CPB") ? atoi(getenv("VPD_WG2_CPB")) : 0;
     double best = 1e30;
     int best_ks[WG2_MAX];
-    auto tchunk = [&](int i) { const double st = (16.0 + (gs[i].NHP + 7) / 8) / 21.0; return st > 1.15 ? st : 1.15; };
+    auto tchunk = [&](int i) {
+        const int kind = kinds ? kinds[i] : 0;
+        if (kind) return (16.0 + 8.0 * kind) / 21.0;      // 1x1: the stream alone (8 or 16 MFMAs per chunk and wave)
+        const double st = (16.0 + (gs[i].NHP + 7) / 8) / 21.0;
+        return st > 1.15 ? st : 1.15;
+    };
     auto eval = [&](double target) {
         int ks[WG2_MAX];
         std::vector<std::pair<double, int>> tl;
@@ -1270,7 +1452,7 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
                 const int c1 = (s + 1) * cpb < nch[i] ? (s + 1) * cpb : nch[i];
                 for (int t = 0; t < tiles[i]; ++t) tl.push_back({(c1 - s * cpb) * tchunk(i) + t_fixed, 0});
             }
-            if (k > 1) { slab += (double)k * 9 * ps[i].Co * ps[i].Kc * 4; any = true; }
+            if (k > 1) { slab += (double)k * ntap[i] * ps[i].Co * ps[i].Kc * 4; any = true; }
         }
         std::stable_sort(tl.begin(), tl.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
         const double cost = wg2_lpt(tl, G, order, nullptr) + 2.0 * slab / bw + (any ? 3.0 : 0.0);
@@ -1362,9 +1544,13 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     WgReduceGroup red = {};
     grp.nprob = n;
     int nhi_max = 0;
+    int kinds[WG2_MAX];
     for (int i = 0; i < n; ++i) {
         if (!vpd_wgrad128_eligible(ps[i])) return hipErrorInvalidValue;
         grp.p[i] = ps[i];
+        const int k1 = wg2_kind_1x1(ps[i]);
+        kinds[i] = grp.kind[i] = k1 > 0 ? k1 : 0;
+        if (k1 > 0) { wg2_geom_1x1(ps[i], &grp.g[i]); continue; }
         if (!wg_halo_geom(ps[i], &grp.g[i])) return hipErrorInvalidValue;
         const int nhi = (grp.g[i].NHP + 7) / 8;
         nhi_max = nhi > nhi_max ? nhi : nhi_max;
@@ -1373,9 +1559,9 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     Wg2Cache* c = cache_v ? static_cast<Wg2Cache*>(cache_v) : &local;
     bool same = c->n == n && c->uploaded_to == dev_table;
     for (int i = 0; i < n && same; ++i)
-        same = c->sig[i][0] == ps[i].M && c->sig[i][1] == ps[i].Co && c->sig[i][2] == ps[i].Kc && c->sig[i][3] == grp.g[i].NHP;
+        same = c->sig[i][0] == ps[i].M && c->sig[i][1] == ps[i].Co && c->sig[i][2] == ps[i].Kc && c->sig[i][3] == grp.g[i].NHP + 1000 * kinds[i];
     if (!same) {
-        wg2_build(ps, grp.g, n, ncu, &c->sch);
+        wg2_build(ps, grp.g, n, ncu, &c->sch, kinds);
         c->n = n;
         if (getenv("VPD_WG2_DEBUG")) {
             int mx = 0, mn = 1 << 30;
@@ -1388,7 +1574,7 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
             for (int i = 0; i < n; ++i) fprintf(stderr, " %d", c->sch.ksplit[i]);
             fprintf(stderr, "\n");
         }
-        for (int i = 0; i < n; ++i) { c->sig[i][0] = ps[i].M; c->sig[i][1] = ps[i].Co; c->sig[i][2] = ps[i].Kc; c->sig[i][3] = grp.g[i].NHP; }
+        for (int i = 0; i < n; ++i) { c->sig[i][0] = ps[i].M; c->sig[i][1] = ps[i].Co; c->sig[i][2] = ps[i].Kc; c->sig[i][3] = grp.g[i].NHP + 1000 * kinds[i]; }
         const size_t tb = c->sch.tasks.size() * sizeof(int), bb = c->sch.blk_begin.size() * sizeof(int);
         if (tb + bb + 64 > vpd_wgrad128_table_bytes()) return hipErrorInvalidValue;
         hipError_t e = hipMemcpyAsync(dev_table, c->sch.tasks.data(), tb, hipMemcpyHostToDevice, stream);
@@ -1402,10 +1588,10 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     grp.tasks = reinterpret_cast<const int4*>(dev_table);
     grp.blk_begin = reinterpret_cast<const int*>((char*)dev_table + ((sch.tasks.size() * sizeof(int) + 63) & ~(size_t)63));
     {
-        size_t need = 0;      // every problem's ring: 4 stages (stride 1) or 2 (stride 2)
+        size_t need = 0;      // every problem's ring: 4 stages (stride 1, and every 1x1) or 2 (3x3 stride 2)
         for (int i = 0; i < n; ++i) {
-            const size_t st = (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
-            const size_t want = (ps[i].istr == 1 ? 4 : 2) * st;
+            const size_t st = kinds[i] ? (size_t)(128 + 64 * kinds[i]) * 64 : (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
+            const size_t want = (kinds[i] || ps[i].istr == 1 ? 4 : 2) * st;
             need = want > need ? want : need;
         }
         grp.stage_elems = (int)need;
@@ -1423,7 +1609,7 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
         if (g.ksplit > 1) {
             red.slab[red.nprob] = reinterpret_cast<const float4*>(ps[i].slab);
             red.dw[red.nprob] = reinterpret_cast<float4*>(ps[i].dw);
-            red.n4[red.nprob] = (long)9 * ps[i].Co * ps[i].Kc / 4;
+            red.n4[red.nprob] = (long)(kinds[i] ? 1 : 9) * ps[i].Co * ps[i].Kc / 4;
             red.ksplit[red.nprob] = g.ksplit;
             max_n4 = red.n4[red.nprob] > max_n4 ? red.n4[red.nprob] : max_n4;
             max_ks = g.ksplit > max_ks ? g.ksplit : max_ks;

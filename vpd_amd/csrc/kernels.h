@@ -71,7 +71,7 @@ hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
 size_t vpd_wgrad_slab_bytes();
 // grouped (per-stage, deferred) weight gradients: see WgGroup in conv_wgrad.hip
 bool vpd_wgrad_group_eligible(const WgradParams& p);
-size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc);
+size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc, int ntaps = 9);
 hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
 bool vpd_wgrad_overwrites(const WgradParams& p);
 // 128 x 64 tiles, persistent blocks, host-built schedule (conv_wgrad128_persistent_kernel in conv_wgrad.hip)

@@ -131,8 +131,8 @@ struct vpd_plan {
     bool lazy_next = false, grads_in_scratch = false;
     int nstem_unpack_blocks = 0;           // leading entries of bmap_unpack[3] that belong to the stem
     bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0: per stage)
-    size_t wg2_tbl_off[4] = {0, 0, 0, 0};      // task tables of the 128 x 64 persistent weight-gradient launches (one per stage)
-    void* wg2_cache[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t wg2_tbl_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // task tables of the persistent weight-gradient launches (two per stage)
+    void* wg2_cache[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
     bool timing = false;
     struct TimedLaunch { int cls; double flops; hipEvent_t a, b; };
@@ -457,34 +457,47 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         if (p->wg_group) {
             // slabs of one LAUNCH live side by side: with wg_merge34 the stages 2 and 3 (layer3, layer4) share a launch
             size_t stage_slab[4] = {0, 0, 0, 0};
-            for (auto& B : p->blocks)
-                for (ConvInfo* cv : {&B.c1, &B.c2}) {
-                    // stride-1 3x3 convs, and the stride-2 3x3 of a stage's first block when the 128 x 64 kernel takes it
-                    // (1x1 convs and the rest: their own launch)
-                    if (cv->slab_off < 0 || cv->k != 3) continue;
-                    if (cv->stride != 1) {
-                        // OFF by default (VPD_WG2_S2=1 enables): inside the stage's launch the three stride-2 problems cost
-                        // 86 us per step against 78 us as launches of their own -- their 55-66 KB per chunk leave room for a
-                        // two-stage ring only, one chunk of prefetch, and the tasks run at the DMA latency
+            auto wq = [&](const ConvInfo& cv) {
+                WgradParams q;
+                memset(&q, 0, sizeof q);
+                q.dzHp = cv.Hout + 2; q.dzWp = cv.Wout + 2; q.dzC = cv.Co; q.dzpad = 1;
+                q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci;
+                q.N = NB; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
+                q.M = NB * cv.Hout * cv.Wout; q.taps = conv_taps_fwd(cv);
+                return q;
+            };
+            for (auto& B : p->blocks) {
+                std::vector<ConvInfo*> cvs = {&B.c1, &B.c2};
+                if (bottleneck) cvs.push_back(&B.c3);
+                if (B.ds) cvs.push_back(&B.cd);
+                for (ConvInfo* cv : cvs) {
+                    if (cv->slab_off < 0) continue;
+                    if (cv->k == 1) {
+                        // 1x1 convolutions: tasks of the stage's persistent launch when it takes them (Co % 128 == 0 ...).
+                        // Bottleneck students: ResNet-50 step 9.32 -> 8.74 ms (36 launches of the atomics kernel at 47 us each
+                        // become tasks; no atomics left).  BasicBlock students keep their three down-sampling convs on
+                        // launches of their own (same-box: 3.945 vs 3.951 ms grouped); VPD_WG2_1X1_BASIC=1 groups them too.
+                        static const bool basic_too = getenv("VPD_WG2_1X1_BASIC") && atoi(getenv("VPD_WG2_1X1_BASIC"));
+                        if ((!bottleneck && !basic_too) || !vpd_wgrad128_eligible(wq(*cv))) continue;
+                    } else if (cv->k != 3) {
+                        continue;
+                    } else if (cv->stride != 1) {
+                        // stride-2 3x3: OFF by default (VPD_WG2_S2=1 enables): inside the stage's launch the three stride-2 problems
+                        // cost 86 us per step against 78 us as launches of their own -- their 55-66 KB per chunk leave room for
+                        // a two-stage ring only, one chunk of prefetch, and the tasks run at the DMA latency
                         static const bool s2_grouped = getenv("VPD_WG2_S2") && atoi(getenv("VPD_WG2_S2"));
-                        if (!s2_grouped) continue;
-                        WgradParams q;
-                        memset(&q, 0, sizeof q);
-                        q.dzHp = cv->Hout + 2; q.dzWp = cv->Wout + 2; q.dzC = cv->Co; q.dzpad = 1;
-                        q.xHp = cv->Hin + 2; q.xWp = cv->Win + 2; q.xC = cv->Ci;
-                        q.N = NB; q.Hs = cv->Hout; q.Ws = cv->Wout; q.istr = cv->stride; q.Kc = cv->Kc; q.Co = cv->Co;
-                        q.M = NB * cv->Hout * cv->Wout; q.taps = conv_taps_fwd(*cv);
-                        if (!vpd_wgrad128_eligible(q)) continue;
+                        if (!s2_grouped || !vpd_wgrad128_eligible(wq(*cv))) continue;
                     }
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
                     const int grp = (p->wg_merge34 && B.stage == 3) ? 2 : B.stage;
                     cv->gslab_off = (long long)stage_slab[grp];
-                    stage_slab[grp] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc);
+                    stage_slab[grp] += vpd_wgrad_group_slab_floats(NB * cv->Hout * cv->Wout, cv->Co, cv->Kc, cv->k == 1 ? 1 : 9);
                 }
+            }
             size_t mx = 16;
             for (int s2 = 0; s2 < 4; ++s2) mx = stage_slab[s2] > mx ? stage_slab[s2] : mx;
             p->gslab_off = bp.take(mx * 4);
-            for (int s2 = 0; s2 < 4; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
+            for (int s2 = 0; s2 < 8; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
         p->relu_bits = !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
         if (p->relu_bits)
@@ -515,7 +528,7 @@ extern "C" void vpd_plan_destroy(vpd_plan_t* p) {
     }
     for (auto& t : p->timed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto e : p->ev_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
         if (p->wg2_cache[i]) vpd_wgrad128_cache_free(p->wg2_cache[i]);
     delete p;
 }
@@ -1187,21 +1200,32 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     auto flush_group = [&](int slot) -> hipError_t {
         if (pending.empty()) return hipSuccess;
         hipError_t r = hipSuccess;
-        // 128 x 64 tiles (conv_wgrad128_persistent_kernel) for every conv that has them: one launch
+        // persistent 128-wide tiles (conv_wgrad128_persistent_kernel) for every conv it takes: one launch per 18 problems
+        // (a ResNet-50 stage has up to 19: two balanced launches)
         std::vector<Pending> rest;
         {
-            WgradParams qs[18];
-            int cnt = 0;
-            double flops = 0.0;
+            std::vector<WgradParams> elig;
+            std::vector<double> fl;
             for (const Pending& pd : pending) {
                 const WgradParams q = make_q(pd);
-                if (cnt < 18 && vpd_wgrad128_eligible(q)) { qs[cnt++] = q; flops += conv_flops(*pd.cv, n); }
+                if (vpd_wgrad128_eligible(q)) { elig.push_back(q); fl.push_back(conv_flops(*pd.cv, n)); }
                 else rest.push_back(pd);
             }
-            if (cnt > 0) {
-                if (!p->wg2_cache[slot]) p->wg2_cache[slot] = vpd_wgrad128_cache_new();
+            const int total = (int)elig.size();
+            const int nl = (total + 17) / 18;
+            int at = 0;
+            for (int l = 0; l < nl && r == hipSuccess; ++l) {
+                const int cnt = (total - at + (nl - l) - 1) / (nl - l);
+                double flops = 0.0;
+                for (int i = 0; i < cnt; ++i) flops += fl[at + i];
+                const int sl = (2 * slot + (l & 1)) & 7;
+                if (l >= 2) {      // more than 36 problems (ResNet-101's layer3): the table slots are reused -- new shapes per launch
+                    if (p->wg2_cache[sl]) { vpd_wgrad128_cache_free(p->wg2_cache[sl]); p->wg2_cache[sl] = nullptr; }
+                }
+                if (!p->wg2_cache[sl]) p->wg2_cache[sl] = vpd_wgrad128_cache_new();
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad128_group(qs, cnt, p->wg2_cache[slot], ws + p->wg2_tbl_off[slot], s);
+                r = vpd_launch_wgrad128_group(elig.data() + at, cnt, p->wg2_cache[sl], ws + p->wg2_tbl_off[sl], s);
+                at += cnt;
             }
         }
         size_t done = 0;
@@ -1277,7 +1301,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         bf16_t* dz2 = c.b16(grouped && B.c2.dz_own_off ? B.c2.dz_own_off : S.dz2_off[par]);
         bf16_t* dz1 = c.b16(grouped && B.c1.dz_own_off ? B.c1.dz_own_off : S.dz1_off[par]);
         if (p->bottleneck) {
-            bf16_t* dz3 = c.b16(S.dz3_off);
+            bf16_t* dz3 = c.b16(grouped && B.c3.dz_own_off ? B.c3.dz_own_off : S.dz3_off);
             bf16_t* da2 = c.b16(p->T_off[0]);
             bf16_t* da1b = c.b16(p->T_off[1]);
             // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout -- or, for identity blocks with the ReLU bit map,
@@ -1292,7 +1316,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
             LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
-                bf16_t* dzd = c.b16(S.dzd_off);
+                bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);
                 LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
                 LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // 1x1 stride 1: writes every input pixel
@@ -1325,7 +1349,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             fB.rows = c.bn_rows(B.cd.bn);
             fB.gamma = params + B.cd.bn.w_off; fB.dgamma = grads + B.cd.bn.w_off; fB.dbeta = grads + B.cd.bn.b_off;
             LCHECK(vpd_launch_bn_bwd_fused2(b, fA, fB, c.b16(B.cd.z_off), c.bn_mean(B.cd.bn), c.bn_rstd(B.cd.bn),
-                                            c.b16(S.dzd_off), s));
+                                            c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), s));
             bn_pair = true;
         }
         // plain (identity) blocks: ReLU mask from the forward's bit map; g = dout * mask is neither written back nor re-read --
@@ -1346,7 +1370,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         }
         LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
-            bf16_t* dzd = c.b16(S.dzd_off);       // one downsample conv per stage: no reuse hazard
+            bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);      // (its own buffer when it joins the stage's launch)
             if (!bn_pair) LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
             LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
             if (conv_pair_ok(c, B.c1, B.cd, true)) {
@@ -1582,27 +1606,32 @@ extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int
 }
 
 // Grouped 128 x 64 weight gradients (conv_wgrad128_persistent_kernel) of `nprob` 3x3 stride-1 pad-1 convolutions in ONE
-// launch.  dims: 6 ints per problem {n, H, W, Co, Ci, stride} (H, W: OUTPUT size; stride 1 or 2, 3x3 pad 1); dz[i]: padded
-// bf16 [n][H+2][W+2][Co]; x[i]: padded bf16 [n][stride*H+2][stride*W+2][Ci]; dw[i]: fp32 [9][Co][Ci]; slab[i]: fp32 scratch of vpd_op_wgrad128_slab_floats(Co, Ci) floats;
+// launch.  dims: 7 ints per problem {n, H, W, Co, Ci, stride, k} (H, W: OUTPUT size; stride 1 or 2; k = 3: 3x3 pad 1, k = 1: 1x1
+// pad 0); dz[i]: padded bf16 [n][H+2][W+2][Co]; x[i]: padded bf16 [n][stride*H+2][stride*W+2][Ci]; dw[i]: fp32 [k*k][Co][Ci]; slab[i]: fp32 scratch of vpd_op_wgrad128_slab_floats(Co, Ci) floats;
 // dev_table: vpd_op_wgrad128_table_bytes() of device memory.
 extern "C" size_t vpd_op_wgrad128_table_bytes(void) { return vpd_wgrad128_table_bytes(); }
-extern "C" size_t vpd_op_wgrad128_slab_floats(int Co, int Ci) { return vpd_wgrad_group_slab_floats(0, Co, Ci); }
+extern "C" size_t vpd_op_wgrad128_slab_floats(int Co, int Ci) { return vpd_wgrad_group_slab_floats(0, Co, Ci, 1) > vpd_wgrad_group_slab_floats(0, Co, Ci, 9) ? vpd_wgrad_group_slab_floats(0, Co, Ci, 1) : vpd_wgrad_group_slab_floats(0, Co, Ci, 9); }
 extern "C" int vpd_op_wgrad128_group(int nprob, const void* const* dz, const void* const* x, float* const* dw,
                                      float* const* slab, const int* dims, void* dev_table, void* stream) {
     if (nprob < 1 || nprob > 18 || !dz || !x || !dw || !slab || !dims || !dev_table) return fail("bad argument");
     WgradParams qs[18];
     for (int i = 0; i < nprob; ++i) {
-        const int n = dims[6 * i], H = dims[6 * i + 1], W = dims[6 * i + 2], Co = dims[6 * i + 3], Ci = dims[6 * i + 4];
-        const int S = dims[6 * i + 5];
-        if (S != 1 && S != 2) return fail("stride must be 1 or 2");
+        const int n = dims[7 * i], H = dims[7 * i + 1], W = dims[7 * i + 2], Co = dims[7 * i + 3], Ci = dims[7 * i + 4];
+        const int S = dims[7 * i + 5], ksz = dims[7 * i + 6];
+        if ((S != 1 && S != 2) || (ksz != 1 && ksz != 3)) return fail("stride must be 1 or 2, k 1 or 3");
         WgradParams q;
         memset(&q, 0, sizeof q);
         q.dz = (const bf16_t*)dz[i]; q.dzHp = H + 2; q.dzWp = W + 2; q.dzC = Co; q.dzpad = 1;
         q.x = (const bf16_t*)x[i]; q.xHp = S * H + 2; q.xWp = S * W + 2; q.xC = Ci;
         q.dw = dw[i]; q.slab = slab[i];
         q.N = n; q.Hs = H; q.Ws = W; q.istr = S; q.Kc = Ci; q.Co = Co; q.M = n * H * W;
-        q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
-        q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
+        if (ksz == 3) {
+            q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
+            q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
+        } else {
+            q.taps.nr = 1; q.taps.nc = 1; q.taps.dy0 = 1; q.taps.dys = 1; q.taps.dx0 = 1; q.taps.dxs = 1;
+            q.taps.w0 = 0; q.taps.wrs = 1; q.taps.wcs = 1;
+        }
         if (!vpd_wgrad128_eligible(q)) return fail("shape not eligible for the 128 x 64 weight-gradient kernel");
         qs[i] = q;
     }
