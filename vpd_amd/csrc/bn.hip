@@ -1124,7 +1124,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused2_kernel(const BnBwdParams p
 bool vpd_bn_bwd_fused2_ok(int M, int C) {
     static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
     static const int off2 = getenv("VPD_BN_PAIR") ? !atoi(getenv("VPD_BN_PAIR")) : 0;
-    return !(off || off2 || C % 8 || C < 64 || C > 1024 || 1024 % (C / 8)) && M >= 1;
+    // (three per-wave sum rows of C floats for 16 waves must leave LDS for the resident slices: C <= 512)
+    return !(off || off2 || C % 8 || C < 64 || C > 512 || 1024 % (C / 8)) && M >= 1;
 }
 
 // p: BatchNorm A as for vpd_launch_bn_bwd_fused (dy, act, z, mean, rstd, dz + geometry); fA / fB: rows, gamma, dgamma, dbeta

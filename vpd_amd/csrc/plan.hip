@@ -1289,6 +1289,31 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         if (bi > 0) return unpack_bucket(3 - B.stage);
         return 0;
     };
+    // block-output BatchNorm (A: the block's last conv) and the down-sampling branch's BatchNorm (Bc) in one launch: same dy,
+    // same ReLU mask (bn_bwd_fused2_kernel); false: not applicable here, the caller runs them one after the other
+    auto bn_bwd_pair = [&](const ConvInfo& A, const ConvInfo& Bc, bf16_t* dout_, const bf16_t* out_act, bf16_t* dzA,
+                           bf16_t* dzB, bool* done) -> int {
+        *done = false;
+        if (!(c.fused(A) && c.fused(Bc) && A.Co == Bc.Co && vpd_bn_bwd_fused2_ok(n * A.Hout * A.Wout, A.Co))) return 0;
+        BnBwdParams b;
+        memset(&b, 0, sizeof b);
+        b.dy = dout_; b.dy_rw = dout_; b.z = c.b16(A.z_off);
+        b.act = out_act; b.aHp = A.Hout + 2; b.aWp = A.Wout + 2; b.apad = 1;
+        b.mean = c.bn_mean(A.bn); b.rstd = c.bn_rstd(A.bn);
+        b.dz = dzA; b.dzHp = A.Hout + 2; b.dzWp = A.Wout + 2; b.dzpad = 1;
+        b.M = n * A.Hout * A.Wout; b.H = A.Hout; b.W = A.Wout; b.C = A.Co;
+        BnFusedBwd fA, fB;
+        fA.rows = c.bn_rows(A.bn); fA.sync = c.ws + A.bn.sync_off;
+        fA.err = reinterpret_cast<unsigned*>(c.ws + p->syncerr_off);
+        fA.gamma = params + A.bn.w_off; fA.dgamma = grads + A.bn.w_off; fA.dbeta = grads + A.bn.b_off;
+        fA.count = (float)b.M;
+        fB = fA;
+        fB.rows = c.bn_rows(Bc.bn);
+        fB.gamma = params + Bc.bn.w_off; fB.dgamma = grads + Bc.bn.w_off; fB.dbeta = grads + Bc.bn.b_off;
+        LCHECK(vpd_launch_bn_bwd_fused2(b, fA, fB, c.b16(Bc.z_off), c.bn_mean(Bc.bn), c.bn_rstd(Bc.bn), dzB, s));
+        *done = true;
+        return 0;
+    };
     std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
@@ -1307,7 +1332,11 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             // bn3 (+ReLU of the block output); leaves g = dout*[out>0] in dout -- or, for identity blocks with the ReLU bit map,
             // leaves dout alone: conv1's data gradient masks it when it adds the identity path (as in the BasicBlock path)
             const unsigned char* mb3 = (!B.ds && relu_bits_ok(c, B.c3)) ? reinterpret_cast<const unsigned char*>(ws + B.mask_off) : nullptr;
-            LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
+            bool bn3_pair = false;      // down-sampling block: bn3 and the 1x1 branch's BatchNorm in one launch
+            if (B.ds)
+                if (bn_bwd_pair(B.c3, B.cd, dout, c.b16(B.out_off), dz3,
+                                c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn3_pair)) return -1;
+            if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
             LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
             LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
@@ -1317,7 +1346,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
                 bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);
-                LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
+                if (!bn3_pair) LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
                 LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // 1x1 stride 1: writes every input pixel
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
@@ -1331,27 +1360,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout.  Already done when the NEXT block's conv1
         // data gradient (the previous iteration of this loop) carried it in its epilogue.
         bool bn_pair = false;      // conv2's BatchNorm and the 1x1 branch's BatchNorm in one launch (same dy, same ReLU mask)
-        if (B.ds && !bn2_fused_for[bi] && c.fused(B.c2) && c.fused(B.cd) && B.c2.Co == B.cd.Co &&
-            vpd_bn_bwd_fused2_ok(n * B.c2.Hout * B.c2.Wout, B.c2.Co)) {
-            BnBwdParams b;
-            memset(&b, 0, sizeof b);
-            b.dy = dout; b.dy_rw = dout; b.z = c.b16(B.c2.z_off);
-            b.act = c.b16(B.out_off); b.aHp = B.c2.Hout + 2; b.aWp = B.c2.Wout + 2; b.apad = 1;
-            b.mean = c.bn_mean(B.c2.bn); b.rstd = c.bn_rstd(B.c2.bn);
-            b.dz = dz2; b.dzHp = B.c2.Hout + 2; b.dzWp = B.c2.Wout + 2; b.dzpad = 1;
-            b.M = n * B.c2.Hout * B.c2.Wout; b.H = B.c2.Hout; b.W = B.c2.Wout; b.C = B.c2.Co;
-            BnFusedBwd fA, fB;
-            fA.rows = c.bn_rows(B.c2.bn); fA.sync = c.ws + B.c2.bn.sync_off;
-            fA.err = reinterpret_cast<unsigned*>(c.ws + p->syncerr_off);
-            fA.gamma = params + B.c2.bn.w_off; fA.dgamma = grads + B.c2.bn.w_off; fA.dbeta = grads + B.c2.bn.b_off;
-            fA.count = (float)b.M;
-            fB = fA;
-            fB.rows = c.bn_rows(B.cd.bn);
-            fB.gamma = params + B.cd.bn.w_off; fB.dgamma = grads + B.cd.bn.w_off; fB.dbeta = grads + B.cd.bn.b_off;
-            LCHECK(vpd_launch_bn_bwd_fused2(b, fA, fB, c.b16(B.cd.z_off), c.bn_mean(B.cd.bn), c.bn_rstd(B.cd.bn),
-                                            c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), s));
-            bn_pair = true;
-        }
+        if (B.ds && !bn2_fused_for[bi])
+            if (bn_bwd_pair(B.c2, B.cd, dout, c.b16(B.out_off), dz2,
+                            c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn_pair)) return -1;
         // plain (identity) blocks: ReLU mask from the forward's bit map; g = dout * mask is neither written back nor re-read --
         // conv1's data gradient, which adds the identity path, masks dout itself (ConvParams::acc_mask)
         const unsigned char* mbits = nullptr;
