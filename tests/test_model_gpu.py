@@ -337,6 +337,29 @@ def test_dgrad_with_batchnorm_backward_in_its_epilogue(tmp_path):
     assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
 
 
+def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
+    """Default path: the stride-1 3x3 data gradients of layers 2-4 add sum g and sum g*z of the BatchNorm that consumes
+    their output to its rows (conv_epilogue.h, EPM 6 / 7) and the BatchNorm launch only finalizes and applies
+    (bn_bwd_apply_fused_kernel); VPD_DGRAD_SUMS=0 is the separate reduce + barrier + apply launch.  Same g, same bf16
+    rounding points; the sums differ in their summation order and in sum g*xhat being formed from sum g*z in fp64."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("g%s.npy" % flag))
+        env = dict(os.environ, VPD_DGRAD_SUMS=flag)
+        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
+    (g0, l0), (g1, l1) = outs
+    assert l0 == l1
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
+    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
+
+
 def _group_of(name):
     return "fc" if ".fc." in name else (name.split(".")[1] if name.split(".")[1].startswith("layer") else "stem")
 

@@ -979,6 +979,72 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
 #undef LD8
 }
 
+// BatchNorm backward, finalize + apply only: the data-gradient convolution that produced dy has added sum g and sum g * z
+// (g = dy * mask) to this BatchNorm's rows in its epilogue (conv_epilogue.h, EPM 6 / 7), so the reduction pass, the atomics
+// and the grid barrier of bn_bwd_fused_kernel are gone.  sum g * xhat = (sum g*z - mean * sum g) * rstd (fp64), and
+// dz = c1 * (g - c2 - xhat * c3) is evaluated as A*g + B*z + D with per-channel A = gamma*rstd, B = -A*rstd*c3,
+// D = -A*c2 - B*mean.
+struct BnBwdApplyArgs {
+    const double* rows; float count;
+    const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta;
+};
+__global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdParams p, const BnBwdApplyArgs f) {
+    extern __shared__ float sm[];                      // A[C] B[C] D[C]
+    const int C = p.C;
+    float* sA = sm; float* sB = sm + C; float* sD = sm + 2 * C;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        double s1 = 0.0, sz = 0.0;
+#pragma unroll
+        for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
+            s1 += f.rows[((size_t)t * 2) * C + ch];
+            sz += f.rows[((size_t)t * 2 + 1) * C + ch];
+        }
+        const double mu = (double)f.mean[ch], rs = (double)f.rstd[ch];
+        const double sx = (sz - mu * s1) * rs;                     // sum g * xhat
+        const double a = (double)f.gamma[ch] * rs;
+        const double b = -a * rs * (sx / (double)f.count);
+        sA[ch] = (float)a; sB[ch] = (float)b;
+        sD[ch] = (float)(-a * (s1 / (double)f.count) - b * mu);
+        if (blockIdx.x == 0) { f.dbeta[ch] = (float)s1; f.dgamma[ch] = (float)sx; }
+    }
+    __syncthreads();
+    const int cv = C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(it / cv);
+        const int c = (int)(it - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        float g[8], z[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c), g);
+        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c), z);
+        const unsigned bits = p.mask_bits[it];                     // it = m * (C / 8) + c / 8
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = ((bits >> j) & 1u) ? g[j] : 0.f;
+            o[j] = sA[c + j] * gj + sB[c + j] * z[j] + sD[c + j];
+        }
+        const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
+        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+    }
+}
+
+hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f0, hipStream_t s) {
+    if (p.C % 8 || p.C > 4096 || !p.mask_bits) return hipErrorInvalidValue;
+    BnBwdApplyArgs f;
+    f.rows = f0.rows; f.count = f0.count; f.gamma = f0.gamma; f.mean = p.mean; f.rstd = p.rstd;
+    f.dgamma = f0.dgamma; f.dbeta = f0.dbeta;
+    const long items = (long)p.M * (p.C / 8);
+    long g = (items + 1023) / 1024;
+    if (g > 512) g = 512;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)3 * p.C * sizeof(float), s, p, f);
+    return hipGetLastError();
+}
+
 // Two BatchNorm backwards that share their output gradient in one launch: the block-output BatchNorm of a down-sampling
 // BasicBlock (A: conv2's, ReLU mask from the stored block output) and the BatchNorm of its 1x1 branch (B: no ReLU of its
 // own, fed with the same masked gradient g).  One read of dy / act, three sums per channel (sum g shared), one grid

@@ -137,6 +137,10 @@ struct ConvParams {
     // accumulate only: the old value of y is first multiplied by this ReLU mask ([M][yC/8] bytes, one bit per element; y dense):
     // y holds d(block output) and the identity path carries d * [out > 0] -- the mask the BatchNorm backward used too
     const unsigned char* acc_mask;
+    // data gradients only: also take the sums of the BatchNorm backward that consumes this launch's output d -- g = d * mask
+    // (mask: ReLU bit map [M][yC/8] of that BatchNorm's activation), sum g and sum g * z (z: the BatchNorm's dense input
+    // [M][yC]) per channel into `stats` (that BatchNorm's own rows).  The BatchNorm backward is then finalize + apply only.
+    const bf16_t* bst_z; const unsigned char* bst_mask;
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
     ConvBnBwd bnb;                              // conv3x3_ws_kernel only

@@ -12,15 +12,59 @@
 //   0 plain store, 1 store + per-channel statistics (train forward), 2 accumulate onto y (data gradient on top of
 //   the identity path), 3 eval epilogue (scale/shift, residual, ReLU); -1 decides at run time (legacy kernels).
 //   4 / 5 fused BatchNorm backward (ConvBnBwd mode 1 / 2): conv_epilogue_bnbwd below, conv3x3_ws_kernel only.
+//   6 / 7 = 0 / 2 + the sums of the consuming BatchNorm's backward (ConvParams::bst_z).
 static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p) {
     if (p.bnb.mode) return 3 + p.bnb.mode;
+    if (p.bst_z) return p.accumulate ? 7 : 6;
     return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
 }
 
-template <int BM, int BN, int WM, int WN, int EPM = -1>
-static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
-                                                     int mtile, int n0, float (&s1)[BN / WN / 16][4],
-                                                     float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base = 0) {
+// EPM 6 / 7: this lane's z fragments and ReLU bits of the consuming BatchNorm (ConvParams::bst_z / bst_mask), fetched ahead
+// of their use -- all loads of a tile in flight together (inside the epilogue the stores to y keep hipcc from hoisting
+// them), and in the persistent kernel before the tile's MFMA loop, which hides their latency altogether.
+template <int NI, int MI>
+struct BstFrag {
+    uint2 z[NI][MI];
+    unsigned long long bits[MI];
+};
+// (at most 4 pixel groups at a time: 8 of them are 64 registers on top of 128 accumulators)
+#define VPD_BST_MB(MI) ((MI) > 4 ? 4 : (MI))
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_bst_prefetch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
+                                                         BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& f,
+                                                         int wave_base = 0, int b0 = 0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = VPD_BST_MB(WTM / 16), NI = WTN / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = (threadIdx.x >> 6) - wave_base;
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HW = geo.Hs * geo.Ws;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mtile * BM + wm * WTM + (b0 + b) * 16 + fr;
+        const int mc = m < geo.M ? m : geo.M - 1;
+        const int bi = mc / HW;
+        const int r = mc - bi * HW;
+        const int yy = r / geo.Ws;
+        const int xx = r - yy * geo.Ws;
+        // y is dense ([pixel][yC], ypad 0): yoff = pixel index * yC, which also indexes z and (in bits) the mask
+        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+        const unsigned char* mp = p.bst_mask + ((yoff + n0 + wn * WTN) >> 3);
+        if (WTN == 64) f.bits[b] = *reinterpret_cast<const unsigned long long*>(mp);
+        else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
+        else f.bits[b] = *reinterpret_cast<const unsigned short*>(mp);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            f.z[a][b] = *reinterpret_cast<const uint2*>(p.bst_z + yoff + n0 + wn * WTN + a * 16 + 4 * fq);
+    }
+}
+
+// PRE: `own` already holds the first VPD_BST_MB pixel groups (the caller ran conv_bst_prefetch ahead of time)
+template <int BM, int BN, int WM, int WN, int EPM, bool PRE>
+static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                          int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                          float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base,
+                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& own) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -35,12 +79,14 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     const int m0 = mtile * BM;
     const int HW = geo.Hs * geo.Ws;
     const bool do_eval = EPM < 0 ? (p.ep_scale != nullptr) : (EPM == 3);
-    const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2);
+    const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2 || EPM == 7);
     const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
+    constexpr bool do_bst = EPM == 6 || EPM == 7;
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
 
     // eval epilogue: this lane's 4 * NI scale / shift values once, not once per pixel group (the stores in between keep hipcc
     // from merging the reloads)
+    constexpr int MB = VPD_BST_MB(MI);
     float4 esc[NI], esh[NI];
     if (do_eval) {
 #pragma unroll
@@ -51,6 +97,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     }
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
+        // (PRE: the caller fetched the first MB groups; the second half of an 8-group tile is fetched here)
+        if (do_bst && b % MB == 0 && (!PRE || b > 0)) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, own, wave_base, b);
         const int m = m0 + wm * WTM + b * 16 + fr;
         const bool valid = m < geo.M;
         const int mc = valid ? m : geo.M - 1;
@@ -71,6 +119,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
             else if (WTN == 32) mbits = *reinterpret_cast<const unsigned*>(mp);
             else mbits = *reinterpret_cast<const unsigned short*>(mp);
         }
+        const BstFrag<NI, MB>& bf = own;
+        const unsigned long long bbits = do_bst ? bf.bits[b % MB] : 0ull;      // ReLU bits of the consuming BatchNorm's activation
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
             const int n = n0 + wn * WTN + a * 16 + 4 * fq;
@@ -108,6 +158,19 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
             if (valid) {
                 *reinterpret_cast<uint2*>(dst) = ov;
             }
+            if (do_bst && valid) {
+                // g = stored d * mask; sum g and sum g * z (the BatchNorm backward's finalize turns the latter into sum g * xhat)
+                const uint2 zr = bf.z[a][b % MB];
+                const unsigned bits = (unsigned)(bbits >> (a * 16 + 4 * fq));
+                const float q0 = (bits & 1u) ? bf2f((unsigned short)(ov.x & 0xffff)) : 0.f;
+                const float q1 = (bits & 2u) ? bf2f((unsigned short)(ov.x >> 16)) : 0.f;
+                const float q2 = (bits & 4u) ? bf2f((unsigned short)(ov.y & 0xffff)) : 0.f;
+                const float q3 = (bits & 8u) ? bf2f((unsigned short)(ov.y >> 16)) : 0.f;
+                s1[a][0] += q0; s2[a][0] += q0 * bf2f((unsigned short)(zr.x & 0xffff));
+                s1[a][1] += q1; s2[a][1] += q1 * bf2f((unsigned short)(zr.x >> 16));
+                s1[a][2] += q2; s2[a][2] += q2 * bf2f((unsigned short)(zr.y & 0xffff));
+                s1[a][3] += q3; s2[a][3] += q3 * bf2f((unsigned short)(zr.y >> 16));
+            }
             if (do_stats && valid) {
                 // statistics are taken over the bf16-rounded values actually stored
                 const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
@@ -120,6 +183,22 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
         }
     }
 
+}
+
+template <int BM, int BN, int WM, int WN, int EPM = -1>
+static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                     int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                     float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base = 0) {
+    BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> own;
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, false>(p, acc, mtile, n0, s1, s2, geo, wave_base, own);
+}
+// ... with the consuming BatchNorm's z fragments / mask bits fetched by the caller (EPM 6 / 7 only)
+template <int BM, int BN, int WM, int WN, int EPM>
+static __device__ __forceinline__ void conv_epilogue_pre(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                         int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                         float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
+                                                         BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst) {
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst);
 }
 
 // Reduce the per-lane partial statistics over the 16 pixel lanes and the WM pixel-waves, then ONE atomic per

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
         __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
         if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
-        if (EPM >= 4) {                                           // conv_epilogue_bnbwd: grid barrier (2) + coefficients (1)
+        if (EPM == 4 || EPM == 5) {          // conv_epilogue_bnbwd: grid barrier (2) + coefficients (1)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
@@ -491,8 +491,13 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
             }
         }
     }
+    // EPM 6 / 7: the epilogue's z fragments and mask bits (first 4 pixel groups) are requested in front of the END barrier
+    // (requesting them a chunk earlier costs the main loop 34 registers it does not have: 28-104 bytes of scratch per lane)
+    constexpr bool BST = EPM == 6 || EPM == 7;
+    BstFrag<NI, VPD_BST_MB(MI)> bst;
+    if (BST) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
     __builtin_amdgcn_s_barrier();                                 // END
-    if constexpr (EPM >= 4) {
+    if constexpr (EPM == 4 || EPM == 5) {
         conv_epilogue_bnbwd<BM, BN, WM, WN, EPM == 5>(p, acc, mtile, n0, geo, smem);
     } else {
         float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
@@ -500,7 +505,8 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-        conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+        if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
+        else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
         if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
     }
 }
@@ -602,6 +608,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         for (int a = 0; a < NI; ++a)
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        BstFrag<NI, VPD_BST_MB(MI)> bst;      // EPM 6 / 7: the epilogue's z fragments and mask bits, in flight behind the MFMA loop
+        if (EPM == 6 || EPM == 7) conv_bst_prefetch<BM, BN, WM, WN>(p, t, 0, geo, bst);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (VPD_ABL(p, 2)) break;
@@ -628,7 +636,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
             }
         }
-        if (!VPD_ABL(p, 8)) conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        if (!VPD_ABL(p, 8)) {
+            if constexpr (EPM == 6 || EPM == 7) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo, bst);
+            else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
+        }
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, 0, red);
@@ -808,6 +819,8 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
         case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
         case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
         case 2: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 6: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 6>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 7: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 7>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
         default: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
     }
     return hipGetLastError();
@@ -1010,6 +1023,8 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
         case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 4: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 4, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 5: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 5, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 6: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 6, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 7: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 7, NS>), grid, dim3(512), lds, stream, q, g); break;
         default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3, NS>), grid, dim3(512), lds, stream, q, g); break;
     }
     return hipGetLastError();
@@ -1067,6 +1082,7 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         case 0: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 0>), grid, dim3(256), lds, stream, q); break;
         case 1: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
         case 2: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, q); break;
+        case 6: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 6>), grid, dim3(256), lds, stream, q); break;
         default: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, stream, q); break;
     }
     return hipGetLastError();
@@ -1123,6 +1139,24 @@ bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu) {
     return blocks <= ncu;
 }
 
+// true when this launch's kernel can take the sums of the consuming BatchNorm's backward in its epilogue (bst_z / bst_mask)
+bool vpd_conv_takes_bn_sums(const ConvParams& p) {
+    if (p.bnb.mode || p.ep_scale || p.alt_w || p.yC != p.Co || p.ypad != 0) return false;
+    HaloGeom g;
+    const int kc = vpd_conv_kernel_class(p, &g);
+    if (kc == 4) {      // gather kernel: the merged parity classes of a stride-2 data gradient (plain store only)
+        static const int s2 = getenv("VPD_DGRAD_SUMS_S2") ? atoi(getenv("VPD_DGRAD_SUMS_S2")) : 1;
+        return s2 && !p.accumulate && p.osub == 2;
+    }
+    if (p.x2 || p.osub != 1) return false;
+    if (kc == 0) {      // layer1's persistent kernel (not its two-group variant)
+        static const int l1 = getenv("VPD_DGRAD_SUMS_L1") ? atoi(getenv("VPD_DGRAD_SUMS_L1")) : 1;
+        HaloGeom g2;
+        return l1 && !c64x2_geom(p, &g2);
+    }
+    return kc == 1 || kc == 2 || kc == 3 || kc == 6;
+}
+
 hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     if (p0.bnb.mode) {
@@ -1130,6 +1164,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         const int kc = vpd_conv_kernel_class(p0, &gg);
         if (kc < 2 || kc > 3) return hipErrorInvalidValue;        // the caller asks vpd_conv_bnbwd_ok first
     }
+    if (p0.bst_z && !vpd_conv_takes_bn_sums(p0)) return hipErrorInvalidValue;      // (the caller asks first)
     ConvParams p = p0;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     p.ablate = ablate;

@@ -64,6 +64,7 @@ struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
+bool vpd_conv_takes_bn_sums(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
 bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu);     // fused dgrad + BatchNorm-backward epilogue (ConvBnBwd) possible
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);
@@ -111,6 +112,9 @@ struct BnFusedBwd {
 hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f, hipStream_t s);
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
+// BatchNorm backward whose sums (sum g, sum g * z) the producing data gradient's epilogue has already added to `f.rows`
+// (ConvParams::bst_z): finalize + apply in one launch, no reduction pass, no grid barrier.  p.mask_bits is required.
+hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
 // two BatchNorm backwards sharing dy and the ReLU mask (a down-sampling block's conv2 BN + its 1x1 branch's BN) in one launch
 bool vpd_bn_bwd_fused2_ok(int M, int C);
 hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p, const BnFusedBwd& fA, const BnFusedBwd& fB, const bf16_t* zB,

@@ -67,6 +67,7 @@ struct BlockInfo {
     int stage = 0;
     size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
     size_t mask_off = 0;                             // train, BasicBlock: [M][C/8] ReLU mask bits of the block output
+    size_t mask1_off = 0;                            // train, BasicBlock with dgrad_sums: ReLU mask bits of a1 (0: none)
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
@@ -127,6 +128,7 @@ struct vpd_plan {
     size_t gslab_off = 0;       // grouped slab region (bytes offset), sized for the largest launch group
     // lazy gradients (vpd_plan_set_lazy_grads): the next vpd_backward leaves the conv weight gradients in the scratch
     // (only the stem's are unpacked), vpd_plan_adamw_step reads them there; vpd_plan_materialize_grads unpacks on demand
+    bool dgrad_sums = true;     // BatchNorm-backward sums in the producing data gradient's epilogue (VPD_DGRAD_SUMS=0: in the BatchNorm launch)
     bool relu_bits = true;      // block-output ReLU masks as bit maps (VPD_RELU_BITS=0: masks from the stored activation, g written back)
     bool lazy_next = false, grads_in_scratch = false;
     int nstem_unpack_blocks = 0;           // leading entries of bmap_unpack[3] that belong to the stem
@@ -505,6 +507,10 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                 const ConvInfo& last = bottleneck ? B.c3 : B.c2;      // the conv whose BatchNorm feeds the block-output ReLU
                 B.mask_off = bp.take((size_t)NB * last.Hout * last.Wout * last.Co / 8 + 16);
             }
+        p->dgrad_sums = p->relu_bits && p->fused_bn && !bottleneck &&
+                        !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS")));
+        if (p->dgrad_sums)
+            for (auto& B : p->blocks) B.mask1_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co / 8 + 16);
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -722,12 +728,22 @@ bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
     return vpd_conv_bnbwd_ok(q, device_cu_count());
 }
 
+// The sums of a BatchNorm backward (sum g, sum g * z with g = d * mask) taken in the epilogue of the data gradient that
+// produces d (ConvParams::bst_z); the BatchNorm launch is then finalize + apply only (run_bn_bwd_apply).
+struct BnSums { const bf16_t* z; const unsigned char* mask; double* rows; };
+bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate) {
+    if (!c.p->dgrad_sums || cv.stride != 1) return false;
+    ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), accumulate);
+    q.bst_z = c.b16(0);
+    return vpd_conv_takes_bn_sums(q);
+}
+
 // bnb: BatchNorm backward fused into this launch's epilogue (the caller has checked dgrad_takes_bn)
 // ds / dzd: the block's 1x1 stride-2 down-sampling conv and its dz -- its data gradient lands on the even-even input pixels,
 // which are class 0 of the 3x3's: extra K-steps of those blocks instead of a read-modify-write launch of its own
 hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
                           const ConvBnBwd* bnb = nullptr, const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr,
-                          const unsigned char* acc_mask = nullptr) {
+                          const unsigned char* acc_mask = nullptr, const BnSums* sums = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = dz; q.xHp = cv.Hout + 2; q.xWp = cv.Wout + 2; q.xC = cv.Co;
@@ -738,6 +754,10 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     if (cv.stride == 1) {
         q = conv_dgrad_s1_params(c, cv, dz, dx, accumulate);
         q.acc_mask = accumulate ? acc_mask : nullptr;
+        if (sums) {      // (the caller has checked dgrad_takes_sums)
+            q.bst_z = sums->z; q.bst_mask = sums->mask;
+            q.stats = sums->rows; q.stat_rows = VPD_FUSED_ROWS;
+        }
         if (bnb) {
             q.bnb = *bnb;
             q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
@@ -778,6 +798,11 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     if (ds) {
         if (q.oph != 0 || q.opw != 0 || q.taps.nr != 1 || q.taps.nc != 1 || ds->Co != cv.Co) return hipErrorInvalidValue;
         q.x2 = dzd; q.w2 = c.b16(c.p->arena_off) + ds->dgr_off; q.Kc2 = ds->Co;
+    }
+    if (sums) {      // the four classes together write every pixel of dx exactly once
+        q.bst_z = sums->z; q.bst_mask = sums->mask;
+        q.stats = sums->rows; q.stat_rows = VPD_FUSED_ROWS;
+        if (accumulate || !vpd_conv_takes_bn_sums(q)) return hipErrorInvalidValue;
     }
     return vpd_launch_conv(q, c.s);
 }
@@ -903,6 +928,24 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     }
     return vpd_launch_bn_bwd(b, (float)b.M, c.params + cv.bn.w_off, grads + cv.bn.w_off, grads + cv.bn.b_off, c.s,
                              reduce_done);
+}
+
+// BatchNorm backward whose sums were taken by the producing data gradient (BnSums): finalize + apply
+hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, bf16_t* dz, int dzpad, float* grads,
+                            const unsigned char* mask_bits) {
+    BnBwdParams b;
+    memset(&b, 0, sizeof b);
+    b.dy = dy; b.z = c.b16(cv.z_off);
+    b.mean = c.bn_mean(cv.bn); b.rstd = c.bn_rstd(cv.bn);
+    b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
+    b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co;
+    b.mask_bits = mask_bits;
+    BnFusedBwd f;
+    memset(&f, 0, sizeof f);
+    f.rows = c.bn_rows(cv.bn);
+    f.gamma = c.params + cv.bn.w_off; f.dgamma = grads + cv.bn.w_off; f.dbeta = grads + cv.bn.b_off;
+    f.count = (float)b.M;
+    return vpd_launch_bn_bwd_apply_fused(b, f, c.s);
 }
 
 // ConvBnBwd of BatchNorm `bncv.bn` for a data-gradient launch whose output gradient is the BatchNorm's dy.
@@ -1088,7 +1131,8 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         } else {
             LCHECK(run_conv_train(c, B.c1, cur, bn_running));
         }
-        LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1));
+        LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1,
+                          B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
@@ -1315,6 +1359,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         return 0;
     };
     std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
+    std::vector<char> bn2_sums_for(p->blocks.size(), 0);       // ... its sums taken by the next block's dgrad (BnSums)
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
         const StageInfo& S = p->stages[B.stage];
@@ -1368,13 +1413,21 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         const unsigned char* mbits = nullptr;
         if (!B.ds && !bn2_fused_for[bi] && relu_bits_ok(c, B.c2) && !(bi > 0 && dgrad_takes_bn(c, B.c1)))
             mbits = reinterpret_cast<const unsigned char*>(ws + B.mask_off);
-        if (!bn2_fused_for[bi] && !bn_pair)
+        if (bn2_sums_for[bi])      // (the next block's conv1 data gradient took the sums: mbits is set, dout is left alone)
+            LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mbits));
+        else if (!bn2_fused_for[bi] && !bn_pair)
             LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits));
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         if (dgrad_takes_bn(c, B.c2)) {
             // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
             const ConvBnBwd f = make_bnb(c, B.c1, 1, nullptr, dz1, grads);
             LCHECK(run_conv_dgrad(c, B.c2, dz2, nullptr, 0, &f));
+        } else if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {
+            // bn1's sums ride in conv2's data gradient; its BatchNorm launch only finalizes and applies
+            const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
+            const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn)};
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, nullptr, nullptr, nullptr, nullptr, &sm));
+            LCHECK(run_bn_bwd_apply(c, B.c1, da1, dz1, 1, grads, m1));
         } else {
             LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
             LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
@@ -1385,8 +1438,20 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             if (!bn_pair) LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
             LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
             if (conv_pair_ok(c, B.c1, B.cd, true)) {
-                // one launch: the 1x1 branch's data gradient is extra K-steps of the even-even class
-                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0, nullptr, &B.cd, dzd));
+                // one launch: the 1x1 branch's data gradient is extra K-steps of the even-even class.  Its result is d(out) of
+                // the previous stage's last block: the sums of that block's bn2 are taken here
+                const BnSums* smp = nullptr;
+                BnSums sm;
+                static const bool s2sums = !(getenv("VPD_DGRAD_SUMS_S2") && !atoi(getenv("VPD_DGRAD_SUMS_S2")));
+                if (bi > 0 && p->dgrad_sums && s2sums && (B.c1.Hin % 2) == 0 && (B.c1.Win % 2) == 0) {
+                    const BlockInfo& Bp = p->blocks[bi - 1];
+                    if (!Bp.ds && relu_bits_ok(c, Bp.c2) && !(bi - 1 > 0 && dgrad_takes_bn(c, Bp.c1))) {
+                        sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn)};
+                        smp = &sm;
+                        bn2_sums_for[bi - 1] = true;
+                    }
+                }
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0, nullptr, &B.cd, dzd, nullptr, smp));
             } else {
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
@@ -1401,8 +1466,20 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, &f));
             bn2_fused_for[bi - 1] = true;
         } else {
-            // dout holds g (or, with the bit map, d(out) and the mask is applied here): identity path + conv path
-            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mbits));
+            // dout holds g (or, with the bit map, d(out) and the mask is applied here): identity path + conv path.
+            // The result is d(out) of the previous block: when that block is a plain one too, the sums of its bn2 are taken here
+            const BnSums* smp = nullptr;
+            BnSums sm;
+            if (bi > 0 && mbits) {
+                const BlockInfo& Bp = p->blocks[bi - 1];
+                if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c2) && !dgrad_takes_bn(c, Bp.c1) &&
+                    dgrad_takes_sums(c, B.c1, 1)) {
+                    sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn)};
+                    smp = &sm;
+                    bn2_sums_for[bi - 1] = true;
+                }
+            }
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mbits, smp));
         }
         if (stage_end(bi)) return -1;
     }
