@@ -360,6 +360,28 @@ def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
     assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
 
 
+def test_fused_head_matches_the_separate_launches(tmp_path):
+    """VPD_FUSED_HEAD=1 (off by default: measured slower): pool + fc + loss in one launch, d(pooled) + dW + db in one launch
+    (head.hip, head_*_fused_kernel) instead of avgpool / sgemm / mse / colsum / avgpool_bwd.  fp32
+    arithmetic on both sides, different summation order: the loss agrees to 1e-6, the gradients as in the tests above."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("g%s.npy" % flag))
+        env = dict(os.environ, VPD_FUSED_HEAD=flag)
+        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
+    (g0, l0), (g1, l1) = outs
+    assert abs(l1 / l0 - 1) < 1e-6, (l0, l1)
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
+    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
+
+
 def _group_of(name):
     return "fc" if ".fc." in name else (name.split(".")[1] if name.split(".")[1].startswith("layer") else "stem")
 

@@ -27,6 +27,37 @@ struct BstFrag {
     uint2 z[NI][MI];
     unsigned long long bits[MI];
 };
+// Accumulate modes (EPM 2 / 7) of the persistent kernel: the old values of y and their ReLU bits (ConvParams::acc_mask),
+// requested before the tile's MFMA loop like the fragments above (y dense, ypad 0).
+template <int NI, int MI>
+struct AccFrag {
+    uint2 old[NI][MI];
+    unsigned long long bits[MI];
+};
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_acc_prefetch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
+                                                         AccFrag<BN / WN / 16, BM / WM / 16>& f) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mtile * BM + wm * WTM + b * 16 + fr;
+        const int mc = m < geo.M ? m : geo.M - 1;
+        f.bits[b] = ~0ull;
+        if (p.acc_mask) {
+            const unsigned char* mp = p.acc_mask + (size_t)mc * (p.yC >> 3) + ((n0 + wn * WTN) >> 3);
+            if (WTN == 64) f.bits[b] = *reinterpret_cast<const unsigned long long*>(mp);
+            else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
+            else f.bits[b] = *reinterpret_cast<const unsigned short*>(mp);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            f.old[a][b] = *reinterpret_cast<const uint2*>(p.y + (size_t)mc * p.yC + n0 + wn * WTN + a * 16 + 4 * fq);
+    }
+}
 // (at most 4 pixel groups at a time: 8 of them are 64 registers on top of 128 accumulators)
 #define VPD_BST_MB(MI) ((MI) > 4 ? 4 : (MI))
 template <int BM, int BN, int WM, int WN>
@@ -60,11 +91,13 @@ static __device__ __forceinline__ void conv_bst_prefetch(const ConvParams& p, in
 }
 
 // PRE: `own` already holds the first VPD_BST_MB pixel groups (the caller ran conv_bst_prefetch ahead of time)
-template <int BM, int BN, int WM, int WN, int EPM, bool PRE>
+// APRE: `accf` holds the old values of y and their mask bits (conv_acc_prefetch; accumulate modes, dense y)
+template <int BM, int BN, int WM, int WN, int EPM, bool PRE, bool APRE = false>
 static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
                                                           int mtile, int n0, float (&s1)[BN / WN / 16][4],
                                                           float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base,
-                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& own) {
+                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& own,
+                                                          const AccFrag<BN / WN / 16, BM / WM / 16>* accf = nullptr) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -113,7 +146,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
         // accumulate with a ReLU bit map: ONE load per pixel covers this wave's WTN channels (WTN / 8 bytes, 8-byte aligned
         // for WTN = 64; a byte load per 4-channel group doubled the epilogue's memory instructions: measured +79 us per step)
         unsigned long long mbits = 0;
-        if (do_acc && p.acc_mask && valid) {
+        if (APRE) mbits = accf->bits[b];
+        if (!APRE && do_acc && p.acc_mask && valid) {
             const unsigned char* mp = p.acc_mask + (size_t)mc * (p.yC >> 3) + ((n0 + wn * WTN) >> 3);
             if (WTN == 64) mbits = *reinterpret_cast<const unsigned long long*>(mp);
             else if (WTN == 32) mbits = *reinterpret_cast<const unsigned*>(mp);
@@ -142,10 +176,10 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
             }
             bf16_t* dst = p.y + yoff + n;
             if (do_acc && valid) {
-                const uint2 ov = *reinterpret_cast<const uint2*>(dst);
+                const uint2 ov = APRE ? accf->old[a][b] : *reinterpret_cast<const uint2*>(dst);
                 float o0 = bf2f((unsigned short)(ov.x & 0xffff)), o1 = bf2f((unsigned short)(ov.x >> 16));
                 float o2 = bf2f((unsigned short)(ov.y & 0xffff)), o3 = bf2f((unsigned short)(ov.y >> 16));
-                if (p.acc_mask) {      // y dense [M][yC]: channel n0 + wn*WTN + k of pixel m = bit k of mbits
+                if (APRE || p.acc_mask) {      // y dense [M][yC]: channel n0 + wn*WTN + k of pixel m = bit k of mbits (APRE: all ones without a mask)
                     const unsigned bits = (unsigned)(mbits >> (a * 16 + 4 * fq));
                     o0 = (bits & 1u) ? o0 : 0.f; o1 = (bits & 2u) ? o1 : 0.f;
                     o2 = (bits & 4u) ? o2 : 0.f; o3 = (bits & 8u) ? o3 : 0.f;
@@ -199,6 +233,16 @@ static __device__ __forceinline__ void conv_epilogue_pre(const ConvParams& p, f3
                                                          float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst) {
     conv_epilogue_impl<BM, BN, WM, WN, EPM, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst);
+}
+
+// ... accumulate modes of the persistent kernel: old values (and, EPM 7, the BatchNorm fragments) fetched by the caller
+template <int BM, int BN, int WM, int WN, int EPM>
+static __device__ __forceinline__ void conv_epilogue_acc_pre(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                             int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                             float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
+                                                             BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst,
+                                                             const AccFrag<BN / WN / 16, BM / WM / 16>& accf) {
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, EPM == 7, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, &accf);
 }
 
 // Reduce the per-lane partial statistics over the 16 pixel lanes and the WM pixel-waves, then ONE atomic per

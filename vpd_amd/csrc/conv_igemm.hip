@@ -609,7 +609,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         BstFrag<NI, VPD_BST_MB(MI)> bst;      // EPM 6 / 7: the epilogue's z fragments and mask bits, in flight behind the MFMA loop
+        AccFrag<NI, MI> accf;                 // EPM 2 / 7: the old values of y and their mask bits, likewise
         if (EPM == 6 || EPM == 7) conv_bst_prefetch<BM, BN, WM, WN>(p, t, 0, geo, bst);
+        if (EPM == 2 || EPM == 7) conv_acc_prefetch<BM, BN, WM, WN>(p, t, 0, geo, accf);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             if (VPD_ABL(p, 2)) break;
@@ -637,7 +639,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
             }
         }
         if (!VPD_ABL(p, 8)) {
-            if constexpr (EPM == 6 || EPM == 7) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo, bst);
+            if constexpr (EPM == 2 || EPM == 7) conv_epilogue_acc_pre<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo, bst, accf);
+            else if constexpr (EPM == 6) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo, bst);
             else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
         }
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
@@ -815,6 +818,8 @@ static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t
     const int grid = ntiles < 256 ? ntiles : 256;
     const size_t lds = ((size_t)9 * 64 + 2 * HROWS) * 64 * sizeof(bf16_t) + 2048;
     ConvParams q = p;
+    // (the accumulate modes fetch the old values of y by dense pixel index ahead of the MFMA loop: conv_acc_prefetch)
+    if (q.accumulate && (q.ypad != 0 || q.osub != 1 || q.yC != q.Co)) return hipErrorInvalidValue;
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
         case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;

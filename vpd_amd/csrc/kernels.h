@@ -129,6 +129,12 @@ hipError_t vpd_launch_avgpool_bwd(const float* dpooled, int H, int W, int C, int
 hipError_t vpd_launch_sgemm(const float* A, const float* B, float* Y, const float* bias, int M, int N, int K, int ta,
                             int tb, int relu, hipStream_t s);
 hipError_t vpd_launch_colsum(const float* A, int M, int N, float* out, hipStream_t s);
+// fused head of the train step without the motion MLP (head.hip): pool + fc + loss forward, d(pooled) + dW + db backward
+hipError_t vpd_launch_head_fwd_fused(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, const float* Wt,
+                                     const float* bias, int D, const float* target, float* pooled, float* emb, float* demb,
+                                     float* partial, unsigned* counter, float* loss_step, double* loss_accum, hipStream_t s);
+hipError_t vpd_launch_head_bwd_fused(const float* demb, const float* Wt, const float* pooled, float* dW, float* db,
+                                     bf16_t* dact, int N, int D, int C, int HW, hipStream_t s);
 hipError_t vpd_launch_relu_mask(float* d, const float* act, long n, hipStream_t s);
 hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, float* loss_step, double* loss_accum,
                           hipStream_t s);

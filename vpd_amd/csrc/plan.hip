@@ -106,6 +106,8 @@ struct vpd_plan {
     size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, T_off[2] = {0, 0}, slab_off = 0;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
+    size_t headpart_off = 0;             // fused head: per-crop losses [max_batch] floats + arrival counter (zero between launches)
+    bool fused_head = false;             // pool + fc + loss / d(pooled) + dW + db as one launch each (no motion MLP; VPD_FUSED_HEAD=1)
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
     int xHp = 0, xWp = 0;
     int H0 = 0, W0 = 0, H1 = 0, W1 = 0;   // stem conv output, pooled output
@@ -501,6 +503,10 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             p->gslab_off = bp.take(mx * 4);
             for (int s2 = 0; s2 < 8; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
+        // OFF by default: measured 49 us per step SLOWER than the seven separate launches (3.716 -> 3.765 ms same-box) -- one
+        // block per crop / per four fc rows walks its 128-256-long dot products behind dependent global loads, where the
+        // MFMA sgemm kernels it replaces are launch-bound at 5-9 us each.  Kept for the A/B and its parity test.
+        p->fused_head = getenv("VPD_FUSED_HEAD") && atoi(getenv("VPD_FUSED_HEAD"));
         p->relu_bits = !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
         if (p->relu_bits)
             for (auto& B : p->blocks) {
@@ -516,6 +522,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
+        p->headpart_off = bp.take((size_t)NB * 4 + 256);
         p->dh2_off = bp.take((size_t)NB * 128 * 4);
         p->dh1_off = bp.take((size_t)NB * 128 * 4);
         p->demb_off = bp.take((size_t)NB * emb_dim * 4);
@@ -986,6 +993,15 @@ int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* 
              float* loss_step, double* loss_accum) {
     vpd_plan* p = c.p;
     const StageInfo& S = p->stages[3];
+    if (target && !p->motion && p->fused_head && p->headpart_off && p->feat % 256 == 0) {
+        float* emb = emb_out ? emb_out : c.f32(p->emb_off);
+        float* part = c.f32(p->headpart_off);
+        LCHECK(vpd_launch_head_fwd_fused(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.params + p->fc.w_off,
+                                         c.params + p->fc.b_off, p->D, target, c.f32(p->pooled_off), emb,
+                                         need_grad ? c.f32(p->dpred_off) : nullptr, part,
+                                         reinterpret_cast<unsigned*>(part + p->max_batch), loss_step, loss_accum, c.s));
+        return 0;
+    }
     LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.f32(p->pooled_off), c.s));
     // without the motion head nothing re-reads the embedding (the fc backward uses the pooled features and d(emb)): the fc
     // GEMM writes the caller's buffer directly; with it, the head's first layer and its weight gradient read the workspace copy
@@ -1212,13 +1228,16 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(vpd_launch_sgemm(c.f32(p->dh1_off), params + L[0].w_off, c.f32(p->demb_off), nullptr, n, L[0].in, L[0].out, 0, 0, 0, s));
         demb = c.f32(p->demb_off);
     }
-    LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, p->feat, n, 1, 0, 0, s));
-    LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
-    LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, p->feat, p->D, 0, 0, 0, s));
-
     int gi = 0;      // index of the G buffer holding d(out) of the current block
     bf16_t* G[3] = {c.b16(p->G_off[0]), c.b16(p->G_off[1]), c.b16(p->G_off[2])};
-    {
+    if (!p->motion && p->fused_head && p->feat % 2 == 0) {
+        const StageInfo& S = p->stages[3];
+        LCHECK(vpd_launch_head_bwd_fused(demb, params + p->fc.w_off, c.f32(p->pooled_off), grads + p->fc.w_off,
+                                         grads + p->fc.b_off, G[gi], n, p->D, p->feat, S.H * S.W, s));
+    } else {
+        LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, p->feat, n, 1, 0, 0, s));
+        LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
+        LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, p->feat, p->D, 0, 0, 0, s));
         const StageInfo& S = p->stages[3];
         LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
     }

@@ -132,7 +132,10 @@ class StudentEngine:
         self.params = torch.zeros(self.param_numel, **z)
         self._grads = torch.zeros(self.param_numel, **z)      # see the `grads` property
         self.bn_running = torch.zeros(max(self.bn_numel, 1), **z)
-        self.num_batches_tracked = torch.zeros(len(self.bn_names), dtype=torch.int64, device=self.device)
+        # nn.BatchNorm2d.num_batches_tracked of every BatchNorm: counted on the host and added to the device tensor when it is
+        # read (the property below, state_dict()) -- a one-element-per-BatchNorm add per step is a 5 us launch of its own
+        self._nbt = torch.zeros(len(self.bn_names), dtype=torch.int64, device=self.device)
+        self._nbt_pending = 0
         self.adam_m = None
         self.adam_v = None
         self.adam_step = 0
@@ -145,6 +148,14 @@ class StudentEngine:
         self.bucket_events = None
 
     # -- helpers -------------------------------------------------------------
+    @property
+    def num_batches_tracked(self):
+        """int64[len(bn_names)] on the device, up to date (train-mode forwards since the last read are added first)"""
+        if self._nbt_pending:
+            self._nbt += self._nbt_pending
+            self._nbt_pending = 0
+        return self._nbt
+
     @property
     def grads(self):
         """The flat fp32 gradient buffer (reference layouts; every p.grad is a view of it).  After a LAZY backward -- the one
@@ -255,7 +266,7 @@ class StudentEngine:
         self._hip_version += 1
         pl.packed_version = (self.params._version, self.bn_running._version, self._hip_version)
         if n > 0:
-            self.num_batches_tracked += 1
+            self._nbt_pending += 1
         self._last = (pl, n) if target is not None else None
         return emb
 

@@ -84,7 +84,17 @@ class RGBF_EmbeddingModel(nn.Module):
                 rm, rv = eng.bn_views(bn)
                 rm.zero_()
                 rv.fill_(1.0)
-            eng.num_batches_tracked.zero_()
+            eng.num_batches_tracked.zero_()      # (the property: pending host-side counts are folded in first, then cleared)
+
+    def state_dict(self, *args, **kwargs):
+        # the BatchNorm modules' num_batches_tracked buffers are views of the engine's counter tensor, which is brought up
+        # to date when read through the engine (StudentEngine.num_batches_tracked)
+        _ = self.engine.num_batches_tracked
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        _ = self.engine.num_batches_tracked      # fold pending counts in before the buffers are overwritten
+        return super().load_state_dict(*args, **kwargs)
 
     def _check_storage(self):
         p = self.get_parameter("resnet.conv1.weight")
