@@ -612,30 +612,50 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         AccFrag<NI, MI> accf;                 // EPM 2 / 7: the old values of y and their mask bits, likewise
         if (EPM == 6 || EPM == 7) conv_bst_prefetch<BM, BN, WM, WN>(p, t, 0, geo, bst);
         if (EPM == 2 || EPM == 7) conv_acc_prefetch<BM, BN, WM, WN>(p, t, 0, geo, accf);
+        // ONE MFMA wave per SIMD and no barrier inside a tile: nothing hides an LDS round trip except this wave's own MFMAs.
+        // Two fragment sets; step s+1's six ds_read_b128 are issued between the eight MFMAs of step s (hipcc left to itself
+        // re-uses one set and waits for each pair of reads right before the MFMA that needs it: ~150 exposed cycles per
+        // 128 cycles of matrix work).
+        bf16x8 af[2][NI], bfm[2][MI];
+        // fragment i of step st: 0 -> af[0], 1 -> bfm[0], 2 -> bfm[1], 3.. -> af[1..] (the order the MFMAs below first need them)
+        auto ldone = [&](int st, int buf, int i) __attribute__((always_inline)) {
+            const int tap = st >> 1, kk = st & 1;
+            const int chunk = kk * 4 + fq;
+            if (i == 1 || i == 2) {
+                const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
+                const int r = hbase[i - 1] + toff;
+                bfm[buf][i - 1] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+            } else {
+                const int a = i == 0 ? 0 : i - 2;
+                const int r = a * 16 + fr;
+                af[buf][a] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * 64 + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+        };
+        static_assert(NI == 4 && MI == 2, "fragment schedule below");
+        if (!VPD_ABL(p, 2)) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (VPD_ABL(p, 2)) break;
-            const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
-            const bf16_t* cW = sW + tap * BN * 64;
+            for (int i = 0; i < NI + MI; ++i) ldone(0, 0, i);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[NI], bfm[MI];
-                const int chunk = kk * 4 + fq;
-#pragma unroll
-                for (int a = 0; a < NI; ++a) {
-                    const int r = a * 16 + fr;
-                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
-#pragma unroll
-                for (int b = 0; b < MI; ++b) {
-                    const int r = hbase[b] + toff;
-                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
-#pragma unroll
-                for (int a = 0; a < NI; ++a)
-#pragma unroll
-                    for (int b = 0; b < MI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            for (int st = 0; st < 18; ++st) {
+                const int cur = st & 1, nxt = cur ^ 1;
+                const bool more = st + 1 < 18;
+#define C64_MFMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][a], bfm[cur][b], acc[a][b], 0, 0, 0)
+                // source order pinned by scheduling barriers: the next step's reads leave in pairs behind the first three MFMAs
+                C64_MFMA(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { ldone(st + 1, nxt, 0); ldone(st + 1, nxt, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                C64_MFMA(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { ldone(st + 1, nxt, 2); ldone(st + 1, nxt, 3); }
+                __builtin_amdgcn_sched_barrier(0);
+                C64_MFMA(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { ldone(st + 1, nxt, 4); ldone(st + 1, nxt, 5); }
+                __builtin_amdgcn_sched_barrier(0);
+                C64_MFMA(1, 1); C64_MFMA(2, 0); C64_MFMA(2, 1); C64_MFMA(3, 0); C64_MFMA(3, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#undef C64_MFMA
             }
         }
         if (!VPD_ABL(p, 8)) {
