@@ -987,25 +987,38 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
 struct BnBwdApplyArgs {
     const double* rows; float count;
     const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta;
+    // PAIR: a second BatchNorm fed with the same g (the 1x1 branch of a down-sampling block)
+    const double* rows2; const float* gamma2; const float* mean2; const float* rstd2; float* dgamma2; float* dbeta2;
+    const bf16_t* z2; bf16_t* dz2;
 };
+static __device__ __forceinline__ void bn_bwd_apply_coef(const double* rows, int C, int ch, float count, float gamma, float mean,
+                                                         float rstd, float* A, float* B, float* D, float* dgamma, float* dbeta,
+                                                         bool write) {
+    double s1 = 0.0, sz = 0.0;
+#pragma unroll
+    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
+        s1 += rows[((size_t)t * 2) * C + ch];
+        sz += rows[((size_t)t * 2 + 1) * C + ch];
+    }
+    const double mu = (double)mean, rs = (double)rstd;
+    const double sx = (sz - mu * s1) * rs;                         // sum g * xhat
+    const double a = (double)gamma * rs;
+    const double b = -a * rs * (sx / (double)count);
+    A[ch] = (float)a; B[ch] = (float)b;
+    D[ch] = (float)(-a * (s1 / (double)count) - b * mu);
+    if (write) { dbeta[ch] = (float)s1; dgamma[ch] = (float)sx; }
+}
+template <bool PAIR>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdParams p, const BnBwdApplyArgs f) {
-    extern __shared__ float sm[];                      // A[C] B[C] D[C]
+    extern __shared__ float sm[];                      // A[C] B[C] D[C] (A2[C] B2[C] D2[C])
     const int C = p.C;
     float* sA = sm; float* sB = sm + C; float* sD = sm + 2 * C;
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-        double s1 = 0.0, sz = 0.0;
-#pragma unroll
-        for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
-            s1 += f.rows[((size_t)t * 2) * C + ch];
-            sz += f.rows[((size_t)t * 2 + 1) * C + ch];
-        }
-        const double mu = (double)f.mean[ch], rs = (double)f.rstd[ch];
-        const double sx = (sz - mu * s1) * rs;                     // sum g * xhat
-        const double a = (double)f.gamma[ch] * rs;
-        const double b = -a * rs * (sx / (double)f.count);
-        sA[ch] = (float)a; sB[ch] = (float)b;
-        sD[ch] = (float)(-a * (s1 / (double)f.count) - b * mu);
-        if (blockIdx.x == 0) { f.dbeta[ch] = (float)s1; f.dgamma[ch] = (float)sx; }
+        bn_bwd_apply_coef(f.rows, C, ch, f.count, f.gamma[ch], f.mean[ch], f.rstd[ch], sA, sB, sD, f.dgamma, f.dbeta,
+                          blockIdx.x == 0);
+        if (PAIR)
+            bn_bwd_apply_coef(f.rows2, C, ch, f.count, f.gamma2[ch], f.mean2[ch], f.rstd2[ch], sA + 3 * C, sB + 3 * C,
+                              sD + 3 * C, f.dgamma2, f.dbeta2, blockIdx.x == 0);
     }
     __syncthreads();
     const int cv = C >> 3;
@@ -1024,24 +1037,38 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
         const unsigned bits = p.mask_bits[it];                     // it = m * (C / 8) + c / 8
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gj = ((bits >> j) & 1u) ? g[j] : 0.f;
-            o[j] = sA[c + j] * gj + sB[c + j] * z[j] + sD[c + j];
+            g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
+            o[j] = sA[c + j] * g[j] + sB[c + j] * z[j] + sD[c + j];
         }
         const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
         *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+        if (PAIR) {      // same g, the branch's own z and coefficients, same padded geometry
+            unpack8(*reinterpret_cast<const uint4*>(f.z2 + (size_t)m * C + c), z);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = sA[3 * C + c + j] * g[j] + sB[3 * C + c + j] * z[j] + sD[3 * C + c + j];
+            *reinterpret_cast<uint4*>(f.dz2 + oo) = pack8(o);
+        }
     }
 }
 
-hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f0, hipStream_t s) {
+hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f0, hipStream_t s, const BnFusedBwd* fB,
+                                         const bf16_t* zB, const float* meanB, const float* rstdB, bf16_t* dzB) {
     if (p.C % 8 || p.C > 4096 || !p.mask_bits) return hipErrorInvalidValue;
     BnBwdApplyArgs f;
+    f = BnBwdApplyArgs{};
     f.rows = f0.rows; f.count = f0.count; f.gamma = f0.gamma; f.mean = p.mean; f.rstd = p.rstd;
     f.dgamma = f0.dgamma; f.dbeta = f0.dbeta;
     const long items = (long)p.M * (p.C / 8);
     long g = (items + 1023) / 1024;
     if (g > 512) g = 512;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(bn_bwd_apply_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)3 * p.C * sizeof(float), s, p, f);
+    if (fB) {
+        f.rows2 = fB->rows; f.gamma2 = fB->gamma; f.mean2 = meanB; f.rstd2 = rstdB; f.dgamma2 = fB->dgamma; f.dbeta2 = fB->dbeta;
+        f.z2 = zB; f.dz2 = dzB;
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<true>, dim3((unsigned)g), dim3(1024), (size_t)6 * p.C * sizeof(float), s, p, f);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_fused_kernel<false>, dim3((unsigned)g), dim3(1024), (size_t)3 * p.C * sizeof(float), s, p, f);
+    }
     return hipGetLastError();
 }
 

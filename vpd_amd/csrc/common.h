@@ -141,6 +141,9 @@ struct ConvParams {
     // (mask: ReLU bit map [M][yC/8] of that BatchNorm's activation), sum g and sum g * z (z: the BatchNorm's dense input
     // [M][yC]) per channel into `stats` (that BatchNorm's own rows).  The BatchNorm backward is then finalize + apply only.
     const bf16_t* bst_z; const unsigned char* bst_mask;
+    // ... and of a SECOND BatchNorm fed with the same g (the 1x1 branch of a down-sampling block: same gradient, same ReLU
+    // mask): sum g * z2 (and sum g again) into `stats2`.  conv3x3_ws_kernel, accumulate mode only (epilogue mode 8).
+    const bf16_t* bst_z2; double* stats2;
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
     ConvBnBwd bnb;                              // conv3x3_ws_kernel only

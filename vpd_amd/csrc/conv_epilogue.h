@@ -12,10 +12,10 @@
 //   0 plain store, 1 store + per-channel statistics (train forward), 2 accumulate onto y (data gradient on top of
 //   the identity path), 3 eval epilogue (scale/shift, residual, ReLU); -1 decides at run time (legacy kernels).
 //   4 / 5 fused BatchNorm backward (ConvBnBwd mode 1 / 2): conv_epilogue_bnbwd below, conv3x3_ws_kernel only.
-//   6 / 7 = 0 / 2 + the sums of the consuming BatchNorm's backward (ConvParams::bst_z).
+//   6 / 7 = 0 / 2 + the sums of the consuming BatchNorm's backward (ConvParams::bst_z); 8 = 7 + a second BatchNorm (bst_z2).
 static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p) {
     if (p.bnb.mode) return 3 + p.bnb.mode;
-    if (p.bst_z) return p.accumulate ? 7 : 6;
+    if (p.bst_z) return p.accumulate ? (p.bst_z2 ? 8 : 7) : 6;
     return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
 }
 
@@ -90,6 +90,36 @@ static __device__ __forceinline__ void conv_bst_prefetch(const ConvParams& p, in
     }
 }
 
+// Mode 8: the second BatchNorm's z fragments and its per-lane sum g * z2
+template <int NI, int MI>
+struct BstPair {
+    uint2 z2[NI][MI];
+    float s3[NI][4];
+};
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_bst2_prefetch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
+                                                          BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& f, int b0 = 0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = VPD_BST_MB(WTM / 16), NI = WTN / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int HW = geo.Hs * geo.Ws;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mtile * BM + wm * WTM + (b0 + b) * 16 + fr;
+        const int mc = m < geo.M ? m : geo.M - 1;
+        const int bi = mc / HW;
+        const int r = mc - bi * HW;
+        const int yy = r / geo.Ws;
+        const int xx = r - yy * geo.Ws;
+        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            f.z2[a][b] = *reinterpret_cast<const uint2*>(p.bst_z2 + yoff + n0 + wn * WTN + a * 16 + 4 * fq);
+    }
+}
+
 // PRE: `own` already holds the first VPD_BST_MB pixel groups (the caller ran conv_bst_prefetch ahead of time)
 // APRE: `accf` holds the old values of y and their mask bits (conv_acc_prefetch; accumulate modes, dense y)
 template <int BM, int BN, int WM, int WN, int EPM, bool PRE, bool APRE = false>
@@ -97,7 +127,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                                                           int mtile, int n0, float (&s1)[BN / WN / 16][4],
                                                           float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base,
                                                           BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& own,
-                                                          const AccFrag<BN / WN / 16, BM / WM / 16>* accf = nullptr) {
+                                                          const AccFrag<BN / WN / 16, BM / WM / 16>* accf,
+                                                          BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& pr) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -112,9 +143,10 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
     const int m0 = mtile * BM;
     const int HW = geo.Hs * geo.Ws;
     const bool do_eval = EPM < 0 ? (p.ep_scale != nullptr) : (EPM == 3);
-    const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2 || EPM == 7);
+    const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2 || EPM == 7 || EPM == 8);
     const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
-    constexpr bool do_bst = EPM == 6 || EPM == 7;
+    constexpr bool do_bst = EPM == 6 || EPM == 7 || EPM == 8;
+    constexpr bool do_pair = EPM == 8;
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
 
     // eval epilogue: this lane's 4 * NI scale / shift values once, not once per pixel group (the stores in between keep hipcc
@@ -132,6 +164,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
     for (int b = 0; b < MI; ++b) {
         // (PRE: the caller fetched the first MB groups; the second half of an 8-group tile is fetched here)
         if (do_bst && b % MB == 0 && (!PRE || b > 0)) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, own, wave_base, b);
+        if (do_pair && b % MB == 0 && (!PRE || b > 0)) conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr, b);
         const int m = m0 + wm * WTM + b * 16 + fr;
         const bool valid = m < geo.M;
         const int mc = valid ? m : geo.M - 1;
@@ -204,6 +237,13 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 s1[a][1] += q1; s2[a][1] += q1 * bf2f((unsigned short)(zr.x >> 16));
                 s1[a][2] += q2; s2[a][2] += q2 * bf2f((unsigned short)(zr.y & 0xffff));
                 s1[a][3] += q3; s2[a][3] += q3 * bf2f((unsigned short)(zr.y >> 16));
+                if (do_pair) {
+                    const uint2 z2 = pr.z2[a][b % MB];
+                    pr.s3[a][0] += q0 * bf2f((unsigned short)(z2.x & 0xffff));
+                    pr.s3[a][1] += q1 * bf2f((unsigned short)(z2.x >> 16));
+                    pr.s3[a][2] += q2 * bf2f((unsigned short)(z2.y & 0xffff));
+                    pr.s3[a][3] += q3 * bf2f((unsigned short)(z2.y >> 16));
+                }
             }
             if (do_stats && valid) {
                 // statistics are taken over the bf16-rounded values actually stored
@@ -224,7 +264,8 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
                                                      int mtile, int n0, float (&s1)[BN / WN / 16][4],
                                                      float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base = 0) {
     BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> own;
-    conv_epilogue_impl<BM, BN, WM, WN, EPM, false>(p, acc, mtile, n0, s1, s2, geo, wave_base, own);
+    BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, false>(p, acc, mtile, n0, s1, s2, geo, wave_base, own, nullptr, pr);
 }
 // ... with the consuming BatchNorm's z fragments / mask bits fetched by the caller (EPM 6 / 7 only)
 template <int BM, int BN, int WM, int WN, int EPM>
@@ -232,7 +273,17 @@ static __device__ __forceinline__ void conv_epilogue_pre(const ConvParams& p, f3
                                                          int mtile, int n0, float (&s1)[BN / WN / 16][4],
                                                          float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst) {
-    conv_epilogue_impl<BM, BN, WM, WN, EPM, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst);
+    BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, nullptr, pr);
+}
+// ... mode 8: both BatchNorms' fragments fetched by the caller; pr.s3 collects the second BatchNorm's sum g * z2
+template <int BM, int BN, int WM, int WN, int EPM>
+static __device__ __forceinline__ void conv_epilogue_pre2(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                          int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                          float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
+                                                          BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst,
+                                                          BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& pr) {
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, nullptr, pr);
 }
 
 // ... accumulate modes of the persistent kernel: old values (and, EPM 7, the BatchNorm fragments) fetched by the caller
@@ -242,7 +293,8 @@ static __device__ __forceinline__ void conv_epilogue_acc_pre(const ConvParams& p
                                                              float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
                                                              BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst,
                                                              const AccFrag<BN / WN / 16, BM / WM / 16>& accf) {
-    conv_epilogue_impl<BM, BN, WM, WN, EPM, EPM == 7, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, &accf);
+    BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, EPM == 7, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, &accf, pr);
 }
 
 // Reduce the per-lane partial statistics over the 16 pixel lanes and the WM pixel-waves, then ONE atomic per
@@ -250,7 +302,8 @@ static __device__ __forceinline__ void conv_epilogue_acc_pre(const ConvParams& p
 template <int BM, int BN, int WM, int WN>
 static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, float (&s1)[BN / WN / 16][4],
                                                         float (&s2)[BN / WN / 16][4], int row, int n0,
-                                                        unsigned char* smem) {
+                                                        unsigned char* smem, double* rows_override = nullptr) {
+    double* const rows = rows_override ? rows_override : p.stats;
     constexpr int WTN = BN / WN;
     constexpr int NI = WTN / 16;
     const int tid = threadIdx.x;
@@ -260,7 +313,7 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
     const int wn = wave / WM;
     const int fr = lane & 15;
     const int fq = lane >> 4;
-    if (p.stats) {
+    if (rows) {
         // reduce over the 16 pixel lanes, then over the WM pixel-waves through LDS
         float* red = reinterpret_cast<float*>(smem);      // [WM][2][BN] (staging LDS is free now)
 #pragma unroll
@@ -285,7 +338,7 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
             // are fp64: the order in which blocks arrive then perturbs a sum at the 1e-16 level, far below the fp32
             // rounding of mean / rstd, so the statistics (and with them the whole step) repeat run to run
             const int rmask = (p.stat_rows ? p.stat_rows : VPD_STAT_ROWS) - 1;
-            atomicAdd(&p.stats[((size_t)(row & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
+            atomicAdd(&rows[((size_t)(row & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
         }
     }
 }

@@ -432,6 +432,10 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may land after the LDS is re-purposed
         __builtin_amdgcn_s_barrier();                             // END: every MFMA wave is done with the tiles
         if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
+        if (EPM == 8) {                                           // second flush: scratch re-use barrier + its own
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
         if (EPM == 4 || EPM == 5) {          // conv_epilogue_bnbwd: grid barrier (2) + coefficients (1)
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
@@ -493,9 +497,17 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
     }
     // EPM 6 / 7: the epilogue's z fragments and mask bits (first 4 pixel groups) are requested in front of the END barrier
     // (requesting them a chunk earlier costs the main loop 34 registers it does not have: 28-104 bytes of scratch per lane)
-    constexpr bool BST = EPM == 6 || EPM == 7;
+    constexpr bool BST = EPM == 6 || EPM == 7 || EPM == 8;
     BstFrag<NI, VPD_BST_MB(MI)> bst;
+    BstPair<NI, VPD_BST_MB(MI)> pr;
     if (BST) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+    if (EPM == 8) {
+        conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pr.s3[a][j] = 0.f;
+    }
     __builtin_amdgcn_s_barrier();                                 // END
     if constexpr (EPM == 4 || EPM == 5) {
         conv_epilogue_bnbwd<BM, BN, WM, WN, EPM == 5>(p, acc, mtile, n0, geo, smem);
@@ -505,9 +517,14 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-        if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
+        if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
+        else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
         else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
         if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
+        if constexpr (EPM == 8) {      // the second BatchNorm's rows: (sum g, sum g * z2)
+            __builtin_amdgcn_s_barrier();                         // the first flush has read the scratch
+            conv_stats_flush<BM, BN, WM, WN>(p, st1, pr.s3, mtile, n0, smem, p.stats2);
+        }
     }
 }
 
@@ -1050,6 +1067,7 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
         case 5: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 5, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 6: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 6, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 7: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 7, NS>), grid, dim3(512), lds, stream, q, g); break;
+        case 8: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 8, NS>), grid, dim3(512), lds, stream, q, g); break;
         default: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 3, NS>), grid, dim3(512), lds, stream, q, g); break;
     }
     return hipGetLastError();
@@ -1170,10 +1188,12 @@ bool vpd_conv_takes_bn_sums(const ConvParams& p) {
     HaloGeom g;
     const int kc = vpd_conv_kernel_class(p, &g);
     if (kc == 4) {      // gather kernel: the merged parity classes of a stride-2 data gradient (plain store only)
+        if (p.bst_z2) return false;
         static const int s2 = getenv("VPD_DGRAD_SUMS_S2") ? atoi(getenv("VPD_DGRAD_SUMS_S2")) : 1;
         return s2 && !p.accumulate && p.osub == 2;
     }
     if (p.x2 || p.osub != 1) return false;
+    if (p.bst_z2) return p.accumulate && p.stats2 && (kc == 1 || kc == 2 || kc == 3 || kc == 6);      // mode 8: conv3x3_ws_kernel only
     if (kc == 0) {      // layer1's persistent kernel (not its two-group variant)
         static const int l1 = getenv("VPD_DGRAD_SUMS_L1") ? atoi(getenv("VPD_DGRAD_SUMS_L1")) : 1;
         HaloGeom g2;

@@ -114,7 +114,10 @@ bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
 // BatchNorm backward whose sums (sum g, sum g * z) the producing data gradient's epilogue has already added to `f.rows`
 // (ConvParams::bst_z): finalize + apply in one launch, no reduction pass, no grid barrier.  p.mask_bits is required.
-hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
+// fB / zB / meanB / rstdB / dzB: a second BatchNorm fed with the same masked gradient (same shape, same padded dz geometry)
+hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s, const BnFusedBwd* fB = nullptr,
+                                         const bf16_t* zB = nullptr, const float* meanB = nullptr, const float* rstdB = nullptr,
+                                         bf16_t* dzB = nullptr);
 // two BatchNorm backwards sharing dy and the ReLU mask (a down-sampling block's conv2 BN + its 1x1 branch's BN) in one launch
 bool vpd_bn_bwd_fused2_ok(int M, int C);
 hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p, const BnFusedBwd& fA, const BnFusedBwd& fB, const bf16_t* zB,

@@ -737,11 +737,13 @@ bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
 
 // The sums of a BatchNorm backward (sum g, sum g * z with g = d * mask) taken in the epilogue of the data gradient that
 // produces d (ConvParams::bst_z); the BatchNorm launch is then finalize + apply only (run_bn_bwd_apply).
-struct BnSums { const bf16_t* z; const unsigned char* mask; double* rows; };
-bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate) {
+// z2 / rows2: a second BatchNorm fed with the same g (the 1x1 branch of a down-sampling block), or null
+struct BnSums { const bf16_t* z; const unsigned char* mask; double* rows; const bf16_t* z2; double* rows2; };
+bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate, bool pair = false) {
     if (!c.p->dgrad_sums || cv.stride != 1) return false;
     ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), accumulate);
     q.bst_z = c.b16(0);
+    if (pair) { q.bst_z2 = c.b16(0); q.stats2 = c.stat_rows(); }
     return vpd_conv_takes_bn_sums(q);
 }
 
@@ -764,6 +766,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
         if (sums) {      // (the caller has checked dgrad_takes_sums)
             q.bst_z = sums->z; q.bst_mask = sums->mask;
             q.stats = sums->rows; q.stat_rows = VPD_FUSED_ROWS;
+            q.bst_z2 = sums->z2; q.stats2 = sums->rows2;
         }
         if (bnb) {
             q.bnb = *bnb;
@@ -938,8 +941,9 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
 }
 
 // BatchNorm backward whose sums were taken by the producing data gradient (BnSums): finalize + apply
+// cvB / dzB: a second BatchNorm fed with the same masked gradient (a down-sampling block's 1x1 branch), same launch
 hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, bf16_t* dz, int dzpad, float* grads,
-                            const unsigned char* mask_bits) {
+                            const unsigned char* mask_bits, const ConvInfo* cvB = nullptr, bf16_t* dzB = nullptr) {
     BnBwdParams b;
     memset(&b, 0, sizeof b);
     b.dy = dy; b.z = c.b16(cv.z_off);
@@ -952,6 +956,14 @@ hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, 
     f.rows = c.bn_rows(cv.bn);
     f.gamma = c.params + cv.bn.w_off; f.dgamma = grads + cv.bn.w_off; f.dbeta = grads + cv.bn.b_off;
     f.count = (float)b.M;
+    if (cvB) {
+        BnFusedBwd fB;
+        memset(&fB, 0, sizeof fB);
+        fB.rows = c.bn_rows(cvB->bn);
+        fB.gamma = c.params + cvB->bn.w_off; fB.dgamma = grads + cvB->bn.w_off; fB.dbeta = grads + cvB->bn.b_off;
+        fB.count = f.count;
+        return vpd_launch_bn_bwd_apply_fused(b, f, c.s, &fB, c.b16(cvB->z_off), c.bn_mean(cvB->bn), c.bn_rstd(cvB->bn), dzB);
+    }
     return vpd_launch_bn_bwd_apply_fused(b, f, c.s);
 }
 
@@ -1379,6 +1391,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     };
     std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
     std::vector<char> bn2_sums_for(p->blocks.size(), 0);       // ... its sums taken by the next block's dgrad (BnSums)
+    static const bool pair_sums = !(getenv("VPD_DGRAD_SUMS_PAIR") && !atoi(getenv("VPD_DGRAD_SUMS_PAIR")));
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
         BlockInfo& B = p->blocks[bi];
         const StageInfo& S = p->stages[B.stage];
@@ -1424,7 +1437,12 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         // bn2 (+ReLU of the block output); leaves g = dout*[out>0] in dout.  Already done when the NEXT block's conv1
         // data gradient (the previous iteration of this loop) carried it in its epilogue.
         bool bn_pair = false;      // conv2's BatchNorm and the 1x1 branch's BatchNorm in one launch (same dy, same ReLU mask)
-        if (B.ds && !bn2_fused_for[bi])
+        if (B.ds && bn2_sums_for[bi]) {      // both sums were taken by the next block's data gradient: one finalize + apply launch for both
+            const unsigned char* mb = reinterpret_cast<const unsigned char*>(ws + B.mask_off);
+            LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mb, &B.cd,
+                                    c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off)));
+            bn_pair = true;
+        } else if (B.ds && !bn2_fused_for[bi])
             if (bn_bwd_pair(B.c2, B.cd, dout, c.b16(B.out_off), dz2,
                             c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn_pair)) return -1;
         // plain (identity) blocks: ReLU mask from the forward's bit map; g = dout * mask is neither written back nor re-read --
@@ -1432,8 +1450,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         const unsigned char* mbits = nullptr;
         if (!B.ds && !bn2_fused_for[bi] && relu_bits_ok(c, B.c2) && !(bi > 0 && dgrad_takes_bn(c, B.c1)))
             mbits = reinterpret_cast<const unsigned char*>(ws + B.mask_off);
-        if (bn2_sums_for[bi])      // (the next block's conv1 data gradient took the sums: mbits is set, dout is left alone)
+        if (bn2_sums_for[bi] && !B.ds)      // (the next block's conv1 data gradient took the sums: mbits is set, dout is left alone)
             LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mbits));
+        else if (bn2_sums_for[bi]) { /* down-sampling block: applied above */ }
         else if (!bn2_fused_for[bi] && !bn_pair)
             LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits));
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
@@ -1444,7 +1463,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         } else if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {
             // bn1's sums ride in conv2's data gradient; its BatchNorm launch only finalizes and applies
             const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
-            const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn)};
+            const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn), nullptr, nullptr};
             LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, nullptr, nullptr, nullptr, nullptr, &sm));
             LCHECK(run_bn_bwd_apply(c, B.c1, da1, dz1, 1, grads, m1));
         } else {
@@ -1465,7 +1484,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 if (bi > 0 && p->dgrad_sums && s2sums && (B.c1.Hin % 2) == 0 && (B.c1.Win % 2) == 0) {
                     const BlockInfo& Bp = p->blocks[bi - 1];
                     if (!Bp.ds && relu_bits_ok(c, Bp.c2) && !(bi - 1 > 0 && dgrad_takes_bn(c, Bp.c1))) {
-                        sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn)};
+                        sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn), nullptr, nullptr};
                         smp = &sm;
                         bn2_sums_for[bi - 1] = true;
                     }
@@ -1493,7 +1512,14 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 const BlockInfo& Bp = p->blocks[bi - 1];
                 if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c2) && !dgrad_takes_bn(c, Bp.c1) &&
                     dgrad_takes_sums(c, B.c1, 1)) {
-                    sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn)};
+                    sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn), nullptr, nullptr};
+                    smp = &sm;
+                    bn2_sums_for[bi - 1] = true;
+                } else if (Bp.ds && Bp.stage == B.stage && pair_sums && c.fused(Bp.c2) && c.fused(Bp.cd) &&
+                           Bp.c2.Co == Bp.cd.Co && relu_bits_ok(c, Bp.c2) && dgrad_takes_sums(c, B.c1, 1, true)) {
+                    // a down-sampling block: conv2's BatchNorm and the 1x1 branch's see the same g -- both sums here
+                    sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn),
+                                c.b16(Bp.cd.z_off), c.bn_rows(Bp.cd.bn)};
                     smp = &sm;
                     bn2_sums_for[bi - 1] = true;
                 }
