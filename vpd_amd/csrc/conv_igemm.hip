@@ -1126,6 +1126,7 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
         case 1: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), lds, stream, q); break;
         case 2: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), lds, stream, q); break;
         case 6: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 6>), grid, dim3(256), lds, stream, q); break;
+        case 7: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 7>), grid, dim3(256), lds, stream, q); break;
         default: VPD_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), lds, stream, q); break;
     }
     return hipGetLastError();
@@ -1190,6 +1191,9 @@ bool vpd_conv_takes_bn_sums(const ConvParams& p) {
     if (kc == 4) {      // gather kernel: the merged parity classes of a stride-2 data gradient (plain store only)
         if (p.bst_z2) return false;
         static const int s2 = getenv("VPD_DGRAD_SUMS_S2") ? atoi(getenv("VPD_DGRAD_SUMS_S2")) : 1;
+        static const int g1 = getenv("VPD_DGRAD_SUMS_1X1") ? atoi(getenv("VPD_DGRAD_SUMS_1X1")) : 1;
+        // ... or a dense stride-1 launch of it (the Bottleneck students' 1x1 convs), plain or accumulating
+        if (p.osub == 1 && p.ncls <= 1 && !p.x2) return g1 != 0;
         return s2 && !p.accumulate && p.osub == 2;
     }
     if (p.x2 || p.osub != 1) return false;

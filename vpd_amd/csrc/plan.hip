@@ -67,7 +67,8 @@ struct BlockInfo {
     int stage = 0;
     size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
     size_t mask_off = 0;                             // train, BasicBlock: [M][C/8] ReLU mask bits of the block output
-    size_t mask1_off = 0;                            // train, BasicBlock with dgrad_sums: ReLU mask bits of a1 (0: none)
+    size_t mask1_off = 0;                            // train with dgrad_sums: ReLU mask bits of a1 (0: none)
+    size_t mask2_off = 0;                            // ... of a2 (Bottleneck)
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
@@ -513,10 +514,17 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                 const ConvInfo& last = bottleneck ? B.c3 : B.c2;      // the conv whose BatchNorm feeds the block-output ReLU
                 B.mask_off = bp.take((size_t)NB * last.Hout * last.Wout * last.Co / 8 + 16);
             }
-        p->dgrad_sums = p->relu_bits && p->fused_bn && !bottleneck &&
-                        !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS")));
+        // Bottleneck students: OFF unless VPD_DGRAD_SUMS_BNECK=1 -- their BatchNorm tensors are 4x wider, the backward
+        // launches run at the memory system's rate rather than on the barrier's latency chain, and the second read of z in the
+        // 1x1 data gradients' (exposed) epilogues costs what the shorter BatchNorm launch saves: ResNet-50 8.73 -> 8.76 ms
+        // with every sum moved, 8.71 / 8.73 with the 3x3 ones only (same-box, two alternations each)
+        p->dgrad_sums = p->relu_bits && p->fused_bn && !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS"))) &&
+                        (!bottleneck || (getenv("VPD_DGRAD_SUMS_BNECK") && atoi(getenv("VPD_DGRAD_SUMS_BNECK"))));
         if (p->dgrad_sums)
-            for (auto& B : p->blocks) B.mask1_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co / 8 + 16);
+            for (auto& B : p->blocks) {
+                B.mask1_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co / 8 + 16);
+                if (bottleneck) B.mask2_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co / 8 + 16);
+            }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
@@ -740,7 +748,9 @@ bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
 // z2 / rows2: a second BatchNorm fed with the same g (the 1x1 branch of a down-sampling block), or null
 struct BnSums { const bf16_t* z; const unsigned char* mask; double* rows; const bf16_t* z2; double* rows2; };
 bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate, bool pair = false) {
-    if (!c.p->dgrad_sums || cv.stride != 1) return false;
+    if (!c.p->dgrad_sums) return false;
+    // a stride-2 conv's merged parity classes (plain store; even input dims: the classes tile the input exactly)
+    if (cv.stride != 1) return cv.stride == 2 && cv.k == 3 && !accumulate && !pair && cv.Hin % 2 == 0 && cv.Win % 2 == 0;
     ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), accumulate);
     q.bst_z = c.b16(0);
     if (pair) { q.bst_z2 = c.b16(0); q.stats2 = c.stat_rows(); }
@@ -1164,7 +1174,8 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
-            LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1));
+            LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1,
+                              B.mask2_off ? reinterpret_cast<unsigned char*>(ws + B.mask2_off) : nullptr));
             LCHECK(run_conv_train(c, B.c3, a2, bn_running));
             unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
             if (B.ds) {
@@ -1413,13 +1424,28 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             if (B.ds)
                 if (bn_bwd_pair(B.c3, B.cd, dout, c.b16(B.out_off), dz3,
                                 c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn3_pair)) return -1;
-            if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
+            if (bn2_sums_for[bi]) LCHECK(run_bn_bwd_apply(c, B.c3, dout, dz3, 1, grads, mb3));      // (sums: next block's conv1 dgrad)
+            else if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
-            LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
-            LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
+            if (B.mask2_off && dgrad_takes_sums(c, B.c3, 0)) {      // bn2's sums ride in conv3's data gradient
+                const unsigned char* m2 = reinterpret_cast<const unsigned char*>(ws + B.mask2_off);
+                const BnSums sm{c.b16(B.c2.z_off), m2, c.bn_rows(B.c2.bn), nullptr, nullptr};
+                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0, nullptr, nullptr, nullptr, nullptr, &sm));
+                LCHECK(run_bn_bwd_apply(c, B.c2, da2, dz2, 1, grads, m2));
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
+                LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
+            }
             LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
-            LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
+            if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {      // bn1's in conv2's (3x3, stride 1 or 2)
+                const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
+                const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn), nullptr, nullptr};
+                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0, nullptr, nullptr, nullptr, nullptr, &sm));
+                LCHECK(run_bn_bwd_apply(c, B.c1, da1b, dz1, 1, grads, m1));
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
+                LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
+            }
             LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
                 bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);
@@ -1429,7 +1455,20 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
                 gi = (gi + 2) % 3;
             } else {
-                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mb3));      // identity path + conv path
+                // identity path + conv path = d(out) of the previous block: when that one is a plain block too, the sums of its
+                // bn3 are taken here
+                const BnSums* smp = nullptr;
+                BnSums sm;
+                if (bi > 0 && mb3) {
+                    const BlockInfo& Bp = p->blocks[bi - 1];
+                    if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c3) && dgrad_takes_sums(c, B.c1, 1)) {
+                        sm = BnSums{c.b16(Bp.c3.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c3.bn),
+                                    nullptr, nullptr};
+                        smp = &sm;
+                        bn2_sums_for[bi - 1] = true;
+                    }
+                }
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mb3, smp));
             }
             if (stage_end(bi)) return -1;
             continue;
