@@ -382,6 +382,31 @@ def test_fused_head_matches_the_separate_launches(tmp_path):
     assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
 
 
+_STEP_SCRIPT_R50 = _STEP_SCRIPT.replace('"resnet34"', '"resnet50"').replace("(256, 5, 128, 128)", "(32, 5, 128, 128)") \
+    .replace("(256, 32)", "(32, 32)")
+
+
+def test_batchnorm_backward_sums_on_a_bottleneck_student(tmp_path):
+    """VPD_DGRAD_SUMS_BNECK=1 (off by default: measured neutral on ResNet-50): bn2 / bn3 sums in the 1x1 data gradients on
+    the gather kernel (epilogue modes 6 / 7), bn1's in conv2's (stride 1 halo kernel or the merged stride-2 launch)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("g%s.npy" % flag))
+        env = dict(os.environ, VPD_DGRAD_SUMS_BNECK=flag)
+        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT_R50.format(repo=repo, out=out)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
+    (g0, l0), (g1, l1) = outs
+    assert l0 == l1
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
+    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
+
+
 def _group_of(name):
     return "fc" if ".fc." in name else (name.split(".")[1] if name.split(".")[1].startswith("layer") else "stem")
 
