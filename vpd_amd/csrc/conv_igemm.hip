@@ -1081,6 +1081,162 @@ static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t 
     return launch_ws_ns<BM, BN, HROWS, HB, WPS, 3>(p, g, stream);
 }
 
+// ---------------------------------------------------------------------------
+// 1x1 stride-1 convolution (the Bottleneck students' conv1 / conv3, forward and data gradient) as a warp-specialised ring
+// GEMM: out[M][Co] = X[M][Kc] W[Co][Kc]^T with X the interior pixels of a padded NHWC activation.
+//   waves 4..7 (loaders): per 64-channel K-step the [BM pixels][64] slice of X (each lane's pixel rows resolved to padded
+//     addresses ONCE, in the prologue) and the [BN][64] weight slice go by LDS-DMA into stage s % NS of an NS-deep ring, AHEAD =
+//     NS - 1 steps in front of the MFMA waves; counted vmcnt waits, one workgroup barrier per K-step.
+//   waves 0..3 (MFMA): 64-channel x (BM / WM)-pixel wave tiles out of LDS, the shared epilogue (conv_epilogue.h).
+// The gather kernel (conv_igemm_kernel: four waves, register staging, two LDS buffers, two blocks per CU) runs these
+// 8.6 GFLOP launches at 180-250 TFLOP/s; its loads are one K-step ahead at best.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int NS, int EPM>
+__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p) {
+    constexpr int WN = BN / 64;
+    constexpr int WM = 4 / WN;
+    constexpr int WTM = BM / WM;
+    constexpr int MI = WTM / 16, NI = 4;
+    constexpr int ASTAGE = BM * 64, STAGE = (BM + BN) * 64;
+    constexpr int A_PER = BM / 32, W_PER = BN / 32, PER_STEP = A_PER + W_PER;      // LDS-DMA instructions per loader wave and step
+    constexpr int AHEAD = NS - 1;
+    static_assert(AHEAD >= 1 && AHEAD <= 3 && 3 * PER_STEP < 64, "vmcnt immediates");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* ring = reinterpret_cast<bf16_t*>(smem);               // [NS][STAGE]: X slice, then W slice
+
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mtile = blockIdx.x;
+    const int n0 = blockIdx.y * BN;
+    const int m0 = mtile * BM;
+    const int nsteps = p.Kc >> 6;
+
+    if (wave >= 4) {
+        const int lw = wave - 4;
+        const int piece = lane & 7;
+        const int lrow = lane >> 3;
+        const int HW = p.Hs * p.Ws;
+        int abase[A_PER], wbase[W_PER];
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int r = (lw + 4 * i) * 8 + lrow;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            const int b = m / HW;
+            const int rr = m - b * HW;
+            const int yy = rr / p.Ws;
+            const int xx = rr - yy * p.Ws;
+            abase[i] = ((b * p.xHp + yy + p.taps.dy0) * p.xWp + xx + p.taps.dx0) * p.xC + ((piece ^ (r & 7)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < W_PER; ++i) {
+            const int n = (lw + 4 * i) * 8 + lrow;
+            wbase[i] = (p.taps.w0 * p.Co + n0 + n) * p.Kc + ((piece ^ (n & 7)) << 3);
+        }
+        auto issue = [&](int s) __attribute__((always_inline)) {
+            bf16_t* st = ring + (s % NS) * STAGE;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.x + abase[i] + s * 64), (lptr_t)(st + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < W_PER; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.w + wbase[i] + s * 64), (lptr_t)(st + ASTAGE + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+        };
+#pragma unroll
+        for (int s = 0; s < AHEAD; ++s)
+            if (s < nsteps) issue(s);
+        for (int s = 0; s < nsteps; ++s) {
+            // step s must have landed; the steps issued behind it (at most AHEAD - 1, fewer at the tail) may still be in flight
+            int behind = nsteps - 1 - s;
+            behind = behind < AHEAD - 1 ? behind : AHEAD - 1;
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STEP) : "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // READY_s (stage (s - 1) % NS is free again)
+            if (s + AHEAD < nsteps) issue(s + AHEAD);
+        }
+        __builtin_amdgcn_s_barrier();                             // END
+        if (p.stats) __builtin_amdgcn_s_barrier();                // matches the barrier inside conv_stats_flush
+        return;
+    }
+
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsteps; ++s) {
+        __builtin_amdgcn_s_barrier();                             // READY_s
+        const bf16_t* cA = ring + (s % NS) * STAGE;
+        const bf16_t* cW = cA + ASTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[NI], bfm[MI];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int a = 0; a < NI; ++a) {
+                const int r = wn * 64 + a * 16 + fr;
+                af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int r = wm * WTM + b * 16 + fr;
+                bfm[b] = *reinterpret_cast<const bf16x8*>(cA + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();                                 // END
+    float st1[NI][4], st2[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
+}
+
+// 1x1, stride 1, one tap, one class, no second convolution / input, plain epilogue modes, K deep enough for the ring to matter
+static bool conv1x1_ws_eligible(const ConvParams& p) {
+    static const int on = getenv("VPD_CONV1X1_WS") ? atoi(getenv("VPD_CONV1X1_WS")) : 1;
+    static const int kmin = getenv("VPD_CONV1X1_KMIN") ? atoi(getenv("VPD_CONV1X1_KMIN")) : 256;
+    return on && p.taps.nr == 1 && p.taps.nc == 1 && p.istr == 1 && p.osub == 1 && p.oph == 0 && p.opw == 0 && p.ncls <= 1 &&
+           !p.alt_w && !p.x2 && !p.bnb.mode && !p.bst_z && p.xC == p.Kc && p.Kc >= kmin && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
+           (long)p.N * p.xHp * p.xWp * p.xC < (1l << 31) && (long)p.Co * p.Kc < (1l << 31);
+}
+template <int BM, int BN, int NS>
+static hipError_t launch_1x1_ws(const ConvParams& p, hipStream_t stream) {
+    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t);
+    static_assert((size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) <= 160 * 1024, "LDS");
+    ConvParams q = p;
+    switch (conv_ep_mode(q)) {
+        case 0: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 0>), grid, dim3(512), lds, stream, q); break;
+        case 1: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 1>), grid, dim3(512), lds, stream, q); break;
+        case 2: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 2>), grid, dim3(512), lds, stream, q); break;
+        case 3: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 3>), grid, dim3(512), lds, stream, q); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// tile choice: the largest tile that still gives every CU a block
+static hipError_t launch_1x1(const ConvParams& p, hipStream_t stream) {
+    const long t256 = (long)((p.M + 255) / 256), t128 = (long)((p.M + 127) / 128);
+    if (p.Co % 128 == 0 && t256 * (p.Co / 128) >= 200) return launch_1x1_ws<256, 128, 3>(p, stream);
+    if (p.Co % 128 == 0 && t128 * (p.Co / 128) >= 200) return launch_1x1_ws<128, 128, 4>(p, stream);
+    return launch_1x1_ws<128, 64, 4>(p, stream);
+}
+
 template <int BM, int BN, int HROWS, bool HALO2>
 static hipError_t launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
@@ -1233,6 +1389,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }
+    if (conv1x1_ws_eligible(p)) return launch_1x1(p, stream);
     // the statistics accumulator rows only depend on the block index, so the tile choice is free
     const int bm = vpd_conv_bm(p.M, p.Co);
     if (halo_eligible(p) && !p.alt_w && !p.x2) {
