@@ -125,6 +125,10 @@ CONV_CASES = [
     ("b1_1x1_s1_256to64", 3, 256, 64, 16, 16, 1, 1, 0),
     ("b3_1x1_s1_128to512_ragged", 5, 128, 512, 4, 4, 1, 1, 0),
     ("ds_1x1_s2_32to16", 2, 64, 128, 32, 32, 1, 2, 0),
+    # the ring-GEMM kernel for deep 1x1 convs (conv1x1_ws_kernel): 256 x 128 tiles / 3 stages, 128 x 128 / 4 stages (forward),
+    # 128 x 64 (the data gradient of the second case: K = 256, 1,024 output channels -> 128 x 128), ragged last tiles
+    ("b_1x1_s1_512to128_t256", 50, 512, 128, 32, 32, 1, 1, 0),
+    ("b_1x1_s1_1024to256_t128", 200, 1024, 256, 8, 8, 1, 1, 0),
 ]
 
 

@@ -1209,9 +1209,13 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p) {
 // 1x1, stride 1, one tap, one class, no second convolution / input, plain epilogue modes, K deep enough for the ring to matter
 static bool conv1x1_ws_eligible(const ConvParams& p) {
     static const int on = getenv("VPD_CONV1X1_WS") ? atoi(getenv("VPD_CONV1X1_WS")) : 1;
+    // K >= 512 (8+ steps), or 4+ steps when the launch is at most a few rounds of blocks: layer1's 256 -> 64 convs (2,048
+    // blocks of four steps) stream their 168 MB faster through the gather kernel's two small blocks per CU
     static const int kmin = getenv("VPD_CONV1X1_KMIN") ? atoi(getenv("VPD_CONV1X1_KMIN")) : 256;
+    static const int mmax = getenv("VPD_CONV1X1_MMAX") ? atoi(getenv("VPD_CONV1X1_MMAX")) : 32768;
+    if (p.Kc < 512 && !(p.Kc >= kmin && p.M <= mmax)) return false;
     return on && p.taps.nr == 1 && p.taps.nc == 1 && p.istr == 1 && p.osub == 1 && p.oph == 0 && p.opw == 0 && p.ncls <= 1 &&
-           !p.alt_w && !p.x2 && !p.bnb.mode && !p.bst_z && p.xC == p.Kc && p.Kc >= kmin && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
+           !p.alt_w && !p.x2 && !p.bnb.mode && !p.bst_z && p.xC == p.Kc && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
            (long)p.N * p.xHp * p.xWp * p.xC < (1l << 31) && (long)p.Co * p.Kc < (1l << 31);
 }
 template <int BM, int BN, int NS>
