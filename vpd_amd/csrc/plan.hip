@@ -769,7 +769,6 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
     q.w = c.b16(c.p->arena_off) + cv.dgr_off;
     q.y = dx; q.yHp = cv.Hin; q.yWp = cv.Win; q.yC = cv.Ci; q.ypad = 0;
     q.N = c.n; q.Kc = cv.Co; q.Co = cv.Ci; q.accumulate = accumulate; q.istr = 1;
-    hipError_t e = hipSuccess;
     if (cv.stride == 1) {
         q = conv_dgrad_s1_params(c, cv, dz, dx, accumulate);
         q.acc_mask = accumulate ? acc_mask : nullptr;
