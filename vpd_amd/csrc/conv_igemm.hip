@@ -960,27 +960,44 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
         for (int a = 0; a < NI; ++a)
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const bf16_t* cW = sW + r * BN * 64;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[NI], bfm[MI];
-                const int chunk = kk * 4 + fq;                    // column tap t = chunk (8 channels each)
-#pragma unroll
-                for (int a = 0; a < NI; ++a) {
-                    const int rr = a * 16 + fr;
-                    af[a] = *reinterpret_cast<const bf16x8*>(cW + rr * 64 + ((chunk ^ (rr & 7)) << 3));
-                }
-#pragma unroll
-                for (int b = 0; b < MI; ++b)
-                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + pbase[b] + (r * Wp + chunk) * 8);
-#pragma unroll
-                for (int a = 0; a < NI; ++a)
-#pragma unroll
-                    for (int b = 0; b < MI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+        // as in conv3x3_c64_persistent_kernel: one MFMA wave per SIMD, no barrier inside a tile -- two fragment sets, the next
+        // half-step's six reads pinned behind the first three MFMAs of the current one
+        static_assert(NI == 4 && MI == 2, "fragment schedule below");
+        bf16x8 af[2][NI], bfm[2][MI];
+        // fragment i of half-step st = 2 * (kernel row r) + kk: 0 -> af[0], 1 -> bfm[0], 2 -> bfm[1], 3.. -> af[1..]
+        auto ldone = [&](int st, int buf, int i) __attribute__((always_inline)) {
+            const int r = st >> 1, kk = st & 1;
+            const int chunk = kk * 4 + fq;                        // column tap t = chunk (8 channels each)
+            if (i == 1 || i == 2) {
+                bfm[buf][i - 1] = *reinterpret_cast<const bf16x8*>(cH + pbase[i - 1] + (r * Wp + chunk) * 8);
+            } else {
+                const int a = i == 0 ? 0 : i - 2;
+                const int rr = a * 16 + fr;
+                af[buf][a] = *reinterpret_cast<const bf16x8*>(sW + r * BN * 64 + rr * 64 + ((chunk ^ (rr & 7)) << 3));
             }
+        };
+#pragma unroll
+        for (int i2 = 0; i2 < NI + MI; ++i2) ldone(0, 0, i2);
+#pragma unroll
+        for (int st = 0; st < 14; ++st) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            const bool more = st + 1 < 14;
+#define STEM_MFMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][a], bfm[cur][b], acc[a][b], 0, 0, 0)
+            STEM_MFMA(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { ldone(st + 1, nxt, 0); ldone(st + 1, nxt, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            STEM_MFMA(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { ldone(st + 1, nxt, 2); ldone(st + 1, nxt, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            STEM_MFMA(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) { ldone(st + 1, nxt, 4); ldone(st + 1, nxt, 5); }
+            __builtin_amdgcn_sched_barrier(0);
+            STEM_MFMA(1, 1); STEM_MFMA(2, 0); STEM_MFMA(2, 1); STEM_MFMA(3, 0); STEM_MFMA(3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#undef STEM_MFMA
         }
         if (!lds_store) {
             conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
