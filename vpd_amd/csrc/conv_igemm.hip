@@ -1109,7 +1109,16 @@ static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t 
 // 8.6 GFLOP launches at 180-250 TFLOP/s; its loads are one K-step ahead at best.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int NS, int EPM>
-__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p0) {
+    // second convolution of the launch (ConvParams::alt_*: a BasicBlock's 1x1 down-sampling branch beside its stride-2 3x3):
+    // the blocks with blockIdx.y >= alt_y0 see it as THE convolution
+    ConvParams p = p0;
+    int by = blockIdx.y;
+    if (p0.alt_w && by >= p0.alt_y0) {
+        by -= p0.alt_y0;
+        p.w = p0.alt_w; p.y = p0.alt_y; p.stats = p0.alt_stats; p.taps = p0.alt_taps;
+        p.ep_scale = p0.alt_ep_scale; p.ep_shift = p0.alt_ep_shift; p.ep_relu = p0.alt_ep_relu; p.res = nullptr;
+    }
     constexpr int WN = BN / 64;
     constexpr int WM = 4 / WN;
     constexpr int WTM = BM / WM;
@@ -1121,45 +1130,74 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);               // [NS][STAGE]: X slice, then W slice
 
-    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    // parity class of a merged stride-2 data gradient (blockIdx.z, heaviest class first as in conv_igemm_kernel)
+    ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    TapSet taps = p.taps;
+    const int cls = (int)gridDim.z - 1 - (int)blockIdx.z;
+    switch (cls) {
+        case 1: geo = p.cls[0].geo; taps = p.cls[0].taps; break;
+        case 2: geo = p.cls[1].geo; taps = p.cls[1].taps; break;
+        case 3: geo = p.cls[2].geo; taps = p.cls[2].taps; break;
+        default: break;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mtile = blockIdx.x;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = by * BN;
     const int m0 = mtile * BM;
-    const int nsteps = p.Kc >> 6;
+    if (m0 >= geo.M) return;                                      // (a smaller class: whole block, before any barrier)
+    const int kchunks = p.Kc >> 6;
+    const int nsteps1 = taps.nr * taps.nc * kchunks;              // K-step s = (tap s / kchunks, 64-channel chunk s % kchunks)
+    // class 0 only: extra K-steps from the second input tensor (same pixels, first tap's offset, its own weights)
+    const int nsteps = nsteps1 + ((p.x2 && cls == 0) ? (p.Kc2 >> 6) : 0);
 
     if (wave >= 4) {
         const int lw = wave - 4;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
-        const int HW = p.Hs * p.Ws;
+        const int HW = geo.Hs * geo.Ws;
         int abase[A_PER], wbase[W_PER];
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int r = (lw + 4 * i) * 8 + lrow;
             int m = m0 + r;
-            m = m < p.M ? m : p.M - 1;
+            m = m < geo.M ? m : geo.M - 1;
             const int b = m / HW;
             const int rr = m - b * HW;
-            const int yy = rr / p.Ws;
-            const int xx = rr - yy * p.Ws;
-            abase[i] = ((b * p.xHp + yy + p.taps.dy0) * p.xWp + xx + p.taps.dx0) * p.xC + ((piece ^ (r & 7)) << 3);
+            const int yy = rr / geo.Ws;
+            const int xx = rr - yy * geo.Ws;
+            abase[i] = ((b * p.xHp + yy * p.istr) * p.xWp + xx * p.istr) * p.xC + ((piece ^ (r & 7)) << 3);
         }
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
             const int n = (lw + 4 * i) * 8 + lrow;
-            wbase[i] = (p.taps.w0 * p.Co + n0 + n) * p.Kc + ((piece ^ (n & 7)) << 3);
+            wbase[i] = (n0 + n) * p.Kc + ((piece ^ (n & 7)) << 3);      // (Kc2 == Kc: checked by the launcher)
         }
         auto issue = [&](int s) __attribute__((always_inline)) {
             bf16_t* st = ring + (s % NS) * STAGE;
+            const bf16_t* xs = p.x;
+            const bf16_t* wsrc = p.w;
+            int aoff, woff;
+            if (s < nsteps1) {
+                const int tap = s / kchunks;
+                const int cc = s - tap * kchunks;
+                const int ir = tap / taps.nc;
+                const int ic = tap - ir * taps.nc;
+                aoff = ((taps.dy0 + ir * taps.dys) * p.xWp + (taps.dx0 + ic * taps.dxs)) * p.xC + cc * 64;
+                woff = (taps.w0 + ir * taps.wrs + ic * taps.wcs) * p.Co * p.Kc + cc * 64;
+            } else {
+                const int cc = s - nsteps1;
+                xs = p.x2; wsrc = p.w2;
+                aoff = (taps.dy0 * p.xWp + taps.dx0) * p.xC + cc * 64;
+                woff = cc * 64;
+            }
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.x + abase[i] + s * 64), (lptr_t)(st + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(xs + abase[i] + aoff), (lptr_t)(st + (lw + 4 * i) * 8 * 64), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < W_PER; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.w + wbase[i] + s * 64), (lptr_t)(st + ASTAGE + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + wbase[i] + woff), (lptr_t)(st + ASTAGE + (lw + 4 * i) * 8 * 64), 16, 0, 0);
         };
 #pragma unroll
         for (int s = 0; s < AHEAD; ++s)
@@ -1230,31 +1268,49 @@ static bool conv1x1_ws_eligible(const ConvParams& p) {
     // blocks of four steps) stream their 168 MB faster through the gather kernel's two small blocks per CU
     static const int kmin = getenv("VPD_CONV1X1_KMIN") ? atoi(getenv("VPD_CONV1X1_KMIN")) : 256;
     static const int mmax = getenv("VPD_CONV1X1_MMAX") ? atoi(getenv("VPD_CONV1X1_MMAX")) : 32768;
+    const bool common = on && !p.bnb.mode && !p.bst_z2 && p.xC == p.Kc && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
+                        (long)p.N * p.xHp * p.xWp * p.xC < (1l << 31) && (long)9 * p.Co * p.Kc < (1l << 31);
+    if (!common) return false;
+    // the merged parity classes of a stride-2 3x3 data gradient (+ the 1x1 branch's as extra K-steps of class 0) at the layer3
+    // and layer4 boundaries (layer2's has 2,048 blocks of 2-8 K-steps: gather kernel)
+    static const int dgon = getenv("VPD_CONV_S2_DGRAD_WS") ? atoi(getenv("VPD_CONV_S2_DGRAD_WS")) : 1;
+    if (p.ncls > 1 || p.x2 || p.osub != 1)
+        return dgon && p.ncls == 4 && p.osub == 2 && p.istr == 1 && !p.alt_w && !p.accumulate && !p.ep_scale && p.Kc >= 256 &&
+               p.Co % 128 == 0 && (!p.x2 || p.Kc2 == p.Kc) && (!p.bst_z || (p.yC == p.Co && p.ypad == 0));
+    if (p.bst_z || p.oph != 0 || p.opw != 0) return false;
+    // the stride-2 convs at the ResNet stage boundaries (3x3 forward, with the BasicBlock's 1x1 branch as second convolution):
+    // 9-36 K-steps, one round of blocks with the tile choice below
+    static const int s2on = getenv("VPD_CONV_S2_WS") ? atoi(getenv("VPD_CONV_S2_WS")) : 1;
+    if (p.istr == 2) return s2on && p.taps.nr == 3 && p.taps.nc == 3 && (!p.alt_w || (p.alt_taps.nr == 1 && p.alt_taps.nc == 1));
     if (p.Kc < 512 && !(p.Kc >= kmin && p.M <= mmax)) return false;
-    return on && p.taps.nr == 1 && p.taps.nc == 1 && p.istr == 1 && p.osub == 1 && p.oph == 0 && p.opw == 0 && p.ncls <= 1 &&
-           !p.alt_w && !p.x2 && !p.bnb.mode && !p.bst_z && p.xC == p.Kc && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
-           (long)p.N * p.xHp * p.xWp * p.xC < (1l << 31) && (long)p.Co * p.Kc < (1l << 31);
+    return p.taps.nr == 1 && p.taps.nc == 1 && p.istr == 1 && !p.alt_w;
 }
 template <int BM, int BN, int NS>
 static hipError_t launch_1x1_ws(const ConvParams& p, hipStream_t stream) {
-    dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
+    int maxM = p.M;
+    for (int k = 1; k < p.ncls; ++k) maxM = p.cls[k - 1].geo.M > maxM ? p.cls[k - 1].geo.M : maxM;
+    dim3 grid((maxM + BM - 1) / BM, (p.Co / BN) * (p.alt_w ? 2 : 1), p.ncls > 1 ? p.ncls : 1);
     const size_t lds = (size_t)NS * (BM + BN) * 64 * sizeof(bf16_t);
     static_assert((size_t)NS * (BM + BN) * 64 * sizeof(bf16_t) <= 160 * 1024, "LDS");
     ConvParams q = p;
+    if (q.alt_w) q.alt_y0 = p.Co / BN;      // the second convolution's blocks follow the first's
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 0>), grid, dim3(512), lds, stream, q); break;
         case 1: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 1>), grid, dim3(512), lds, stream, q); break;
         case 2: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 2>), grid, dim3(512), lds, stream, q); break;
         case 3: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 3>), grid, dim3(512), lds, stream, q); break;
+        case 6: VPD_LAUNCH((conv1x1_ws_kernel<BM, BN, NS, 6>), grid, dim3(512), lds, stream, q); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 // tile choice: the largest tile that still gives every CU a block
 static hipError_t launch_1x1(const ConvParams& p, hipStream_t stream) {
-    const long t256 = (long)((p.M + 255) / 256), t128 = (long)((p.M + 127) / 128);
-    if (p.Co % 128 == 0 && t256 * (p.Co / 128) >= 200) return launch_1x1_ws<256, 128, 3>(p, stream);
-    if (p.Co % 128 == 0 && t128 * (p.Co / 128) >= 200) return launch_1x1_ws<128, 128, 4>(p, stream);
+    long t256 = (long)((p.M + 255) / 256), t128 = (long)((p.M + 127) / 128);
+    for (int k = 1; k < p.ncls; ++k) { t256 += (p.cls[k - 1].geo.M + 255) / 256; t128 += (p.cls[k - 1].geo.M + 127) / 128; }
+    const int nconv = p.alt_w ? 2 : 1;
+    if (p.Co % 128 == 0 && t256 * (p.Co / 128) * nconv >= 200) return launch_1x1_ws<256, 128, 3>(p, stream);
+    if (p.Co % 128 == 0 && t128 * (p.Co / 128) * nconv >= 200) return launch_1x1_ws<128, 128, 4>(p, stream);
     return launch_1x1_ws<128, 64, 4>(p, stream);
 }
 
