@@ -276,7 +276,12 @@ def main():
         traffic, traffic_note = None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-            rows = [v for k, v in pmc["kernels"].items() if dom.split("<")[0].split(" ")[0] in k]
+            # rows of the dominant class only: its kernel name AND one of its tile shapes ("<256,64,416>" -> "<256, 64, 416,")
+            import re
+            base = dom.split("<")[0].split(" ")[0]
+            tiles = [", ".join(t.split(",")) for t in re.findall(r"<([0-9,]+)>", dom)]
+            rows = [v for k, v in pmc["kernels"].items()
+                    if base in k and (not tiles or any(("<" + t + ",") in k or ("<" + t + ">") in k for t in tiles))]
             n = sum(r["launches"] for r in rows)
             traffic = sum(r["launches"] * (2 * r["fetch_KB_per_launch"] + r["write_KB_per_launch"]) for r in rows) / n * 1024
             traffic_note = pmc["note"]
