@@ -341,10 +341,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
 // ---------------------------------------------------------------------------
 // HB: halo buffers (1 when the conv has a single 64-channel chunk: the smaller footprint lets two blocks share a
 // CU and overlap each other's prologue / epilogue); WPS: launch-bounds waves per SIMD (4 = two blocks per CU).
-template <int BM, int BN, int HROWS, int HB, int WPS, int EPM, int NS>
-__global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
+// NMW: MFMA waves (4 = one per SIMD; 8 = two per SIMD, which hide each other's LDS round trips: 12 waves per block, three
+// per SIMD, at most 168 registers each)
+template <int BM, int BN, int HROWS, int HB, int WPS, int EPM, int NS, int NMW = 4>
+__global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const ConvParams p, const HaloGeom g) {
     constexpr int WN = BN / 64;
-    constexpr int WM = 4 / WN;
+    constexpr int WM = NMW / WN;
     constexpr int WTM = BM / WM;
     constexpr int MI = WTM / 16, NI = 4;
     constexpr int AHEAD = NS - 1;                    // weight tiles in flight beyond the one being consumed
@@ -370,9 +372,9 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
     const int nchunks = Ci >> 6;
     const int nsteps = nchunks * 9;
 
-    if (wave >= 4) {
+    if (wave >= NMW) {
         // ------------------------------ loader waves ------------------------------
-        const int lw = wave - 4;
+        const int lw = wave - NMW;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
         const int gr0 = mtile * g.TR;
@@ -465,34 +467,42 @@ __global__ __launch_bounds__(512, WPS) void conv3x3_ws_kernel(const ConvParams p
         for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int s = 0;
+    auto tap_body = [&](int tap, const bf16_t* cH) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_barrier();                             // READY_s
+        if (VPD_ABL(p, 2)) return;
+        const int ir = tap / 3, ic = tap - ir * 3;
+        const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
+        const bf16_t* cW = sW + (s % NS) * WSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[NI], bfm[MI];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int a = 0; a < NI; ++a) {
+                const int r = wn * 64 + a * 16 + fr;
+                af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int r = hbase[b] + toff;
+                bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+        }
+    };
     for (int cc = 0; cc < nchunks; ++cc) {
         const bf16_t* cH = sH + (cc & (HB - 1)) * HBUF;
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            __builtin_amdgcn_s_barrier();                         // READY_s
-            if (VPD_ABL(p, 2)) continue;
-            const int ir = tap / 3, ic = tap - ir * 3;
-            const int toff = (p.taps.dy0 + ir * p.taps.dys) * Wp + (p.taps.dx0 + ic * p.taps.dxs);
-            const bf16_t* cW = sW + (s % NS) * WSTAGE;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[NI], bfm[MI];
-                const int chunk = kk * 4 + fq;
-#pragma unroll
-                for (int a = 0; a < NI; ++a) {
-                    const int r = wn * 64 + a * 16 + fr;
-                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
-#pragma unroll
-                for (int b = 0; b < MI; ++b) {
-                    const int r = hbase[b] + toff;
-                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
-#pragma unroll
-                for (int a = 0; a < NI; ++a)
-#pragma unroll
-                    for (int b = 0; b < MI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
-            }
+        if constexpr (NMW == 8) {
+            // 168 registers per wave here: keep the tap loop a loop (unrolled, hipcc hoists the fragment addresses of all nine
+            // taps out of the chunk loop: 212 bytes of scratch per lane)
+#pragma nounroll
+            for (int tap = 0; tap < 9; ++tap, ++s) tap_body(tap, cH);
+        } else {
+            for (int tap = 0; tap < 9; ++tap, ++s) tap_body(tap, cH);
         }
     }
     // EPM 6 / 7: the epilogue's z fragments and mask bits (first 4 pixel groups) are requested in front of the END barrier
@@ -1076,6 +1086,24 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
     const size_t lds = ((size_t)HB * HROWS + NS * BN) * 64 * sizeof(bf16_t);
     static_assert(((size_t)HB * HROWS + NS * BN) * 64 * sizeof(bf16_t) <= 160 * 1024, "LDS");
     ConvParams q = p;
+    // layer2's 256 x 128 tile with EIGHT MFMA waves (64 x 64 wave tiles, two waves per SIMD) + the four loader waves
+    // (the 256 x 64 tile with eight MFMA waves -- 32 x 64 wave tiles, six fragment reads per eight MFMAs -- is LDS-read-bound:
+    //  class 525 -> 590 us)
+    if constexpr (BM == 256 && BN == 128 && NS == 4) {
+        static const int mw8 = getenv("VPD_WS_MW8") ? atoi(getenv("VPD_WS_MW8")) : 1;
+        if (mw8) {
+            switch (conv_ep_mode(q)) {
+                case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 0, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 1, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 2, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 3: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 3, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 6: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 6, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 7: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 7, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                case 8: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, 3, 8, NS, 8>), grid, dim3(768), lds, stream, q, g); return hipGetLastError();
+                default: break;
+            }
+        }
+    }
     switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1, NS>), grid, dim3(512), lds, stream, q, g); break;
