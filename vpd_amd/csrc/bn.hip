@@ -820,8 +820,8 @@ hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f0,
     f.momentum = f0.momentum; f.eps = f0.eps;
     const long items = (long)p.M * (p.C / 8);
     long g = (items + 1023) / 1024;
-    // every block pays the finalize prologue (2*C*VPD_FUSED_ROWS doubles): few, fat blocks -- two per CU
-    if (g > 512) g = 512;
+    // every block pays the finalize prologue (2*C*VPD_FUSED_ROWS doubles): few, fat blocks -- one per CU
+    if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)4 * p.C * sizeof(float), s, p, f);
     return hipGetLastError();
@@ -1060,7 +1060,7 @@ hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd&
     f.dgamma = f0.dgamma; f.dbeta = f0.dbeta;
     const long items = (long)p.M * (p.C / 8);
     long g = (items + 1023) / 1024;
-    if (g > 512) g = 512;
+    if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
     if (fB) {
         f.rows2 = fB->rows; f.gamma2 = fB->gamma; f.mean2 = meanB; f.rstd2 = rstdB; f.dgamma2 = fB->dgamma; f.dbeta2 = fB->dbeta;
