@@ -750,7 +750,8 @@ struct BnSums { const bf16_t* z; const unsigned char* mask; double* rows; const 
 bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate, bool pair = false) {
     if (!c.p->dgrad_sums) return false;
     // a stride-2 conv's merged parity classes (plain store; even input dims: the classes tile the input exactly)
-    if (cv.stride != 1) return cv.stride == 2 && cv.k == 3 && !accumulate && !pair && cv.Hin % 2 == 0 && cv.Win % 2 == 0;
+    static const bool s2on = !(getenv("VPD_DGRAD_SUMS_S2") && !atoi(getenv("VPD_DGRAD_SUMS_S2")));      // (as vpd_conv_takes_bn_sums)
+    if (cv.stride != 1) return s2on && cv.stride == 2 && cv.k == 3 && !accumulate && !pair && cv.Hin % 2 == 0 && cv.Win % 2 == 0;
     ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), accumulate);
     q.bst_z = c.b16(0);
     if (pair) { q.bst_z2 = c.b16(0); q.stats2 = c.stat_rows(); }
