@@ -196,6 +196,8 @@ struct HaloGeom {
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
+#include "conv_pws.h"
+
 template <int BM, int BN, int HROWS, bool HALO2>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, const HaloGeom g) {
     constexpr int WM = 2, WN = 2;
@@ -1080,6 +1082,65 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// conv3x3_pws_kernel (conv_pws.h): persistent blocks, LDS flag hand-off.  VPD_PWS=0 restores conv3x3_ws_kernel.
+// ---------------------------------------------------------------------------
+static int pws_cu_count() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 1;
+        // VPD_PWS_BLOCKS: pretend the device has this many CUs (tests: many tiles per block on small problems)
+        if (getenv("VPD_PWS_BLOCKS") && atoi(getenv("VPD_PWS_BLOCKS")) > 0) ncu = atoi(getenv("VPD_PWS_BLOCKS"));
+    }
+    return ncu;
+}
+static int pws_variant(const ConvParams& p) {      // experiments: train-forward launches only (bench_conv.py)
+    static const int v = getenv("VPD_PWS_VAR") ? atoi(getenv("VPD_PWS_VAR")) : 0;
+    return conv_ep_mode(p) == 1 ? v : 0;
+}
+static bool pws_enabled(const ConvParams& p) {
+    static const int on = getenv("VPD_PWS") ? atoi(getenv("VPD_PWS")) : 1;
+    const int mode = conv_ep_mode(p);
+    return on && mode != 4 && mode != 5;
+}
+// EXP: an experimental variant (VPD_PWS_VAR): only the train-forward epilogue is instantiated
+template <int BM, int BN, int HROWS, int NS, int AHEAD, int NMW, bool PIPE, bool EXP = false>
+static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
+    constexpr int WN = BN / 64, WM = NMW / WN;
+    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + 1024 + 256 + (size_t)2 * WM * BN * 4;
+    static_assert(lds <= 160 * 1024, "LDS");
+    PwsGrid sg;
+    sg.MT = (p.M + BM - 1) / BM;
+    sg.NT = p.Co / BN;
+    int lanes = pws_cu_count() / sg.NT;
+    if (lanes < 1) lanes = 1;
+    if (lanes > sg.MT) lanes = sg.MT;
+    if (lanes >= 8) lanes &= ~7;
+    sg.lanes = lanes;
+    sg.xcd = lanes % 8 == 0;
+    const dim3 grid(lanes * sg.NT), block((NMW + 4) * 64);
+    ConvParams q = p;
+    if constexpr (EXP) {
+        if (conv_ep_mode(q) != 1) return hipErrorInvalidValue;
+        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg);
+        return hipGetLastError();
+    } else {
+    switch (conv_ep_mode(q)) {
+        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 3, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 6, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 7, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 8, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+    }
+}
+
 template <int BM, int BN, int HROWS, int HB, int WPS, int NS>
 static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     dim3 grid((p.M + BM - 1) / BM, p.Co / BN);
@@ -1485,12 +1546,36 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
             if (c64x2_geom(p, &g2)) return launch_c64x2(p, g2, stream);      // inference: two MFMA wave groups on 256-pixel tiles
             return launch_c64<224>(p, g, stream);
         }
-        case 1: return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
+        case 1:
+            if (pws_enabled(p)) {
+                if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 4, 1, 8, false, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<256, 128, 352, 4, 3, 8, false, true>(p, g, stream);
+                return launch_pws<256, 128, 352, 4, 2, 8, false>(p, g, stream);
+            }
+            return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
         // four ring stages (the loaders three weight tiles ahead): same-box A/B against 3 / 5 stages in
         // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
-        case 2: return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
-        case 3: return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
-        case 6: return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB
+        case 2:
+            if (pws_enabled(p)) {
+                if (pws_variant(p) == 1) return launch_pws<128, 128, 288, 5, 3, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<128, 128, 288, 4, 2, 4, true, true>(p, g, stream);
+                return launch_pws<128, 128, 288, 5, 2, 4, true>(p, g, stream);
+            }
+            return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
+        case 3:
+            if (pws_enabled(p)) {
+                if (pws_variant(p) == 1) return launch_pws<128, 64, 288, 8, 4, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<128, 64, 288, 5, 3, 4, true, true>(p, g, stream);
+                return launch_pws<128, 64, 288, 6, 3, 4, true>(p, g, stream);
+            }
+            return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
+        case 6:
+            if (pws_enabled(p)) {
+                if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 3, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 5, 2, 4, true, true>(p, g, stream);
+                return launch_pws<256, 64, 416, 6, 3, 4, true>(p, g, stream);
+            }
+            return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }

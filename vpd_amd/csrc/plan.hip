@@ -677,6 +677,7 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.oph = 0; q.opw = 0; q.istr = cv.stride;
     q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout; q.accumulate = 0;
     q.taps = conv_taps_fwd(cv);
+    q.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
     double flops = conv_flops(cv, c.n);
     if (alt) {
         const ConvInfo& av = *alt->cv;
@@ -726,6 +727,7 @@ ConvParams conv_dgrad_s1_params(const Ctx& c, const ConvInfo& cv, const bf16_t* 
     q.taps.nr = cv.k; q.taps.nc = cv.k;
     q.taps.dy0 = cv.pad + 1; q.taps.dys = -1; q.taps.dx0 = cv.pad + 1; q.taps.dxs = -1;
     q.taps.w0 = 0; q.taps.wrs = cv.k; q.taps.wcs = 1;
+    q.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
     return q;
 }
 
