@@ -13,6 +13,10 @@
 // barrier per step.  LDS tiles are [rows][64] bf16 (128-B rows) with the 16-B
 // chunk index XOR-ed by (row & 7): conflict-free for ds_read_b128 fragments.
 #include <stdlib.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -1106,10 +1110,10 @@ static bool pws_enabled(const ConvParams& p) {
     return on && mode != 4 && mode != 5;
 }
 // EXP: an experimental variant (VPD_PWS_VAR): only the train-forward epilogue is instantiated
-template <int BM, int BN, int HROWS, int NS, int AHEAD, int NMW, bool PIPE, bool EXP = false>
+template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false>
 static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     constexpr int WN = BN / 64, WM = NMW / WN;
-    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + 1024 + 256 + (size_t)2 * WM * BN * 4;
+    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + 1024 + (size_t)2 * WM * BN * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     PwsGrid sg;
     sg.MT = (p.M + BM - 1) / BM;
@@ -1122,21 +1126,53 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
     sg.xcd = lanes % 8 == 0;
     const dim3 grid(lanes * sg.NT), block((NMW + 4) * 64);
     ConvParams q = p;
+#ifdef PWS_STAMPS
+    // diagnostic build: stamps of launch 30 of each kernel shape, as differences from the block's entry, median over blocks
+    static unsigned long long* dstamps = nullptr;
+    static int nlaunch = 0;
+    if (!dstamps) (void)hipMalloc(&dstamps, 4096 * 16 * 8);
+    (void)hipMemsetAsync(dstamps, 0, 4096 * 16 * 8, stream);
+    q.err = reinterpret_cast<unsigned*>(dstamps);
+    struct Dump { static void run(int nb, const char* tag) {
+        static unsigned long long h[4096 * 16];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, dstamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost);
+        const char* names[16] = {"entry", "setup done", "first READY", "K loop done", "epilogue issued", "tiles done", "stats flushed",
+                                 "stores drained", "L entry", "L halo issued", "L first landed", "L done", "", "", "", ""};
+        fprintf(stderr, "[pws stamps %s, %d blocks] cycles from the consumer's entry (median / max over blocks)\n", tag, nb);
+        for (int k = 1; k < 12; ++k) {
+            if (k == 8) continue;
+            std::vector<long long> d;
+            for (int b = 0; b < nb; ++b) if (h[b * 16 + k] && h[b * 16]) d.push_back((long long)(h[b * 16 + k] - h[b * 16]));
+            if (d.empty()) continue;
+            std::sort(d.begin(), d.end());
+            fprintf(stderr, "  %-16s %8lld %8lld\n", names[k], d[d.size() / 2], d.back());
+        }
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int b = 0; b < nb; ++b) { if (h[b * 16] && h[b * 16] < lo) lo = h[b * 16]; if (h[b * 16 + 7] > hi) hi = h[b * 16 + 7]; }
+        fprintf(stderr, "  first entry -> last drained: %llu cycles; entry spread: ", hi - lo);
+        unsigned long long emax = 0; for (int b = 0; b < nb; ++b) if (h[b * 16] > emax) emax = h[b * 16];
+        fprintf(stderr, "%llu cycles\n", emax - lo);
+    } };
+#endif
     if constexpr (EXP) {
         if (conv_ep_mode(q) != 1) return hipErrorInvalidValue;
-        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg);
+        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg);
         return hipGetLastError();
     } else {
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 3, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 6, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 7, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, AHEAD, 8, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 3, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 6, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 7, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 8, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
         default: return hipErrorInvalidValue;
     }
+#ifdef PWS_STAMPS
+    if (++nlaunch == 30) { char tag[64]; snprintf(tag, sizeof tag, "<%d,%d> NS %d mode %d", BM, BN, NS, conv_ep_mode(q)); Dump::run((int)grid.x, tag); }
+#endif
     return hipGetLastError();
     }
 }
@@ -1548,32 +1584,31 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         }
         case 1:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 4, 1, 8, false, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<256, 128, 352, 4, 3, 8, false, true>(p, g, stream);
-                return launch_pws<256, 128, 352, 4, 2, 8, false>(p, g, stream);
+                if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 3, 8, false, true>(p, g, stream);
+                return launch_pws<256, 128, 352, 4, 8, false>(p, g, stream);
             }
             return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
         // four ring stages (the loaders three weight tiles ahead): same-box A/B against 3 / 5 stages in
         // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
         case 2:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<128, 128, 288, 5, 3, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<128, 128, 288, 4, 2, 4, true, true>(p, g, stream);
-                return launch_pws<128, 128, 288, 5, 2, 4, true>(p, g, stream);
+                if (pws_variant(p) == 1) return launch_pws<128, 128, 288, 4, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<128, 128, 288, 3, 4, true, true>(p, g, stream);
+                return launch_pws<128, 128, 288, 5, 4, true>(p, g, stream);
             }
             return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
         case 3:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<128, 64, 288, 8, 4, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<128, 64, 288, 5, 3, 4, true, true>(p, g, stream);
-                return launch_pws<128, 64, 288, 6, 3, 4, true>(p, g, stream);
+                if (pws_variant(p) == 1) return launch_pws<128, 64, 288, 4, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<128, 64, 288, 5, 4, true, true>(p, g, stream);
+                return launch_pws<128, 64, 288, 7, 4, true>(p, g, stream);
             }
             return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
         case 6:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 3, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 5, 2, 4, true, true>(p, g, stream);
-                return launch_pws<256, 64, 416, 6, 3, 4, true>(p, g, stream);
+                if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 4, true, true>(p, g, stream);
+                if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 3, 4, true, true>(p, g, stream);
+                return launch_pws<256, 64, 416, 4, 4, true>(p, g, stream);
             }
             return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }

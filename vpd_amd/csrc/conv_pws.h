@@ -9,32 +9,30 @@
 //   * persistent blocks: grid = (pixel-tile lanes) x (channel tiles), at most one block per CU; a block keeps its
 //     channel tile and walks pixel tiles, so the loader stream simply CONTINUES into the next tile's halo and weights
 //     while the MFMA waves run the epilogue, and the per-channel statistics are flushed once per block;
-//   * no barrier in the K loop.  The K-steps of a block are numbered 0, 1, 2 ... across its tiles; step i lives in ring
-//     stage i % NS.  Every loader wave keeps ONE word READY[l] = number of steps whose bytes it has landed, every MFMA
-//     wave ONE word DONE[w] = number of steps whose fragments it holds in registers (plain LDS stores of growing
-//     values; MI355X_MICROARCH.md, price list row "ring-gemm").  A consumer may read step s when min READY > s, a
-//     loader may refill the stage of step i when min DONE > i - NS.  Both sides CACHE the last minimum they saw, so a
-//     wave that is behind never polls: it reads the flags again only when its cached value no longer covers the step;
-//   * a loader that finds its stage still busy first drains its own transfers (vmcnt 0) and publishes everything it
-//     has issued, then spins; a loader that is not blocked publishes behind a counted vmcnt wait that leaves AHEAD
-//     bundles in flight;
-//   * the MFMA waves run a two-set fragment pipeline ACROSS K-steps: while the MFMAs of half-step h issue, the
-//     ds_read_b128 of half-step h + 1 are in flight (PIPE);
-//   * the halo of the next 64-channel chunk (or of the next tile's first chunk) rides in the weight bundles of taps
-//     NS - 1 .. 8 of the current chunk: the ring's own DONE wait then also proves that the halo buffer it overwrites is
-//     no longer read (its last reader is at or before the step whose stage the bundle re-fills), and in-order vmcnt
-//     retirement proves that it has landed before the first step that reads it is published.  The loader loop is
-//     unrolled over the nine taps, so every bundle's size is a compile-time constant and no filler transfer is needed:
-//     the LDS-DMA path of a CU (~65 GB/s out of L2) is the scarcest resource of these kernels.
-// Every spin is bounded; a time-out is counted in ConvParams::err (sticky, read by vpd_plan_sync_errors) and the wave
-// free-runs to the end: wrong numbers that the host sees, never a hung GPU.
+//   * ONE workgroup barrier per K-step is kept -- measured (tools/probe/flag_probe.hip, profiles/r03_flag_probe.txt): an
+//     s_barrier costs ~33 cycles, one LDS flag hop (store -> seen by a spinning wave) ~210, so the point-to-point flag
+//     ring this kernel was first built with (READY / DONE words per wave, profiles/r03_pws_flag_variant.txt) lost to the
+//     barrier it replaced.  What the barrier guarantees is moved instead: the K-steps of a block are numbered
+//     0, 1, 2 ... across its tiles, step i lives in ring stage i % NS, NS = A + 2; barrier READY_s means "steps s AND
+//     s + 1 have landed, and every wave has finished reading step s - 1".  Behind it the loaders issue the bundle of
+//     step s + 1 + A into the stage of step s - 1; in front of the next one they wait with a counted vmcnt that leaves
+//     the A - 1 youngest bundles in flight;
+//   * because step s + 1 is known to be there, the MFMA waves run a two-set fragment pipeline ACROSS the barrier: while
+//     the MFMAs of half-step h issue, the ds_read_b128 of half-step h + 1 are in flight (PIPE) -- in conv3x3_ws_kernel
+//     every group of reads sits exposed in front of its MFMAs, twice per K-step, on all four waves at once;
+//   * the loaders sit at READY of the next tile's first step while the MFMA waves run the epilogue, with that tile's
+//     first A + 1 weight bundles and its halo already on their way;
+//   * the halo of the next 64-channel chunk (or of the next tile's first chunk) rides in the weight bundles issued
+//     behind READY of taps 0 .. 8 - A of the current chunk: after READY of tap 0 nobody reads the buffer it overwrites
+//     (the previous chunk's last fragments were read before that barrier), and the bundle issued behind tap 8 - A has
+//     landed at READY of tap 8, the first step whose pipeline reads the new chunk.  The loader loop is unrolled over the
+//     nine taps, so every bundle's size is a compile-time constant and no filler transfer is needed: the LDS-DMA path
+//     of a CU (~65 GB/s out of L2) is the scarcest resource of these kernels.
 #pragma once
 #include <type_traits>
 
 #include "common.h"
 #include "conv_epilogue.h"
-
-#define PWS_SPIN_LIMIT (1 << 22)
 
 struct PwsGrid {
     int lanes;      // pixel-tile lanes: a block takes pixel tiles lane, lane + lanes, ...
@@ -43,71 +41,45 @@ struct PwsGrid {
     int xcd;        // 1: blocks b, b + 8, ... (one XCD under round-robin placement) take the channel tiles of ONE lane group
 };
 
+// -DPWS_STAMPS (diagnostic builds only; tools/probe): ConvParams::err points at 16 x u64 per block; MFMA wave 0 stamps
+// slots 0..7, loader wave 0 slots 8..15 with s_memtime at the points named at the call sites
+#ifdef PWS_STAMPS
+#define PWS_STAMP(slot) do { if (p.err && lane == 0 && (wave == 0 || wave == NMW)) \
+    reinterpret_cast<unsigned long long*>(p.err)[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PWS_STAMP(slot) do { } while (0)
+#endif
+
 template <int N>
 static __device__ __forceinline__ void pws_vmwait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 // LDS-DMA, 16 bytes per lane, as assembly: opaque to hipcc's wait-count pass, which would otherwise drain every
-// outstanding transfer in front of the loader's next LDS access (its flag polls)
+// outstanding transfer in front of a wave's next LDS access
 static __device__ __forceinline__ void pws_dma16(const void* gsrc, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
-// Flag words: plain LDS stores by the owning wave (all lanes store the same value: one LDS write, no atomics, no EXEC
-// games), 16-byte LDS loads by the waiting waves.  The LDS address space is explicit: through a generic pointer hipcc
-// turns a volatile access into flat_load ... sc0 sc1 + s_waitcnt vmcnt(0).
-typedef volatile unsigned __attribute__((address_space(3)))* pws_flag_t;
-typedef const volatile u32x4 __attribute__((address_space(3)))* pws_flag4_t;
-static __device__ __forceinline__ void pws_store(unsigned* w, unsigned v) { *(pws_flag_t)w = v; }
-static __device__ __forceinline__ unsigned pws_min4(const u32x4& a) {
-    const unsigned m = a.x < a.y ? a.x : a.y;
-    const unsigned n = a.z < a.w ? a.z : a.w;
-    return m < n ? m : n;
-}
 // s_waitcnt lgkmcnt(0) as the BUILTIN (vmcnt / expcnt fields at their maxima): hipcc's wait-count pass sees it and does
-// not wait again for the fragments it covers (behind an asm wait it put lgkmcnt(4..1) in front of the next MFMAs, i.e.
-// it waited for half of the reads issued a moment ago)
+// not wait again for the fragments it covers
 static __device__ __forceinline__ void pws_lgkm0() {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     asm volatile("" ::: "memory");
 }
-// smallest of the NW words at w (NW = 4 or 8), wave-uniform
-template <int NW>
-static __device__ __forceinline__ unsigned pws_min_words(const unsigned* w) {
-    const u32x4 a = *(pws_flag4_t)w;
-    unsigned m = pws_min4(a);
-    if constexpr (NW == 8) {
-        const u32x4 b = *(pws_flag4_t)(w + 4);
-        const unsigned k = pws_min4(b);
-        m = m < k ? m : k;
-    }
-    return __builtin_amdgcn_readfirstlane(m);
-}
-// spin until the minimum reaches `target`; returns the minimum seen (on time-out: `dead` is set and target is returned)
-template <int NW>
-static __device__ __forceinline__ unsigned pws_spin(const unsigned* w, unsigned target, bool& dead, unsigned* err) {
-    if (dead) return target;
-    for (int spin = 0; spin < PWS_SPIN_LIMIT; ++spin) {
-        const unsigned m = pws_min_words<NW>(w);
-        if (m >= target) return m;
-    }
-    dead = true;
-    if ((threadIdx.x & 63) == 0 && err) atomicAdd(err, 1u);
-    return target;
-}
 
-// DMA instructions per loader wave in the bundle of tap t (weights of one K-step + this tap's share of the next chunk's halo),
-// and the vmcnt immediates that follow from them
-template <int W_PER, int HPASS, int HOFF, int HT, int AHEAD>
+// DMA instructions per loader wave in the bundle issued behind READY of tap t (the weights of step s + 1 + A and this
+// tap's share of the next chunk's halo), and the vmcnt immediates that follow from them
+template <int W_PER, int HPASS, int HT, int A>
 struct PwsSched {
-    static constexpr int cnt(int u) { return HPASS / HT + (u < HPASS % HT ? 1 : 0); }              // u-th halo-carrying bundle
-    static constexpr int first(int u) { int k = 0; for (int v = 0; v < u; ++v) k += cnt(v); return k; }   // its first slice
-    static constexpr int per(int t) { return W_PER + (t >= HOFF ? cnt(t - HOFF) : 0); }
-    // outstanding instructions allowed after the bundle of tap t when everything up to the bundle `ahead` steps back must have landed
-    static constexpr int inflight(int t, int ahead) { int n = 0; for (int k = 0; k < ahead; ++k) n += per(((t - k) % 9 + 9) % 9); return n; }
-    static constexpr int max_inflight() { int m = 0; for (int t = 0; t < 9; ++t) m = inflight(t, AHEAD) > m ? inflight(t, AHEAD) : m; return m; }
+    static constexpr int cnt(int t) { return t < HT ? HPASS / HT + (t < HPASS % HT ? 1 : 0) : 0; }   // halo slices behind READY of tap t
+    static constexpr int first(int t) { int k = 0; for (int v = 0; v < t; ++v) k += cnt(v); return k; }
+    static constexpr int per(int t) { return W_PER + cnt(t); }
+    // in front of READY of tap t the weights of step s + 1 must have landed: they were issued behind READY of step s - A, so
+    // the bundles issued behind the READYs of steps s - A + 1 .. s - 1 may stay in flight
+    static constexpr int inflight(int t) { int n = 0; for (int k = 1; k < A; ++k) n += per(((t - k) % 9 + 9) % 9); return n; }
+    static constexpr int max_inflight() { int m = 0; for (int t = 0; t < 9; ++t) m = inflight(t) > m ? inflight(t) : m; return m; }
 };
 
-template <int BM, int BN, int HROWS, int NS, int AHEAD, int EPM, int NMW, bool PIPE>
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
 __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_kernel(const ConvParams p, const HaloGeom g,
                                                                                    const PwsGrid sg) {
     constexpr int WN = BN / 64;
@@ -118,25 +90,18 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     constexpr int HBUF = HROWS * 64;
     constexpr int W_PER = BN / 32;                   // weight-tile DMA instructions per loader wave and step
     constexpr int HPASS = HROWS / 32;                // halo DMA instructions per loader wave and chunk
-    // halo slices of the NEXT chunk ride in the bundles of taps HOFF .. 8 of the current one (HT of them), spread evenly:
-    // PwsSched<...>::cnt(u) DMA instructions in the u-th of those bundles, none elsewhere -- every bundle's size is a
-    // compile-time constant of its tap, so the counted vmcnt waits need no filler transfers
-    constexpr int HOFF = NS - 1;
-    constexpr int HT = 9 - HOFF;
-    using SC = PwsSched<W_PER, HPASS, HOFF, HT, AHEAD>;
-    static_assert(HROWS % 32 == 0 && HT >= 1 && NS >= AHEAD + 1 && AHEAD >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
+    constexpr int A = NS - 2;                        // weight bundles beyond the two readable steps
+    constexpr int HT = 9 - A;                        // READYs of a chunk behind which the next chunk's halo slices may be issued
+    using SC = PwsSched<W_PER, HPASS, HT, A>;
+    static_assert(HROWS % 32 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
     static_assert(EPM == 0 || EPM == 1 || EPM == 2 || EPM == 3 || EPM == 6 || EPM == 7 || EPM == 8, "epilogue mode");
-    static_assert(NMW == 4 || NMW == 8, "flag words");
     constexpr unsigned OFF_W = 2u * HBUF * 2u;                       // bytes
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
-    constexpr unsigned OFF_FLAG = OFF_DUMP + 1024u;
-    constexpr unsigned OFF_RED = OFF_FLAG + 256u;
+    constexpr unsigned OFF_RED = OFF_DUMP + 1024u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                    // [2][HBUF]
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem + OFF_W);            // [NS][WSTAGE]
-    unsigned* ready = reinterpret_cast<unsigned*>(smem + OFF_FLAG);  // [4]: steps landed by loader wave l
-    unsigned* done = ready + 16;                                     // [NMW]: steps read by MFMA wave w (own 64-byte line)
     unsigned char* red = smem + OFF_RED;
 
     const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
@@ -148,6 +113,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     const int nchunks = Ci >> 6;
     const int nsteps = nchunks * 9;
 
+    PWS_STAMP(wave == 0 ? 0 : 8);                                    // kernel entry
     // block -> (lane group, channel tile)
     int lane0, nt;
     {
@@ -158,8 +124,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     const int n0 = nt * BN;
     const int njobs = lane0 < sg.MT ? (sg.MT - lane0 + sg.lanes - 1) / sg.lanes : 0;
     if (njobs == 0) return;                                          // (whole block, before any barrier)
-    if (tid < 64) ready[tid] = 0u;
-    __syncthreads();
+    const int total = njobs * nsteps;                                // K-steps of this block = READY barriers
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;            // LDS byte address of the dynamic segment
 
     if (wave >= NMW) {
@@ -167,7 +132,6 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const int lw = wave - NMW;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
-        bool dead = false;
         auto tile_gp0 = [&](int mtile) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
             int prow0;
@@ -189,67 +153,64 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             const int n = (lw + 4 * i) * 8 + lrow;
             wrow[i] = (n0 + n) * Ci + ((piece ^ (n & 7)) << 3);
         }
-        // first tile, first chunk: the whole halo ahead of bundle 0 (retired in order with it)
+        auto issue_w = [&](int tap, int cc, unsigned stg) __attribute__((always_inline)) {
+            const int wsl = p.taps.w0 + (tap / 3) * p.taps.wrs + (tap % 3) * p.taps.wcs;
+            const bf16_t* wbp = p.w + (size_t)wsl * p.Co * Ci + cc * 64;
+#pragma unroll
+            for (int k = 0; k < W_PER; ++k)
+                pws_dma16(wbp + wrow[k], lds0 + OFF_W + stg * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
+        };
+        // prologue: the first tile's first halo, then the weights of steps 0 .. A (retired in this order)
         {
             const int gp0 = tile_gp0(lane0);
 #pragma unroll
             for (int k = 0; k < HPASS; ++k) halo_instr(gp0, 0, 0, k);
         }
-        unsigned st_i = 0;                                           // ring stage of the bundle being issued (i % NS)
-        unsigned i = 0;                                              // bundle = K-step index in the block's sequence
-        unsigned kd = 0;                                             // cached min DONE
-        unsigned pub = 0;                                            // steps this wave has published
+        PWS_STAMP(9);                                                // first halo issued
+        int w_tap = 0, w_cc = 0;                                     // tap / chunk-in-tile of the next weight bundle
+        unsigned w_st = 0;                                           // ... and its ring stage
+        int w_step = 0;                                              // ... and its step index
+#pragma unroll
+        for (int k = 0; k <= A; ++k) {
+            if (w_step < total && !VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
+            ++w_step;
+            if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
+            if (++w_st == NS) w_st = 0;
+        }
         const int total_chunks = njobs * nchunks;
-        int w_cc = 0;                                                // chunk of the weight stream inside its tile
-        int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0; // the chunk whose halo rides in this chunk's bundles
+        int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0; // the chunk whose halo is issued during this chunk
         for (int c = 0; c < total_chunks; ++c) {
             const bool has_next = c + 1 < total_chunks;
             const int h_gp0 = has_next ? tile_gp0(lane0 + h_job * sg.lanes) : 0;
             const int h_buf = (c + 1) & 1;
-            // one chunk = nine bundles, unrolled: tap t's weights and its fixed share of the next chunk's halo
-            auto bundle = [&](auto tc) __attribute__((always_inline)) {
+            // one chunk = nine READY barriers, unrolled: every bundle's size is a constant of its tap
+            auto step = [&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
-                // the stage last held step i - NS: every MFMA wave must have read it (DONE > i - NS)
-                if (i >= (unsigned)NS && kd < i - NS + 1u) {
-                    kd = pws_min_words<NMW>(done);
-                    if (kd < i - NS + 1u) {
-                        // blocked: nothing to issue, so land and publish everything issued so far, then wait
-                        pws_vmwait<0>();
-                        if (pub < i) { pub = i; pws_store(ready + lw, pub); }
-                        kd = pws_spin<NMW>(done, i - NS + 1u, dead, p.err);
+                // steps s and s + 1 have landed; on the block's last chunk (bundles shrink: no next halo, no more weights) everything
+                if (has_next) pws_vmwait<SC::inflight(t)>();
+                else pws_vmwait<0>();
+                if (c == 0 && t == 0) PWS_STAMP(10);                 // first two steps landed
+                if (!VPD_ABL(p, 16) || (c == 0 && t == 0)) __builtin_amdgcn_s_barrier();      // READY_s (ablation 16: one tile per block only)
+                if (w_step < total) {
+                    if (!VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
+                    ++w_step;
+                    if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
+                    if (++w_st == NS) w_st = 0;
+                }
+                if constexpr (SC::cnt(t) > 0) {
+                    if (has_next && !VPD_ABL(p, 4)) {
+#pragma unroll
+                        for (int u = 0; u < SC::cnt(t); ++u) halo_instr(h_gp0, h_cc, h_buf, SC::first(t) + u);
                     }
                 }
-                asm volatile("" ::: "memory");
-                if (!VPD_ABL(p, 1)) {
-                    const int wsl = p.taps.w0 + (t / 3) * p.taps.wrs + (t % 3) * p.taps.wcs;
-                    const bf16_t* wbp = p.w + (size_t)wsl * p.Co * Ci + w_cc * 64;
-#pragma unroll
-                    for (int k = 0; k < W_PER; ++k)
-                        pws_dma16(wbp + wrow[k], lds0 + OFF_W + st_i * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
-                }
-                if constexpr (t >= HOFF) {
-                    if (!VPD_ABL(p, 4)) {
-#pragma unroll
-                        for (int u = 0; u < SC::cnt(t - HOFF); ++u) {
-                            if (has_next) halo_instr(h_gp0, h_cc, h_buf, SC::first(t - HOFF) + u);
-                            else pws_dma16(p.w, lds0 + OFF_DUMP);    // last chunk of the block only: keeps the counts
-                        }
-                    }
-                }
-                // not blocked: everything up to the bundle AHEAD steps back has landed
-                pws_vmwait<SC::inflight(t, AHEAD)>();
-                if (i >= (unsigned)AHEAD && pub < i + 1u - AHEAD) { pub = i + 1u - AHEAD; pws_store(ready + lw, pub); }
-                ++i;
-                if (++st_i == NS) st_i = 0;
             };
-            bundle(std::integral_constant<int, 0>{}); bundle(std::integral_constant<int, 1>{}); bundle(std::integral_constant<int, 2>{});
-            bundle(std::integral_constant<int, 3>{}); bundle(std::integral_constant<int, 4>{}); bundle(std::integral_constant<int, 5>{});
-            bundle(std::integral_constant<int, 6>{}); bundle(std::integral_constant<int, 7>{}); bundle(std::integral_constant<int, 8>{});
-            if (++w_cc == nchunks) w_cc = 0;
+            step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
             if (++h_cc == nchunks) { h_cc = 0; ++h_job; }
         }
         pws_vmwait<0>();
-        pws_store(ready + lw, i);                                    // everything has landed
+        PWS_STAMP(11);                                               // loader done
         __builtin_amdgcn_s_barrier();                                // END
         if (EPM == 1 || EPM == 6 || EPM == 7 || EPM == 8) __builtin_amdgcn_s_barrier();      // inside conv_stats_flush
         if (EPM == 8) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }         // second flush
@@ -270,12 +231,12 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
         hbase[b] = hrow * Wp + xx;
     }
-    // weight fragment a of K-half kk: element offset wa[kk] + a * 16 * 64 inside a stage (row wn*64 + a*16 + fr: r & 7 == fr & 7)
-    int wa[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    // weight fragment a of K-half kk: LDS byte offset wa0 (kk = 0) + a * 2048 inside a stage (row wn*64 + a*16 + fr:
+    // r & 7 == fr & 7); K-half 1 is the same address with bit 6 flipped (the 16-byte piece index kk*4 + fq flips bit 2)
+    unsigned wa0;
+    {
         const int r = wn * 64 + fr;
-        wa[kk] = r * 64 + (((kk * 4 + fq) ^ (r & 7)) << 3);
+        wa0 = (unsigned)(r * 128 + ((fq ^ (r & 7)) << 4));
     }
     float st1[NI][4], st2[NI][4];
 #pragma unroll
@@ -291,10 +252,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             for (int j = 0; j < 4; ++j) pr.s3[a][j] = 0.f;
     }
 
-    bool dead = false;
-    unsigned stage = 0;                                              // ring stage of the step being consumed (sgl % NS)
-    unsigned sgl = 0;                                                // its index in the block's step sequence
-    unsigned kr = 0;                                                 // cached min READY
+    unsigned stage = 0;                                              // ring stage of the step being consumed
     int gch = 0;                                                     // global chunk index: halo buffer gch & 1
     for (int job = 0; job < njobs; ++job) {
         const int mtile = lane0 + job * sg.lanes;
@@ -304,18 +262,23 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x8 af0[NI], bf0[MI], af1[NI], bf1[MI];
-        auto load_a = [&](bf16x8 (&af)[NI], unsigned stg, int kk) __attribute__((always_inline)) {
-            const bf16_t* cW = sW + stg * WSTAGE + wa[kk];
+        typedef const bf16x8 __attribute__((address_space(3)))* frag_t;
+        // fragments by LDS byte address.  A: `wst` = the stage's base + wa0 (^ 64 for K-half 1).  B: halo pixel r of K-half 0 is at
+        // hb + r * 128 + (((r & 7) ^ fq) << 4) = hb + ((r * 8 + ((r & 7) ^ fq)) << 4), K-half 1 at that address ^ 64 (buffers are
+        // 128-byte aligned): three VALU operations per fragment and step on top of the tap shift, one for the second half
+        auto load_a = [&](bf16x8 (&af)[NI], unsigned addr) __attribute__((always_inline)) {
 #pragma unroll
-            for (int a = 0; a < NI; ++a) af[a] = *reinterpret_cast<const bf16x8*>(cW + a * 16 * 64);
+            for (int a = 0; a < NI; ++a) af[a] = *(frag_t)(size_t)(addr + a * 2048u);
         };
-        // pixel fragments of one K-half: halo rows hbase[b] + toff (toff: the tap's shift in halo pixels, wave-uniform)
-        auto load_b = [&](bf16x8 (&bfm)[MI], const bf16_t* cH, int toff, int kk) __attribute__((always_inline)) {
-            const int chunk = kk * 4 + fq;
+        auto load_b = [&](bf16x8 (&bfm)[MI], const unsigned (&addr)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < MI; ++b) bfm[b] = *(frag_t)(size_t)addr[b];
+        };
+        auto b_addr = [&](unsigned (&addr)[MI], unsigned hb, int toff) __attribute__((always_inline)) {
 #pragma unroll
             for (int b = 0; b < MI; ++b) {
-                const int r = hbase[b] + toff;
-                bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+                const unsigned r = (unsigned)(hbase[b] + toff);
+                addr[b] = hb + ((r * 8u + ((r & 7u) ^ (unsigned)fq)) << 4);
             }
         };
         auto mfma_set = [&](bf16x8 (&af)[NI], bf16x8 (&bfm)[MI]) __attribute__((always_inline)) {
@@ -325,65 +288,77 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
                 for (int b = 0; b < MI; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
         };
+        // Interleave of one half-step region: its MFMAs (NI * MI) with the address arithmetic and the NI + MI fragment reads of
+        // the NEXT half-step, which the source places in front of them.  Left to itself hipcc issues address math, reads and
+        // MFMAs as three blocks (and sched_barrier pins exactly that): ~200 cycles of VALU + LDS issue exposed per half-step.
+        auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NI + MI; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);      // up to three VALU / SALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NI * MI - (NI + MI), 0);
+        };
 
-        // the tile's first step: an exposed wait (everything the loaders could run ahead is already there)
-        if (kr < sgl + 1u) kr = pws_spin<4>(ready, sgl + 1u, dead, p.err);
-        asm volatile("" ::: "memory");
-        const bf16_t* cH = sH + (gch & 1) * HBUF;
+        const unsigned hb0 = lds0, hb1 = lds0 + HBUF * 2u;           // the two halo buffers
+        unsigned hb = (gch & 1) ? hb1 : hb0;
         // tap walk (rolled: unrolled, hipcc hoists the fragment addresses of all nine taps out of the loops and spills)
         const int tstep_c = p.taps.dxs, tstep_r = p.taps.dys * Wp - 2 * p.taps.dxs;
         const int toff0 = p.taps.dy0 * Wp + p.taps.dx0;
         int tap = 0, tcol = 0, toff = toff0;
+        unsigned ba[MI];                                             // K-half 0 addresses of the current step's pixel fragments
+        // the tile's first READY; its first fragments are the one exposed LDS round trip of the tile
+        if (job == 0) PWS_STAMP(1);                                  // set-up done, waiting for the first bytes
+        __builtin_amdgcn_s_barrier();
+        if (job == 0) PWS_STAMP(2);                                  // first READY
         if constexpr (PIPE) {
-            load_a(af0, stage, 0); load_b(bf0, cH, toff, 0);
-            if (VPD_ABL(p, 2)) { load_a(af1, stage, 1); load_b(bf1, cH, toff, 1); }      // (defined values for the epilogue)
+            b_addr(ba, hb, toff);
+            load_a(af0, lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0); load_b(bf0, ba);
         }
 #pragma nounroll
         for (int s = 0; s < nsteps; ++s) {
-            const bool last = s + 1 == nsteps;
             const unsigned nstage = stage + 1 == NS ? 0u : stage + 1;
             // the next step's tap: shift and halo buffer
             const bool wrap = tap == 8;
             const int ntoff = wrap ? toff0 : toff + (tcol == 2 ? tstep_r : tstep_c);
-            const bf16_t* nH = wrap ? sH + ((gch + 1) & 1) * HBUF : cH;
+            const unsigned nhb = wrap ? (hb == hb0 ? hb1 : hb0) : hb;
+            if (s != 0 && !VPD_ABL(p, 16)) __builtin_amdgcn_s_barrier(); // READY_s: this step and the next have landed
             if constexpr (PIPE) {
-                if (!VPD_ABL(p, 2)) { load_a(af1, stage, 1); load_b(bf1, cH, toff, 1); }
-                // the next step's bytes: only when the cached count does not cover them is READY read again -- speculatively,
-                // in front of the MFMAs that hide the round trip, and checked behind them
-                const bool need = !last && kr < sgl + 2u;
-                u32x4 fv = {0u, 0u, 0u, 0u};
-                if (need) fv = *(pws_flag4_t)ready;
-                __builtin_amdgcn_sched_barrier(0);
-                if (!VPD_ABL(p, 2)) mfma_set(af0, bf0);
-                __builtin_amdgcn_sched_barrier(0);
-                pws_lgkm0();                                            // every fragment of this stage is in registers
-                pws_store(done + wave, sgl + 1u);
-                if (!last) {
-                    if (need) {
-                        kr = __builtin_amdgcn_readfirstlane(pws_min4(fv));
-                        if (kr < sgl + 2u) kr = pws_spin<4>(ready, sgl + 2u, dead, p.err);
-                    }
-                    asm volatile("" ::: "memory");
-                    if (!VPD_ABL(p, 2)) { load_a(af0, nstage, 0); load_b(bf0, nH, ntoff, 0); }
+                if (!VPD_ABL(p, 2)) {
+                    // region 1: K-half 1 of this step is requested while K-half 0 multiplies
+                    unsigned ba1[MI];
+#pragma unroll
+                    for (int b = 0; b < MI; ++b) ba1[b] = ba[b] ^ 64u;
+                    if (!VPD_ABL(p, 32)) { load_a(af1, (lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0) ^ 64u); load_b(bf1, ba1); }
+                    if (!VPD_ABL(p, 64)) mfma_set(af0, bf0);
+                    interleave();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // region 2: K-half 0 of the NEXT step (landed: READY_s covers it; behind a tile's last step these are the next
+                    // tile's first fragments or stale bytes, never used) while K-half 1 multiplies
+                    b_addr(ba, nhb, ntoff);
+                    if (!VPD_ABL(p, 32)) { load_a(af0, lds0 + OFF_W + nstage * (WSTAGE * 2u) + wa0); load_b(bf0, ba); }
+                    if (!VPD_ABL(p, 64)) mfma_set(af1, bf1);
+                    interleave();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!VPD_ABL(p, 2)) mfma_set(af1, bf1);
-                __builtin_amdgcn_sched_barrier(0);
             } else {
-                if (kr < sgl + 1u) kr = pws_spin<4>(ready, sgl + 1u, dead, p.err);
-                asm volatile("" ::: "memory");
-                load_a(af0, stage, 0); load_b(bf0, cH, toff, 0);
-                load_a(af1, stage, 1); load_b(bf1, cH, toff, 1);
+                b_addr(ba, hb, toff);
+                unsigned ba1[MI];
+#pragma unroll
+                for (int b = 0; b < MI; ++b) ba1[b] = ba[b] ^ 64u;
+                const unsigned wst = lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0;
+                load_a(af0, wst); load_b(bf0, ba);
+                load_a(af1, wst ^ 64u); load_b(bf1, ba1);
                 mfma_set(af0, bf0);
-                pws_lgkm0();
-                pws_store(done + wave, sgl + 1u);
                 mfma_set(af1, bf1);
             }
-            stage = nstage; ++sgl;
-            toff = ntoff; cH = nH;
+            stage = nstage;
+            toff = ntoff; hb = nhb;
             tcol = tcol == 2 ? 0 : tcol + 1;
             if (wrap) { tap = 0; ++gch; } else ++tap;
         }
+        if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
         if (VPD_ABL(p, 8)) continue;
         BstFrag<NI, VPD_BST_MB(MI)> bst;
@@ -392,7 +367,9 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
         else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+        if (job == 0) PWS_STAMP(4);                                  // first tile's epilogue issued
     }
+    PWS_STAMP(5);                                                    // all tiles done
     __builtin_amdgcn_s_barrier();                                    // END
     if constexpr (EPM == 1 || BST) {
         conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, n0, red);
@@ -401,4 +378,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             conv_stats_flush<BM, BN, WM, WN>(p, st1, pr.s3, blockIdx.x, n0, red, p.stats2);
         }
     }
+    PWS_STAMP(6);                                                    // statistics flushed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PWS_STAMP(7);                                                    // stores drained (diagnostic wait)
 }
