@@ -67,6 +67,13 @@ static __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Exact m / d for 0 <= m < 2^21 and 1 <= d <= 2^21 by one multiplication with the float reciprocal (rcp = 1.0f / d, IEEE):
+// (m + 0.5) / d lies at least 0.5 / d away from an integer and the two roundings move it by < q * 1.2e-7.  hipcc's integer
+// division is ~45 VALU instructions; a tile's pixel -> (image, row, column) split used to cost the conv epilogues ~1,600
+// cycles per tile and the persistent kernels ~2,000 cycles of set-up (profiles/r03_pws_stamps_timeline.txt).
+#define VPD_FDIV_MAX (1 << 21)
+static __device__ __forceinline__ int vpd_fdiv(int m, float rcp) { return (int)(((float)m + 0.5f) * rcp); }
+
 // Activation tensor descriptor: bf16 NHWC with a zero border of `pad` pixels.
 // Element offset of interior pixel (b, y, x): ((b*Hp + y + pad)*Wp + x + pad)*C.
 struct TensorDesc {

@@ -19,6 +19,33 @@ static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p)
     return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
 }
 
+// Output pixel m of the sub-grid -> element offset of its first channel in y.  Dense outputs (train-mode z, data gradients:
+// y is [M][yC] in sub-grid order) need no split at all; otherwise image / row / column by float-reciprocal division.
+struct PixSplit {
+    float rHW, rW; int HW, W; bool dense, fast;
+};
+static __device__ __forceinline__ PixSplit pix_split_init(const ConvParams& p, const ConvGeo& geo) {
+    PixSplit s;
+    s.HW = geo.Hs * geo.Ws; s.W = geo.Ws;
+    s.rHW = 1.0f / (float)s.HW; s.rW = 1.0f / (float)s.W;
+    s.dense = p.ypad == 0 && p.osub == 1 && geo.oph == 0 && geo.opw == 0 && p.yWp == geo.Ws && p.yHp == geo.Hs;
+    s.fast = geo.M < VPD_FDIV_MAX;
+    return s;
+}
+static __device__ __forceinline__ void pix_split(const PixSplit& s, int mc, int& bi, int& yy, int& xx) {
+    if (s.fast) {
+        bi = vpd_fdiv(mc, s.rHW);
+        const int r = mc - bi * s.HW;
+        yy = vpd_fdiv(r, s.rW);
+        xx = r - yy * s.W;
+    } else {
+        bi = mc / s.HW;
+        const int r = mc - bi * s.HW;
+        yy = r / s.W;
+        xx = r - yy * s.W;
+    }
+}
+
 // EPM 6 / 7: this lane's z fragments and ReLU bits of the consuming BatchNorm (ConvParams::bst_z / bst_mask), fetched ahead
 // of their use -- all loads of a tile in flight together (inside the epilogue the stores to y keep hipcc from hoisting
 // them), and in the persistent kernel before the tile's MFMA loop, which hides their latency altogether.
@@ -69,17 +96,19 @@ static __device__ __forceinline__ void conv_bst_prefetch(const ConvParams& p, in
     const int wave = (threadIdx.x >> 6) - wave_base;
     const int wm = wave % WM, wn = wave / WM;
     const int fr = lane & 15, fq = lane >> 4;
-    const int HW = geo.Hs * geo.Ws;
+    const PixSplit ps = pix_split_init(p, geo);
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = mtile * BM + wm * WTM + (b0 + b) * 16 + fr;
         const int mc = m < geo.M ? m : geo.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / geo.Ws;
-        const int xx = r - yy * geo.Ws;
         // y is dense ([pixel][yC], ypad 0): yoff = pixel index * yC, which also indexes z and (in bits) the mask
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+        size_t yoff;
+        if (ps.dense) yoff = (size_t)mc * p.yC;
+        else {
+            int bi, yy, xx;
+            pix_split(ps, mc, bi, yy, xx);
+            yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+        }
         const unsigned char* mp = p.bst_mask + ((yoff + n0 + wn * WTN) >> 3);
         if (WTN == 64) f.bits[b] = *reinterpret_cast<const unsigned long long*>(mp);
         else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
@@ -104,16 +133,18 @@ static __device__ __forceinline__ void conv_bst2_prefetch(const ConvParams& p, i
     const int wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int fr = lane & 15, fq = lane >> 4;
-    const int HW = geo.Hs * geo.Ws;
+    const PixSplit ps = pix_split_init(p, geo);
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = mtile * BM + wm * WTM + (b0 + b) * 16 + fr;
         const int mc = m < geo.M ? m : geo.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / geo.Ws;
-        const int xx = r - yy * geo.Ws;
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+        size_t yoff;
+        if (ps.dense) yoff = (size_t)mc * p.yC;
+        else {
+            int bi, yy, xx;
+            pix_split(ps, mc, bi, yy, xx);
+            yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
+        }
 #pragma unroll
         for (int a = 0; a < NI; ++a)
             f.z2[a][b] = *reinterpret_cast<const uint2*>(p.bst_z2 + yoff + n0 + wn * WTN + a * 16 + 4 * fq);
@@ -141,7 +172,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
     const int fr = lane & 15;
     const int fq = lane >> 4;
     const int m0 = mtile * BM;
-    const int HW = geo.Hs * geo.Ws;
+    const PixSplit ps = pix_split_init(p, geo);
     const bool do_eval = EPM < 0 ? (p.ep_scale != nullptr) : (EPM == 3);
     const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2 || EPM == 7 || EPM == 8);
     const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
@@ -168,14 +199,14 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
         const int m = m0 + wm * WTM + b * 16 + fr;
         const bool valid = m < geo.M;
         const int mc = valid ? m : geo.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / geo.Ws;
-        const int xx = r - yy * geo.Ws;
-        const size_t yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp +
-                             (xx * p.osub + geo.opw + p.ypad)) * p.yC;
-        size_t roff = 0;
-        if (do_eval && p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+        size_t yoff, roff = 0;
+        if (ps.dense && !(do_eval && p.res)) yoff = (size_t)mc * p.yC;
+        else {
+            int bi, yy, xx;
+            pix_split(ps, mc, bi, yy, xx);
+            yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp + (xx * p.osub + geo.opw + p.ypad)) * p.yC;
+            if (do_eval && p.res) roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+        }
         // accumulate with a ReLU bit map: ONE load per pixel covers this wave's WTN channels (WTN / 8 bytes, 8-byte aligned
         // for WTN = 64; a byte load per 4-channel group doubled the epilogue's memory instructions: measured +79 us per step)
         unsigned long long mbits = 0;

@@ -195,6 +195,8 @@ struct HaloGeom {
     int HR;        // padded rows in the halo
     int NHP;       // halo pixels = HR * (W + 2)
     int total_pix; // N * (H+2) * (W+2): clamp for the last (ragged) tile
+    // conv3x3_pws_kernel only: swizzle key of halo pixel (row hr, column xp of the padded tile) = (xp & kmask) ^ ((hr & rowmask) << kshift)
+    int kmask, kshift, rowmask;
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -1089,6 +1091,19 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 // ---------------------------------------------------------------------------
 // conv3x3_pws_kernel (conv_pws.h): persistent blocks, LDS flag hand-off.  VPD_PWS=0 restores conv3x3_ws_kernel.
 // ---------------------------------------------------------------------------
+// ring depths per tile class (NS = A + 2: two readable steps + A weight bundles in flight); -D overrides for same-box A/B builds
+#ifndef PWS_NS_C1
+#define PWS_NS_C1 4
+#endif
+#ifndef PWS_NS_C2
+#define PWS_NS_C2 5
+#endif
+#ifndef PWS_NS_C3
+#define PWS_NS_C3 7
+#endif
+#ifndef PWS_NS_C6
+#define PWS_NS_C6 5
+#endif
 static int pws_cu_count() {
     static int ncu = 0;
     if (!ncu) {
@@ -1107,7 +1122,8 @@ static int pws_variant(const ConvParams& p) {      // experiments: train-forward
 static bool pws_enabled(const ConvParams& p) {
     static const int on = getenv("VPD_PWS") ? atoi(getenv("VPD_PWS")) : 1;
     const int mode = conv_ep_mode(p);
-    return on && mode != 4 && mode != 5;
+    // (global output rows below 2^21: the kernel's float-reciprocal divisions, vpd_fdiv)
+    return on && mode != 4 && mode != 5 && (long)p.N * p.Hs < VPD_FDIV_MAX;
 }
 // EXP: an experimental variant (VPD_PWS_VAR): only the train-forward epilogue is instantiated
 template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false>
@@ -1460,6 +1476,10 @@ static bool halo_geom(const ConvParams& p, int BM, int hrows_max, HaloGeom* g) {
     g->TR = TR;
     g->NHP = g->HR * (W + 2);
     g->total_pix = p.N * (H + 2) * (W + 2);
+    // a 16-pixel MFMA fragment spans 16 / W image rows.  W >= 8: the column index alone separates its pixels (two rows of 8 use
+    // opposite halves of the eight 16-byte pieces of a bank row); W = 4: two column bits + the row parity
+    if (W >= 8) { g->kmask = 7; g->kshift = 0; g->rowmask = 0; }
+    else { g->kmask = 3; g->kshift = 2; g->rowmask = 1; }
     return g->NHP <= hrows_max;
 }
 
@@ -1583,9 +1603,11 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
             return launch_c64<224>(p, g, stream);
         }
         case 1:
-            if (pws_enabled(p)) {
+            // (eight MFMA waves, no fragment pipeline: two waves per SIMD cover each other's LDS round trips.  With ONE tile per
+            //  block conv3x3_ws_kernel, whose loaders run three bundles ahead instead of two, is 3 % faster: 25.5 vs 26.3 us)
+            if (pws_enabled(p) && (p.M + 255) / 256 > pws_cu_count() / (p.Co / 128)) {
                 if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 3, 8, false, true>(p, g, stream);
-                return launch_pws<256, 128, 352, 4, 8, false>(p, g, stream);
+                return launch_pws<256, 128, 352, PWS_NS_C1, 8, false>(p, g, stream);
             }
             return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
         // four ring stages (the loaders three weight tiles ahead): same-box A/B against 3 / 5 stages in
@@ -1594,21 +1616,21 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
             if (pws_enabled(p)) {
                 if (pws_variant(p) == 1) return launch_pws<128, 128, 288, 4, 4, true, true>(p, g, stream);
                 if (pws_variant(p) == 2) return launch_pws<128, 128, 288, 3, 4, true, true>(p, g, stream);
-                return launch_pws<128, 128, 288, 5, 4, true>(p, g, stream);
+                return launch_pws<128, 128, 288, PWS_NS_C2, 4, true>(p, g, stream);
             }
             return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
         case 3:
             if (pws_enabled(p)) {
                 if (pws_variant(p) == 1) return launch_pws<128, 64, 288, 4, 4, true, true>(p, g, stream);
                 if (pws_variant(p) == 2) return launch_pws<128, 64, 288, 5, 4, true, true>(p, g, stream);
-                return launch_pws<128, 64, 288, 7, 4, true>(p, g, stream);
+                return launch_pws<128, 64, 288, PWS_NS_C3, 4, true>(p, g, stream);
             }
             return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
         case 6:
             if (pws_enabled(p)) {
                 if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 4, true, true>(p, g, stream);
                 if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 3, 4, true, true>(p, g, stream);
-                return launch_pws<256, 64, 416, 4, 4, true>(p, g, stream);
+                return launch_pws<256, 64, 416, PWS_NS_C6, 4, true>(p, g, stream);
             }
             return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }

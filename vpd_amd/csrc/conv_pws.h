@@ -118,11 +118,12 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     int lane0, nt;
     {
         const int b = blockIdx.x;
-        if (sg.xcd) { const int k = b >> 3; nt = k % sg.NT; lane0 = (k / sg.NT) * 8 + (b & 7); }
-        else { nt = b % sg.NT; lane0 = b / sg.NT; }
+        const float rNT = 1.0f / (float)sg.NT;
+        if (sg.xcd) { const int k = b >> 3; const int q = vpd_fdiv(k, rNT); nt = k - q * sg.NT; lane0 = q * 8 + (b & 7); }
+        else { lane0 = vpd_fdiv(b, rNT); nt = b - lane0 * sg.NT; }
     }
     const int n0 = nt * BN;
-    const int njobs = lane0 < sg.MT ? (sg.MT - lane0 + sg.lanes - 1) / sg.lanes : 0;
+    const int njobs = lane0 < sg.MT ? vpd_fdiv(sg.MT - lane0 + sg.lanes - 1, 1.0f / (float)sg.lanes) : 0;
     if (njobs == 0) return;                                          // (whole block, before any barrier)
     const int total = njobs * nsteps;                                // K-steps of this block = READY barriers
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;            // LDS byte address of the dynamic segment
@@ -132,18 +133,24 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const int lw = wave - NMW;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
+        // first padded pixel of a tile's halo (gr0 = its first global output row b * H + y; < 2^21 for every shape the
+        // launcher admits, so the float-reciprocal division is exact)
+        const float rH = 1.0f / (float)H;
         auto tile_gp0 = [&](int mtile) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
-            int prow0;
-            if (g.multi) prow0 = (gr0 / H) * (H + 2);
-            else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
+            const int b = vpd_fdiv(gr0, rH);
+            const int prow0 = g.multi ? b * (H + 2) : b * (H + 2) + (gr0 - b * H);
             return prow0 * Wp;
         };
+        // halo pixel hp (row hr, column xp of the padded tile) keeps its 16-byte pieces XOR-ed with key(hr, xp): HaloGeom
+        const float rWp = 1.0f / (float)Wp;
         auto halo_instr = [&](int gp0, int cc, int buf, int k) __attribute__((always_inline)) {
             const int hp = (lw + 4 * k) * 8 + lrow;
+            const int hr = vpd_fdiv(hp, rWp);
+            const int key = ((hp - hr * Wp) & g.kmask) ^ ((hr & g.rowmask) << g.kshift);
             int gp = gp0 + hp;
             gp = gp < g.total_pix ? gp : g.total_pix - 1;
-            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ (hp & 7)) << 3);
+            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ key) << 3);
             pws_dma16(src, lds0 + (unsigned)buf * (HBUF * 2u) + (unsigned)(lw + 4 * k) * 1024u);
         };
         // per-lane element offset of this wave's W_PER weight rows inside a [Co][Ci] tap slice
@@ -222,14 +229,29 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     const int wn = wave / WM;
     const int fr = lane & 15;
     const int fq = lane >> 4;
-    int hbase[MI];
+    // Pixel-fragment addresses.  Halo pixel r = hbase + toff (toff = tdy * Wp + tdx, the tap's shift) of K-half 0 lives at
+    // hb + r * 128 + ((key ^ fq) << 4); key (HaloGeom) depends on the pixel's COLUMN and row parity only, so the lane-dependent
+    // part is one of three precomputed words per fragment -- lo[ic][b] = hbase * 128 + (((column + dx_ic) & kmask) ^ rowkey ^ fq) * 16
+    // for the tap columns ic = 0, 1, 2 -- and the address of a step is ONE v_add with the wave-uniform hb + toff * 128
+    // (^ the tap row's parity bit when rowmask is set).  With the tap loop unrolled over ic, that is all the VALU a step needs:
+    // an MFMA wave has room for ~2 other instructions per 16-cycle MFMA, and the generic r -> (r * 8 + ((r & 7) ^ fq)) << 4
+    // arithmetic (5 VALU per fragment) plus the tap bookkeeping took ~85 instruction slots per 32-MFMA step.
+    unsigned lo[3][MI];
+    {
+        const float rW = 1.0f / (float)W, rH = 1.0f / (float)H;
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = wm * WTM + b * 16 + fr;
-        const int lr = m / W;
-        const int xx = m - lr * W;
-        const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
-        hbase[b] = hrow * Wp + xx;
+        for (int b = 0; b < MI; ++b) {
+            const int m = wm * WTM + b * 16 + fr;
+            const int lr = vpd_fdiv(m, rW);
+            const int xx = m - lr * W;
+            const int li = vpd_fdiv(lr, rH);
+            const int hrow = g.multi ? li * (H + 2) + (lr - li * H) : lr;
+            const unsigned rowkey = (unsigned)(((hrow & g.rowmask) << g.kshift) ^ fq);
+#pragma unroll
+            for (int ic = 0; ic < 3; ++ic)
+                lo[ic][b] = (unsigned)((hrow * Wp + xx) * 128) +
+                            ((((unsigned)(xx + p.taps.dx0 + ic * p.taps.dxs) & (unsigned)g.kmask) ^ rowkey) << 4);
+        }
     }
     // weight fragment a of K-half kk: LDS byte offset wa0 (kk = 0) + a * 2048 inside a stage (row wn*64 + a*16 + fr:
     // r & 7 == fr & 7); K-half 1 is the same address with bit 6 flipped (the 16-byte piece index kk*4 + fq flips bit 2)
@@ -264,8 +286,10 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         bf16x8 af0[NI], bf0[MI], af1[NI], bf1[MI];
         typedef const bf16x8 __attribute__((address_space(3)))* frag_t;
         // fragments by LDS byte address.  A: `wst` = the stage's base + wa0 (^ 64 for K-half 1).  B: halo pixel r of K-half 0 is at
-        // hb + r * 128 + (((r & 7) ^ fq) << 4) = hb + ((r * 8 + ((r & 7) ^ fq)) << 4), K-half 1 at that address ^ 64 (buffers are
-        // 128-byte aligned): three VALU operations per fragment and step on top of the tap shift, one for the second half
+        // hb + r * 128 + ((key ^ fq) << 4) = hb + ((r * 8 + (key ^ fq)) << 4), K-half 1 at that address ^ 64 (buffers are
+        // 128-byte aligned).  key (HaloGeom) is made of the pixel's column and row parity, not of r: the 16 pixels of a fragment
+        // span 16 / W image rows whose r differ by the two padding columns, and keyed on r & 7 two of those rows meet in the
+        // same banks (2-way conflicts on every pixel read of layer3 / layer4: the LDS pipe was ~95 % busy at full MFMA rate)
         auto load_a = [&](bf16x8 (&af)[NI], unsigned addr) __attribute__((always_inline)) {
 #pragma unroll
             for (int a = 0; a < NI; ++a) af[a] = *(frag_t)(size_t)(addr + a * 2048u);
@@ -274,12 +298,11 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 #pragma unroll
             for (int b = 0; b < MI; ++b) bfm[b] = *(frag_t)(size_t)addr[b];
         };
-        auto b_addr = [&](unsigned (&addr)[MI], unsigned hb, int toff) __attribute__((always_inline)) {
+        // K-half 0 addresses of the pixel fragments of tap column ic in the tap row whose wave-uniform terms are S (hb + toff * 128
+        // of its first column + ic * dxs * 128) and P (row-parity bit of the key, as an address bit)
+        auto b_addr = [&](unsigned (&addr)[MI], int ic, unsigned S, unsigned P) __attribute__((always_inline)) {
 #pragma unroll
-            for (int b = 0; b < MI; ++b) {
-                const unsigned r = (unsigned)(hbase[b] + toff);
-                addr[b] = hb + ((r * 8u + ((r & 7u) ^ (unsigned)fq)) << 4);
-            }
+            for (int b = 0; b < MI; ++b) addr[b] = (lo[ic][b] + S) ^ P;
         };
         auto mfma_set = [&](bf16x8 (&af)[NI], bf16x8 (&bfm)[MI]) __attribute__((always_inline)) {
 #pragma unroll
@@ -303,60 +326,70 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 
         const unsigned hb0 = lds0, hb1 = lds0 + HBUF * 2u;           // the two halo buffers
         unsigned hb = (gch & 1) ? hb1 : hb0;
-        // tap walk (rolled: unrolled, hipcc hoists the fragment addresses of all nine taps out of the loops and spills)
-        const int tstep_c = p.taps.dxs, tstep_r = p.taps.dys * Wp - 2 * p.taps.dxs;
-        const int toff0 = p.taps.dy0 * Wp + p.taps.dx0;
-        int tap = 0, tcol = 0, toff = toff0;
+        // tap walk: one kernel ROW per iteration (rolled: fully unrolled, hipcc hoists the addresses of all nine taps out of the
+        // loops and spills), its three columns unrolled
+        const int dxs128 = p.taps.dxs * 128;
+        auto row_S = [&](unsigned hbuf, int tdy) __attribute__((always_inline)) {
+            return hbuf + (unsigned)((tdy * Wp + p.taps.dx0) * 128);
+        };
+        auto row_P = [&](int tdy) __attribute__((always_inline)) { return (unsigned)(((tdy & g.rowmask) << g.kshift) << 4); };
+        int ir = 0, tdy = p.taps.dy0;
+        unsigned S0 = row_S(hb, tdy), P = row_P(tdy);
         unsigned ba[MI];                                             // K-half 0 addresses of the current step's pixel fragments
         // the tile's first READY; its first fragments are the one exposed LDS round trip of the tile
         if (job == 0) PWS_STAMP(1);                                  // set-up done, waiting for the first bytes
         __builtin_amdgcn_s_barrier();
         if (job == 0) PWS_STAMP(2);                                  // first READY
         if constexpr (PIPE) {
-            b_addr(ba, hb, toff);
+            b_addr(ba, 0, S0, P);
             load_a(af0, lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0); load_b(bf0, ba);
         }
+        const int nrows = nchunks * 3;
 #pragma nounroll
-        for (int s = 0; s < nsteps; ++s) {
-            const unsigned nstage = stage + 1 == NS ? 0u : stage + 1;
-            // the next step's tap: shift and halo buffer
-            const bool wrap = tap == 8;
-            const int ntoff = wrap ? toff0 : toff + (tcol == 2 ? tstep_r : tstep_c);
+        for (int row = 0; row < nrows; ++row) {
+            // the next tap row: the same chunk's, or the first one of the next chunk (other halo buffer)
+            const bool wrap = ir == 2;
             const unsigned nhb = wrap ? (hb == hb0 ? hb1 : hb0) : hb;
-            if (s != 0 && !VPD_ABL(p, 16)) __builtin_amdgcn_s_barrier(); // READY_s: this step and the next have landed
-            if constexpr (PIPE) {
-                if (!VPD_ABL(p, 2)) {
-                    // region 1: K-half 1 of this step is requested while K-half 0 multiplies
+            const int ntdy = wrap ? p.taps.dy0 : tdy + p.taps.dys;
+            const unsigned nS0 = row_S(nhb, ntdy), nP = row_P(ntdy);
+#pragma unroll
+            for (int ic = 0; ic < 3; ++ic) {
+                const unsigned nstage = stage + 1 == NS ? 0u : stage + 1;
+                if ((row != 0 || ic != 0) && !VPD_ABL(p, 16)) __builtin_amdgcn_s_barrier();      // READY_s: this step and the next have landed
+                if constexpr (PIPE) {
+                    if (!VPD_ABL(p, 2)) {
+                        // region 1: K-half 1 of this step is requested while K-half 0 multiplies
+                        unsigned ba1[MI];
+#pragma unroll
+                        for (int b = 0; b < MI; ++b) ba1[b] = ba[b] ^ 64u;
+                        if (!VPD_ABL(p, 32)) { load_a(af1, (lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0) ^ 64u); load_b(bf1, ba1); }
+                        if (!VPD_ABL(p, 64)) mfma_set(af0, bf0);
+                        interleave();
+                        __builtin_amdgcn_sched_barrier(0);
+                        // region 2: K-half 0 of the NEXT step (landed: READY_s covers it; behind a tile's last step these are the
+                        // next tile's first fragments or stale bytes, never used) while K-half 1 multiplies
+                        if (ic < 2) b_addr(ba, ic + 1, S0 + (unsigned)((ic + 1) * dxs128), P);
+                        else b_addr(ba, 0, nS0, nP);
+                        if (!VPD_ABL(p, 32)) { load_a(af0, lds0 + OFF_W + nstage * (WSTAGE * 2u) + wa0); load_b(bf0, ba); }
+                        if (!VPD_ABL(p, 64)) mfma_set(af1, bf1);
+                        interleave();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    b_addr(ba, ic, S0 + (unsigned)(ic * dxs128), P);
                     unsigned ba1[MI];
 #pragma unroll
                     for (int b = 0; b < MI; ++b) ba1[b] = ba[b] ^ 64u;
-                    if (!VPD_ABL(p, 32)) { load_a(af1, (lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0) ^ 64u); load_b(bf1, ba1); }
-                    if (!VPD_ABL(p, 64)) mfma_set(af0, bf0);
-                    interleave();
-                    __builtin_amdgcn_sched_barrier(0);
-                    // region 2: K-half 0 of the NEXT step (landed: READY_s covers it; behind a tile's last step these are the next
-                    // tile's first fragments or stale bytes, never used) while K-half 1 multiplies
-                    b_addr(ba, nhb, ntoff);
-                    if (!VPD_ABL(p, 32)) { load_a(af0, lds0 + OFF_W + nstage * (WSTAGE * 2u) + wa0); load_b(bf0, ba); }
-                    if (!VPD_ABL(p, 64)) mfma_set(af1, bf1);
-                    interleave();
-                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned wst = lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0;
+                    load_a(af0, wst); load_b(bf0, ba);
+                    load_a(af1, wst ^ 64u); load_b(bf1, ba1);
+                    mfma_set(af0, bf0);
+                    mfma_set(af1, bf1);
                 }
-            } else {
-                b_addr(ba, hb, toff);
-                unsigned ba1[MI];
-#pragma unroll
-                for (int b = 0; b < MI; ++b) ba1[b] = ba[b] ^ 64u;
-                const unsigned wst = lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0;
-                load_a(af0, wst); load_b(bf0, ba);
-                load_a(af1, wst ^ 64u); load_b(bf1, ba1);
-                mfma_set(af0, bf0);
-                mfma_set(af1, bf1);
+                stage = nstage;
             }
-            stage = nstage;
-            toff = ntoff; hb = nhb;
-            tcol = tcol == 2 ? 0 : tcol + 1;
-            if (wrap) { tap = 0; ++gch; } else ++tap;
+            hb = nhb; tdy = ntdy; S0 = nS0; P = nP;
+            if (wrap) { ir = 0; ++gch; } else ++ir;
         }
         if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
