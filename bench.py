@@ -77,33 +77,88 @@ def synthetic_batch(n, device, seed):
     return img, emb
 
 
-def cpu_baseline(sample_batch=32, budget_s=20.0, max_steps=40):
-    """The CPU oracle (fp32 torch-CPU restatement of the reference loop, kind "port") on the
-    host cores this process may run on: same network/loss/optimizer on a bounded sample of the
-    same workload (about `budget_s` seconds of CPU work)."""
-    from oracle import vpd_oracle as O
+def host_cpu():
+    """(threads to use, description): the PHYSICAL cores this process may be scheduled on, and the CPU model string.
+    /proc/cpuinfo gives (physical id, core id) per logical CPU; SMT siblings share a pair."""
     try:
-        cores = len(os.sched_getaffinity(0))
+        allowed = set(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))              # more threads than that only adds contention at this size
+        allowed = set(range(os.cpu_count() or 1))
+    model, cores, cur = "unknown CPU", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur and int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = [t.strip() for t in line.split(":", 1)]
+            cur[k] = v
+            if k == "model name":
+                model = v
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    phys = len(cores) or len(allowed)
+    return phys, "%s, %d physical cores of %d schedulable logical CPUs" % (model, phys, len(allowed))
+
+
+def cpu_baseline(batch=64, warm=3, timed=10):
+    """BASELINE.md section 3 / SURVEY 8d: the CPU oracle (fp32 torch-CPU restatement of the reference loop, kind "port") on ALL
+    physical host cores: ResNet-34, 5x128x128, D=128, --motion head on, B=64 synthetic crops; 3 warm-up + >= 10 timed train
+    steps (fwd + sum-MSE + bwd + AdamW: train_vpd_model.py:67-98) and 3 + >= 10 timed embed() calls (models/rgb.py:72-86).
+    Returns (train block, apply block)."""
+    from oracle import vpd_oracle as O
+    threads, desc = host_cpu()
     torch.set_num_threads(threads)
     enc = O.reference_init_state_dict(ARCH, C_IN, EMB_DIM, 0)
-    orc = O.StudentOracle(ARCH, C_IN, EMB_DIM, False, enc)
+    dec = O.procedural_state_dict(O.decoder_schema(EMB_DIM), 3)
+    orc = O.StudentOracle(ARCH, C_IN, EMB_DIM, True, enc, dec)
     orc.get_optimizer(5e-4)
-    img = O.synthetic_crops(sample_batch, C_IN, HW, 1)
-    tgt = O.synthetic_targets(sample_batch, EMB_DIM, False, 2)
-    t0 = time.perf_counter()
-    orc.train_step(img[:4], tgt[:4])              # warm-up (allocator, thread pool)
-    warm = time.perf_counter() - t0
-    steps, t0 = 0, time.perf_counter()
-    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
+    img = O.synthetic_crops(batch, C_IN, HW, 1)
+    tgt = O.synthetic_targets(batch, EMB_DIM, True, 2)
+    for _ in range(warm):
         orc.train_step(img, tgt)
-        steps += 1
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        orc.train_step(img, tgt)
     dt = time.perf_counter() - t0
-    return {"value": sample_batch * steps / dt, "unit": "crops/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps of %d crops in %.1f s (ResNet-34, 5x128x128, fp32, torch-CPU oracle; "
-                      "%d schedulable cores, warm-up %.1f s)" % (steps, sample_batch, dt, cores, warm)}
+    train = {"value": batch * timed / dt, "unit": "crops/s", "cores": threads, "kind": "port",
+             "sample": "%d warm-up + %d timed train steps of %d crops in %.1f s (ResNet-34, 5x128x128, D=128, motion head, "
+                       "fp32, torch-CPU oracle; %s)" % (warm, timed, batch, dt, desc)}
+    for _ in range(warm):
+        O.embed(orc.enc, img, ARCH, True)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        O.embed(orc.enc, img, ARCH, True)
+    dt = time.perf_counter() - t0
+    apply = {"value": batch * timed / dt, "unit": "crops/s", "cores": threads, "kind": "port",
+             "sample": "%d warm-up + %d timed embed() calls of %d crops in %.1f s (same student, eval mode; %s)"
+                       % (warm, timed, batch, dt, desc)}
+    return train, apply
+
+
+def visible_gpu_count():
+    """GPUs this process tree may use, WITHOUT touching the HIP runtime (the parent of the ranks must not initialise it):
+    the visibility variables if set, else the KFD topology nodes that have SIMDs."""
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    n = 0
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(root):
+            try:
+                props = dict(line.split() for line in open(os.path.join(root, node, "properties")) if len(line.split()) == 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return n
 
 
 def spawn_ranks(n, argv):
@@ -116,7 +171,7 @@ def spawn_ranks(n, argv):
         port = sk.getsockname()[1]
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    ngpu = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    ngpu = visible_gpu_count()                        # (no torch.cuda.* call in the parent of the ranks)
     procs = []
     for r in range(n):
         # fewer devices than ranks (a 1-GPU box driving the 2-rank path over gloo): ranks share device r % ngpu
@@ -255,6 +310,11 @@ def main():
         cls = eng.read_timing(pl) if args.profile_steps > 0 else {}
         eng.set_timing(pl, False)
 
+    # a grid-barrier time-out (fused BatchNorm backward; vpd_amd/csrc/sync.h) means the timed steps were not valid steps
+    nerr = eng.sync_errors()
+    if nerr:
+        raise SystemExit("bench.py: %d in-launch barrier time-outs on rank %d: the measured steps are invalid" % (nerr, rank))
+
     out = None
     if rank == 0:
         crops = args.batch * world * args.steps
@@ -313,7 +373,9 @@ def main():
         if world == 1 and not args.no_apply and args.arch == ARCH:
             out["apply"] = apply_block(enc, device)
         if world == 1 and not args.no_cpu_baseline and args.arch == ARCH:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], apply_cpu = cpu_baseline()
+            if "apply" in out:
+                out["apply"]["cpu_baseline"] = apply_cpu
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -168,15 +168,27 @@ CASES = [
     # (here: three) train step(s) of the reference on the CPU
     ("c1_r34_c5_d128_m1_n64", "resnet34", 5, 128, True, 64, 128, 5e-4),
 ]
+# Full-size cases: BASELINE configs[1]-[4] at their own per-GPU sizes, so that the HIP path is compared with
+# values the REFERENCE produced at 256 / 512 / 1000 crops, not only with size-independent properties.
+#   level "full":  everything run_case stores except the post-step eval embeddings and the loss trajectory
+#   level "light": eval embeddings + train-mode embeddings, loss and BatchNorm taps (no backward: halves the CPU time / memory)
+#   level "eval":  eval embeddings only (the apply path)
+# name, arch, c_in, D, motion, N, HW, lr, level, crop normalisation
+FULLSIZE_CASES = [
+    ("c2_r34_c5_d128_m0_n256", "resnet34", 5, 128, False, 256, 128, 5e-4, "full", None),
+    ("c3_r34_c5_d128_m1_n512_fs", "resnet34", 5, 128, True, 512, 128, 5e-4, "light", "fs"),
+    ("c3_r34_c6_d128_m1_n512", "resnet34", 6, 128, True, 512, 128, 5e-4, "light", None),
+    ("c5_r34_c5_d128_n1000", "resnet34", 5, 128, False, 1000, 128, 5e-4, "eval", None),
+]
 TAP_BNS = ["resnet.bn1", "resnet.layer1.0.bn1", "resnet.layer2.0.downsample.1",
            "resnet.layer3.1.bn2", "resnet.layer4.1.bn2"]
 
 
-def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
+def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed, level="all", norm=None):
     ref_module, ref_rgb, ref_util, ref_train, _, _ = ref
     enc_sd = O.procedural_state_dict(O.encoder_schema(arch, c_in, D), seed)
     dec_sd = O.procedural_state_dict(O.decoder_schema(D), seed + 7) if motion else None
-    img = O.synthetic_crops(N, c_in, HW, seed + 1)
+    img = O.synthetic_crops(N, c_in, HW, seed + 1, O.FS_MEAN_STD if norm == "fs" else None)
     tgt = O.synthetic_targets(N, D, motion, seed + 2)
 
     def build():
@@ -206,11 +218,13 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
         return enc, tr
 
     out = {"meta": json.dumps(dict(name=name, arch=arch, c_in=c_in, emb_dim=D, motion=motion,
-                                   n=N, hw=HW, lr=lr, seed=seed))}
+                                   n=N, hw=HW, lr=lr, seed=seed, level=level, norm=norm))}
 
     # (1) eval-mode embeddings through the reference's embed()  (models/rgb.py:72-86)
     enc, tr = build()
     out["emb_eval"] = enc.embed(img.numpy())
+    if level == "eval":
+        return out
     # eval-mode epoch value (optimizer=None): train_vpd_model.py:70-76
     out["epoch_eval"] = np.float64(tr.epoch([{"img": img, "emb": tgt}]))
 
@@ -228,10 +242,16 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
             hooks.append(mods[bn_name].register_forward_hook(hk))
     if motion:
         tr.fcn_time.train()
-    emb = enc(img)
-    pred = tr.fcn_time(emb) if motion else emb
-    loss = torch.nn.functional.mse_loss(pred, tgt, reduction="sum")
-    loss.backward()
+    if level == "light":
+        with torch.no_grad():
+            emb = enc(img)
+            pred = tr.fcn_time(emb) if motion else emb
+            loss = torch.nn.functional.mse_loss(pred, tgt, reduction="sum")
+    else:
+        emb = enc(img)
+        pred = tr.fcn_time(emb) if motion else emb
+        loss = torch.nn.functional.mse_loss(pred, tgt, reduction="sum")
+        loss.backward()
     for h in hooks:
         h.remove()
     out["emb_train"] = emb.detach().numpy()
@@ -239,6 +259,8 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
     for k, (m, v) in taps.items():
         out["bnmean/" + k] = m
         out["bnvar/" + k] = v
+    if level == "light":
+        return out
     named = [("enc." + k, p) for k, p in enc.named_parameters()]
     if motion:
         named += [("dec." + k, p) for k, p in tr.fcn_time.named_parameters()]
@@ -261,6 +283,8 @@ def run_case(ref, name, arch, c_in, D, motion, N, HW, lr, seed):
         named += [("dec." + k, p) for k, p in tr.fcn_time.named_parameters()]
     for k, p in named:
         out["psamp/" + k] = _samples(p)
+    if level == "full":
+        return out
     out["emb_eval_post"] = enc.embed(img.numpy())
     # second + third step losses (three-step trajectory, SURVEY 8c probe)
     traj = [float(out["epoch_train"])]
@@ -384,6 +408,12 @@ def main():
         out = run_case(ref, *case, seed=100 + 10 * i)
         np.savez_compressed(os.path.join(OUT, case[0] + ".npz"), **out)
         print("wrote", case[0], "loss", float(out["loss_train"]), "traj", out["epoch_traj"])
+    for i, case in enumerate(FULLSIZE_CASES):      # only on request: GOLDEN_ONLY=<names> (minutes of CPU time, GBs of memory)
+        if not only or case[0] not in only.split(","):
+            continue
+        out = run_case(ref, *case[:8], seed=500 + 10 * i, level=case[8], norm=case[9])
+        np.savez_compressed(os.path.join(OUT, case[0] + ".npz"), **out)
+        print("wrote", case[0], "loss", float(out.get("loss_train", float("nan"))))
     if not only or "init" in only.split(","):
         with open(os.path.join(OUT, "init_stats.json"), "w") as fp:
             json.dump(init_case(ref), fp, indent=0, sort_keys=True)

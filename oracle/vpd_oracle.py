@@ -415,11 +415,17 @@ DIVING48_MEAN_STD = ((0.3411329922282787, 0.46349889258964044, 0.516248167401569
                      (0.16302619019820488, 0.17092395707914718, 0.19266662199338647))
 
 
-def synthetic_crops(n: int, c_in: int, hw: int, seed: int) -> torch.Tensor:
+# figure-skating crops (BASELINE configs[3]): vpd_dataset/common.py:19-22
+FS_MEAN_STD = ((0.5747710337842444, 0.5644043210903272, 0.6334494151377134),
+               (0.21349823115367886, 0.21827191146692457, 0.20393919008463163))
+
+
+def synthetic_crops(n: int, c_in: int, hw: int, seed: int, mean_std=None) -> torch.Tensor:
     rs = np.random.RandomState(seed)
     rgb = rs.randint(0, 256, size=(n, 3, hw, hw)).astype(np.float32) / 255.0
-    mean = np.asarray(DIVING48_MEAN_STD[0], np.float32).reshape(1, 3, 1, 1)
-    std = np.asarray(DIVING48_MEAN_STD[1], np.float32).reshape(1, 3, 1, 1)
+    mean_std = mean_std or DIVING48_MEAN_STD
+    mean = np.asarray(mean_std[0], np.float32).reshape(1, 3, 1, 1)
+    std = np.asarray(mean_std[1], np.float32).reshape(1, 3, 1, 1)
     x = (rgb - mean) / std
     if c_in > 3:
         fl = np.clip(np.round(124 + 12 * rs.standard_normal((n, c_in - 3, hw, hw))), 0, 255)

@@ -738,3 +738,39 @@ def test_lazy_gradients_of_the_fused_step_match_the_eager_path():
     # weight gradients take the halo kernel, not the atomics kernel): two runs agree to the last bit
     assert np.array_equal(g1, g0), rel_l2(g1, g0)
     assert np.array_equal(m1, m0) and np.array_equal(p1, p0), (rel_l2(m1, m0), rel_l2(p1, p0))
+
+
+def test_step_with_a_torch_optimizer_reads_complete_gradients():
+    """models.util.step() accepts ANY optimizer (reference models/util.py:50-58).  Only FusedAdamW may get the lazy
+    backward; torch.optim.AdamW over the same parameters must see complete p.grad views -- three steps with it equal three
+    steps with FusedAdamW (same AdamW arithmetic, torch's kernel vs ours) to 1e-5, and its default zero_grad(set_to_none)
+    does not lose the gradient views."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.models.util import step
+    from vpd_amd.trainer import ModelTrainer
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(6, 5, 64, 64, generator=g).cuda()
+    tgt = torch.randn(6, 64, generator=g).cuda()
+    out = []
+    for kind in ("fused", "torch"):
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, torch.device("cuda:0"))
+        enc.reset_parameters(seed=3)
+        tr = ModelTrainer(enc, motion=True)
+        for q in tr.fcn_time.parameters():
+            with torch.no_grad():
+                q.copy_(torch.randn(q.shape, generator=torch.Generator().manual_seed(q.numel())).to(q.device) * 0.05)
+        if kind == "fused":
+            opt, sc = tr.get_optimizer(5e-4)
+        else:
+            opt, sc = torch.optim.AdamW(list(enc.parameters()) + list(tr.fcn_time.parameters()), lr=5e-4), None
+            assert not getattr(opt, "consumes_lazy_grads", False)
+        enc.train()
+        for it in range(3):
+            loss = tr._forward_loss(img, tgt, train=True)
+            step(opt, sc, loss)
+        torch.cuda.synchronize()
+        out.append(enc.engine.params.detach().cpu().numpy().copy())
+    p_fused, p_torch = out
+    assert np.isfinite(p_torch).all()
+    # Adam's first steps move every weight by ~lr: a stale (zero) conv gradient would leave conv weights at lr * wd scale only
+    assert np.abs(p_fused - p_torch).max() < 2e-5, np.abs(p_fused - p_torch).max()

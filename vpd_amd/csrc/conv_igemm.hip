@@ -1092,6 +1092,12 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 // conv3x3_pws_kernel (conv_pws.h): persistent blocks, LDS flag hand-off.  VPD_PWS=0 restores conv3x3_ws_kernel.
 // ---------------------------------------------------------------------------
 // ring depths per tile class (NS = A + 2: two readable steps + A weight bundles in flight); -D overrides for same-box A/B builds
+#ifndef PWS_PREFER_C6
+#define PWS_PREFER_C6 0
+#endif
+#ifndef PWS_C1_ALWAYS
+#define PWS_C1_ALWAYS 0
+#endif
 #ifndef PWS_NS_C1
 #define PWS_NS_C1 4
 #endif
@@ -1534,6 +1540,13 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
         if (p.Co % 128 == 0) {
             const long t256 = (long)((p.M + 255) / 256) * (p.Co / 128);
             const long t128 = (long)((p.M + 127) / 128) * (p.Co / 128);
+            // 256 x 64 tiles on the pipelined persistent kernel where 256 x 128 tiles would give every block exactly one tile: twice
+            // the tiles, so a block overlaps one tile's epilogue with the next one's loads (layer2 at 256 crops: 23.2 vs 25.2 us;
+            // with several 256 x 128 tiles per block the eight-wave kernel below is faster: 83.7 vs 90.6 us at 1000 crops)
+            static const int w64_first = getenv("VPD_PWS_PREFER_C6") ? atoi(getenv("VPD_PWS_PREFER_C6")) : PWS_PREFER_C6;
+            if ((w64_first || (p.M + 255) / 256 <= pws_cu_count() / (p.Co / 128)) && pws_enabled(p) && t256 >= 200 &&
+                halo_geom(p, 256, 416, g))
+                return 6;
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
             // 256 pixels x 64 channels: the FLOPs of a 128 x 128 tile for 30 % fewer staged bytes per K-step (8 KB of weights +
             // 1/9 of a 52 KB halo instead of 16 KB + 1/9 of 36 KB) where 256-pixel tiles alone would leave half the chip idle
@@ -1605,7 +1618,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         case 1:
             // (eight MFMA waves, no fragment pipeline: two waves per SIMD cover each other's LDS round trips.  With ONE tile per
             //  block conv3x3_ws_kernel, whose loaders run three bundles ahead instead of two, is 3 % faster: 25.5 vs 26.3 us)
-            if (pws_enabled(p) && (p.M + 255) / 256 > pws_cu_count() / (p.Co / 128)) {
+            if (pws_enabled(p) && (PWS_C1_ALWAYS || (p.M + 255) / 256 > pws_cu_count() / (p.Co / 128))) {
                 if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 3, 8, false, true>(p, g, stream);
                 return launch_pws<256, 128, 352, PWS_NS_C1, 8, false>(p, g, stream);
             }

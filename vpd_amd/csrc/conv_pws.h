@@ -266,6 +266,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     constexpr bool BST = EPM == 6 || EPM == 7 || EPM == 8;
+    constexpr bool BST_EARLY = PIPE && MI <= 2 && (EPM == 6 || EPM == 7);      // (64 x 64 wave tiles: 40 more registers spill)
     BstPair<NI, VPD_BST_MB(MI)> pr;
     if (EPM == 8) {
 #pragma unroll
@@ -345,8 +346,14 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             load_a(af0, lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0); load_b(bf0, ba);
         }
         const int nrows = nchunks * 3;
+        // modes 6 / 7: the epilogue's z fragments and mask bits (first 4 pixel groups) are requested at the start of the tile's
+        // LAST chunk -- nine K-steps (~3 us) ahead of their use; requested behind the K loop (conv3x3_ws_kernel: its 256-pixel
+        // tile has no registers for them) they cost the data gradients ~2 us of exposed memory latency per tile (in-step stamps:
+        // 8,400 cycles of epilogue against 3,700 for the plain forward store).  Mode 8 has no registers left for it.
+        BstFrag<NI, VPD_BST_MB(MI)> bst;
 #pragma nounroll
         for (int row = 0; row < nrows; ++row) {
+            if (BST_EARLY && row == nrows - 3) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
             // the next tap row: the same chunk's, or the first one of the next chunk (other halo buffer)
             const bool wrap = ir == 2;
             const unsigned nhb = wrap ? (hb == hb0 ? hb1 : hb0) : hb;
@@ -394,8 +401,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
         if (VPD_ABL(p, 8)) continue;
-        BstFrag<NI, VPD_BST_MB(MI)> bst;
-        if (BST) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+        if (BST && !BST_EARLY) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
         if (EPM == 8) conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr);
         if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);

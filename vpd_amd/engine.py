@@ -195,6 +195,7 @@ class StudentEngine:
         if pl is None or pl.max_batch < n:
             if pl is not None:
                 if self._step_plan is pl:
+                    self.materialize_grads()       # a pending lazy backward lives in the workspace that is about to go
                     self._step_plan = None
                 pl.close()
             pl = _Plan(self, h, w, max(n, pl.max_batch if pl else 0), train, motion)
@@ -277,11 +278,11 @@ class StudentEngine:
             raise RuntimeError("backward() without a preceding train-mode forward with a target")
         pl, n = self._last
         self._last = None
+        self.materialize_grads()           # a pending lazy backward of the PREVIOUS step plan (possibly another plan) first
         self._step_plan = pl
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
-        self.materialize_grads()           # (a pending lazy backward of ANOTHER plan would otherwise be lost)
         if lazy and ev is None:
             check(lib().vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
         check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
@@ -303,6 +304,12 @@ class StudentEngine:
             self.adam_v = torch.zeros_like(self.params)
         self.adam_step += 1
         pl = self._step_plan
+        if pl is not None and numel < pl.param_numel:
+            # an optimizer that was NOT given the motion head, behind a plan that trains it: the fused pass would update the
+            # head's tensors too (torch.optim.AdamW never touches tensors it was not given) -- plain flat update of the leading
+            # `numel` elements instead; the plan repacks its bf16 weights before its next forward
+            self.materialize_grads()
+            pl = None
         if pl is not None and pl.packed_version == self.weights_version() and os.environ.get("VPD_FUSED_ADAMW", "1") != "0":
             # the train plan of the last backward: AdamW + refresh of its packed bf16 weights in one pass
             check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self._grads), _ptr(self.adam_m),

@@ -12,8 +12,11 @@ def step(optimizer, scaler, loss):
     needs no loss scaling, so get_optimizer() returns scaler=None."""
     if scaler is not None:
         raise ValueError("the bf16 HIP path does not use a GradScaler; pass scaler=None")
-    # same three calls as the reference; the fused loss object offers a backward that hands the gradients to the optimizer
-    # in the kernels' own layout (the reference's loop never reads .grad between these calls; loss.backward() does fill it)
-    (getattr(loss, "backward_for_step", loss.backward) if _LAZY else loss.backward)()
+    # same three calls as the reference.  The fused loss object offers a backward that leaves the conv weight gradients in
+    # the kernels' own layout -- ONLY an optimizer that reads that layout may get it (FusedAdamW: `consumes_lazy_grads`).
+    # Any other optimizer (the reference's step() accepts any: torch.optim.AdamW over encoder.parameters(), a wrapper that
+    # looks at p.grad) gets the plain loss.backward(), which completes every p.grad view of the flat gradient buffer.
+    lazy = _LAZY and getattr(optimizer, "consumes_lazy_grads", False) and hasattr(loss, "backward_for_step")
+    (loss.backward_for_step if lazy else loss.backward)()
     optimizer.step()
     optimizer.zero_grad()

@@ -33,6 +33,8 @@ class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW(params, lr) with torch defaults (train_vpd_model.py:104) as ONE
     HIP kernel over the engine's flat fp32 buffers (weight decay on every tensor)."""
 
+    consumes_lazy_grads = True      # models.util.step(): this optimizer reads the weight-gradient kernels' own layout
+
     def __init__(self, params, engine, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
         params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -117,6 +119,23 @@ class ModelTrainer:
             self._reducer.reduce(pl)
         else:
             eng.backward(lazy=lazy)
+        if not lazy:
+            self._reattach_grads()
+
+    def _reattach_grads(self):
+        """A torch optimizer's zero_grad() drops .grad (set_to_none=True is torch's default): every plain backward() makes
+        sure the parameters' .grad are the views of the engine's flat gradient buffer again."""
+        eng = self.encoder.engine
+        first = next(iter(self.encoder.parameters()))
+        if first.grad is not None and (not hasattr(self, 'fcn_time') or next(iter(self.fcn_time.parameters())).grad is not None):
+            return
+        g = eng.grads
+        for k in eng.enc_names:
+            self.encoder.get_parameter(k).grad = eng.view(k, g)
+        if hasattr(self, 'fcn_time'):
+            from .models.module import DECODER_PARAM_NAMES
+            for k in DECODER_PARAM_NAMES:
+                self.fcn_time.get_parameter(k).grad = eng.view("decoder." + k, g)
 
     def epoch(self, data_loader, optimizer=None, scaler=None, progress_cb=None):
         eng = self.encoder.engine
