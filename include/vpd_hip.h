@@ -115,12 +115,16 @@ int vpd_plan_adamw_step(vpd_plan_t* plan, float* params, const float* grads, flo
                         int step, void* workspace, void* stream);
 
 /* Lazy gradients for the fused train step (reference: models/util.py:50-58, where nothing looks at .grad between
- * loss.backward() and optimizer.step()).  vpd_plan_set_lazy_grads(plan, 1) arms the NEXT vpd_backward (ignored when it is
- * given bucket events, i.e. under data parallelism): the conv weight gradients then stay in the kernels' own fp32 scratch
- * layout and vpd_plan_adamw_step reads them there, so the layout pass into `grads` (170 MB of traffic per step) is skipped;
- * every other tensor's gradient, and the stem's, is in `grads` as usual.  vpd_plan_grads_pending() tells whether `grads` is
- * incomplete; vpd_plan_materialize_grads() completes it on demand (no-op otherwise). */
+ * loss.backward() and optimizer.step()).  vpd_plan_set_lazy_grads(plan, 1) arms the NEXT vpd_backward: the conv weight
+ * gradients then stay in the kernels' own fp32 scratch layout and vpd_plan_adamw_step reads them there, so the layout pass
+ * into `grads` (170 MB of traffic per step) is skipped; every other tensor's gradient, and the stem's, is in `grads` as usual.
+ * vpd_plan_grads_pending() tells whether `grads` is incomplete; vpd_plan_materialize_grads() completes it on demand (no-op
+ * otherwise).  Under data parallelism (bucket events given) a lazy backward leaves bucket b's conv gradients in the workspace
+ * range vpd_plan_bucket_scratch_range(plan, b) (byte offset into the workspace, fp32 count): a SUM all-reduce is layout-
+ * agnostic (train_vpd_model.py:87: the loss is a sum over crops), so the reducer sums that range and the non-conv tensors
+ * (+ the stem) of the flat buffer; bucket b's event is recorded when both are final. */
 int vpd_plan_set_lazy_grads(vpd_plan_t* plan, int on);
+int vpd_plan_bucket_scratch_range(const vpd_plan_t* plan, int bucket, long long* ws_byte_offset, long long* numel);
 int vpd_plan_grads_pending(const vpd_plan_t* plan);
 int vpd_plan_materialize_grads(vpd_plan_t* plan, float* grads, void* workspace, void* stream);
 

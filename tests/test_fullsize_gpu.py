@@ -215,3 +215,110 @@ def test_fused_adamw_full_buffer_matches_torch():
     for off, numel in pl.buckets:
         a, b = float(eng.params[off:off + numel].double().sum()), float(ref.detach()[off:off + numel].double().sum())
         assert abs(a - b) <= 1e-6 * max(1.0, abs(b)) + 1e-3
+
+
+# ---------------------------------------------------------------------------
+# Values the REFERENCE produced at full size: tests/golden/c2_* / c3_* / c5_*.npz come from
+# oracle/gen_golden.py running the reference's own RGBF_EmbeddingModel / ModelTrainer / FCNet on the CPU at 256 / 512 /
+# 1000 crops (train_vpd_model.py:77-98, models/rgb.py:72-86); the HIP path is held to the same EMB_TOL / LOSS_TOL as on
+# the small golden cases of tests/test_model_gpu.py.
+# ---------------------------------------------------------------------------
+import json
+import os
+
+from oracle import vpd_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+EMB_TOL, LOSS_TOL = 2e-2, 1e-2
+
+
+def _golden_build(meta):
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    enc_sd = O.procedural_state_dict(O.encoder_schema(meta["arch"], meta["c_in"], meta["emb_dim"]), meta["seed"])
+    dec_sd = O.procedural_state_dict(O.decoder_schema(meta["emb_dim"]), meta["seed"] + 7) if meta["motion"] else None
+    img = O.synthetic_crops(meta["n"], meta["c_in"], meta["hw"], meta["seed"] + 1,
+                            O.FS_MEAN_STD if meta.get("norm") == "fs" else None)
+    tgt = O.synthetic_targets(meta["n"], meta["emb_dim"], meta["motion"], meta["seed"] + 2)
+    enc = RGBF_EmbeddingModel(meta["arch"], meta["emb_dim"], meta["c_in"] != 3, "cuda",
+                              in_channels=None if meta["c_in"] in (3, 5) else meta["c_in"])
+    enc.load_state_dict(enc_sd)
+    tr = ModelTrainer(enc, meta["motion"])
+    if meta["motion"]:
+        tr.fcn_time.load_state_dict(dec_sd)
+    return enc, tr, img, tgt
+
+
+def _per_sample_rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize("name", ["c2_r34_c5_d128_m0_n256", "c3_r34_c5_d128_m1_n512_fs", "c3_r34_c6_d128_m1_n512",
+                                  "c5_r34_c5_d128_n1000"])
+def test_fullsize_values_match_the_reference(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(g["meta"]))
+    enc, tr, img, tgt = _golden_build(meta)
+    rec = {"meta": meta}
+    # eval-mode embed(): every crop against the reference's embedding of the same crop
+    e = enc.embed(img.numpy())
+    ps = _per_sample_rel(e, g["emb_eval"])
+    rec["emb_eval_per_sample_max"] = float(ps.max())
+    assert e.shape == g["emb_eval"].shape and ps.max() <= EMB_TOL, float(ps.max())
+    if meta["level"] == "eval":
+        # the apply path's own route: ONE hipGraph launch of the 1000-crop batch (apply_vpd_model.py:15, :160-162)
+        x = img.cuda()
+        out = torch.empty((meta["n"], meta["emb_dim"]), dtype=torch.float32, device="cuda")
+        enc.eval()
+        pl = enc.engine.capture_eval_graph(x, out)
+        enc.engine.launch_eval_graph(pl, meta["n"])
+        torch.cuda.synchronize()
+        assert _per_sample_rel(out.cpu().numpy(), g["emb_eval"]).max() <= EMB_TOL
+        return
+    ev = tr.epoch([{"img": img, "emb": tgt}])
+    assert abs(ev - float(g["epoch_eval"])) <= LOSS_TOL * abs(float(g["epoch_eval"])), (ev, float(g["epoch_eval"]))
+    # train-mode forward: embeddings under batch statistics, loss, BatchNorm taps
+    enc, tr, img, tgt = _golden_build(meta)
+    enc.train()
+    eng = enc.engine
+    emb = eng.forward_train(img.cuda(), tgt.cuda(), motion=meta["motion"], accumulate_loss=False).clone()
+    l_hip = float(eng.loss_step.item())
+    rec["loss_train"] = [l_hip, float(g["loss_train"])]
+    assert abs(l_hip - float(g["loss_train"])) <= LOSS_TOL * abs(float(g["loss_train"])), rec["loss_train"]
+    ps = _per_sample_rel(emb.cpu().numpy(), g["emb_train"])
+    rec["emb_train_per_sample_max"] = float(ps.max())
+    assert ps.max() <= EMB_TOL, float(ps.max())
+    if meta["level"] == "light":
+        return
+    # full: gradients (per-stage norms against the reference's recorded norms), running statistics after the step
+    eng.backward()
+    torch.cuda.synchronize()
+    stage = lambda k: k.split(".")[2] if k.startswith("enc.resnet.layer") else ("stem" if "conv1" in k or "bn1" in k else "fc")
+    hip2, ref2 = {}, {}
+    for k in [f[len("gnorm/"):] for f in g.files if f.startswith("gnorm/")]:
+        got = enc.get_parameter(k[4:]).grad
+        s_ = stage(k)
+        hip2[s_] = hip2.get(s_, 0.0) + float(got.double().pow(2).sum())
+        ref2[s_] = ref2.get(s_, 0.0) + float(g["gnorm/" + k]) ** 2
+    rec["grad_norm_ratio_by_stage"] = {s_: (hip2[s_] / ref2[s_]) ** 0.5 for s_ in ref2}
+    # bf16 operands against an fp32 reference: the norm of a stage's gradient is held to 15 % (the per-tensor direction is
+    # gated on the small cases and in test_backward_matches_bf16_emulation_directly, where an emulation can be afforded)
+    assert all(0.85 <= v <= 1.15 for v in rec["grad_norm_ratio_by_stage"].values()), rec["grad_norm_ratio_by_stage"]
+    # BatchNorm running statistics after ONE reference step (epoch_train ran on fresh modules: same single update)
+    sd = enc.state_dict()
+    worst = 0.0
+    for f in g.files:
+        if f.startswith("post/") and not f.endswith("num_batches_tracked"):
+            worst = max(worst, _rel(sd[f[len("post/"):]].cpu().numpy(), g[f]))
+    rec["running_stats_rel_l2_max"] = worst
+    assert worst <= 2e-2, worst
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_fullsize_%s.json" % name), "w") as fp:
+        json.dump(rec, fp, indent=1)

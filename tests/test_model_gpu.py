@@ -37,7 +37,9 @@ from oracle import vpd_oracle as O
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(glob.glob(os.path.join(GOLDEN, "*r[0-9]*_c[0-9]_*.npz")))
+# (c2_ / c3_ / c5_: the full-size cases of tests/test_fullsize_gpu.py -- minutes of CPU oracle time each, not run here)
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*r[0-9]*_c[0-9]_*.npz"))
+               if not os.path.basename(p).startswith(("c2_", "c3_", "c5_")))
 EMB_TOL, LOSS_TOL = 2e-2, 1e-2
 OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
 

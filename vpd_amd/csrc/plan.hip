@@ -101,6 +101,9 @@ struct vpd_plan {
     long long arena_elems = 0, wg_elems = 0, slab_elems = 0;
     // gradient buckets (flat-buffer ranges) -- bucket 0 = layer4+fc+decoder ... bucket 3 = stem+layer1
     long long bucket_off[4], bucket_numel[4];
+    // ... and the part of the weight-gradient scratch (fp32 elements from wg_off) that holds bucket b's conv gradients, the
+    // stem excluded (its row-tap packing is always undone into the flat buffer): vpd_plan_bucket_scratch_range
+    long long bucket_wg_off[4], bucket_wg_numel[4];
     // workspace offsets (bytes)
     size_t ws_bytes = 0;
     size_t xin_off = 0, arena_off = 0, wg_off = 0, partial_off = 0, z0_off = 0, p0_off = 0, idx_off = 0;
@@ -322,12 +325,32 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     };
     push_desc(p->stem, 3);
     p->nstem_unpack_blocks = (int)p->bmap_unpack[3].size() / 2;
+    for (int b = 0; b < 4; ++b) { p->bucket_wg_off[b] = -1; p->bucket_wg_numel[b] = 0; }
     for (auto& B : p->blocks) {
         const int bucket = 3 - B.stage;
         push_desc(B.c1, bucket);
         push_desc(B.c2, bucket);
         if (bottleneck) push_desc(B.c3, bucket);
         if (B.ds) push_desc(B.cd, bucket);
+        // the scratch is laid out in construction order (add_conv), stage after stage: a bucket's convs are ONE range
+        auto take = [&](const ConvInfo& cv) {
+            const long long n = (long long)cv.ntaps * cv.Co * cv.Kc;
+            if (p->bucket_wg_off[bucket] < 0) p->bucket_wg_off[bucket] = cv.wg_off;
+            p->bucket_wg_off[bucket] = std::min(p->bucket_wg_off[bucket], (long long)cv.wg_off);
+            p->bucket_wg_numel[bucket] += n;
+        };
+        take(B.c1); take(B.c2);
+        if (bottleneck) take(B.c3);
+        if (B.ds) take(B.cd);
+    }
+    {
+        // contiguity check: the four ranges tile [stem's end, wg_elems) in bucket order 3, 2, 1, 0
+        long long at = (long long)p->stem.ntaps * p->stem.Co * p->stem.Kc;
+        for (int b = 3; b >= 0; --b) {
+            if (p->bucket_wg_off[b] != at) { delete p; return fail("internal: weight-gradient scratch is not bucket-contiguous"); }
+            at += p->bucket_wg_numel[b];
+        }
+        if (at != p->wg_elems) { delete p; return fail("internal: weight-gradient scratch size mismatch"); }
     }
     {
         // block map of vpd_plan_adamw_step: every conv tile as in the pack map (not the stem), then the ranges
@@ -575,6 +598,13 @@ extern "C" int vpd_plan_num_buckets(const vpd_plan_t*) { return 4; }
 extern "C" int vpd_plan_bucket_range(const vpd_plan_t* p, int b, long long* offset, long long* numel) {
     if (b < 0 || b >= 4) return fail("bucket index out of range");
     *offset = p->bucket_off[b]; *numel = p->bucket_numel[b];
+    return 0;
+}
+extern "C" int vpd_plan_bucket_scratch_range(const vpd_plan_t* p, int b, long long* ws_byte_offset, long long* numel) {
+    if (b < 0 || b >= 4) return fail("bucket index out of range");
+    if (!p->train) return fail("plan was created with train=0");
+    *ws_byte_offset = (long long)p->wg_off + p->bucket_wg_off[b] * 4;
+    *numel = p->bucket_wg_numel[b];
     return 0;
 }
 extern "C" size_t vpd_plan_workspace_bytes(const vpd_plan_t* p) { return p->ws_bytes; }
@@ -1209,8 +1239,11 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     if (n == 0) {      // empty shard: the gradient of a sum over no crops is zero; every bucket is "ready" at once
-        p->lazy_next = false; p->grads_in_scratch = false;
+        // (lazy: the reducer sums the scratch ranges, and the optimizer step reads them there afterwards)
+        p->grads_in_scratch = p->lazy_next;
+        p->lazy_next = false;
         HCHECK(hipMemsetAsync(grads, 0, (size_t)p->nparam_padded * sizeof(float), s));
+        if (p->grads_in_scratch) HCHECK(hipMemsetAsync(ws + p->wg_off, 0, (size_t)p->wg_elems * sizeof(float), s));
         for (int b = 0; b < 4; ++b)
             if (bucket_events && bucket_events[b]) HCHECK(hipEventRecord((hipEvent_t)bucket_events[b], s));
         return 0;
@@ -1345,8 +1378,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         }
         return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed);
     };
-    // lazy: no bucket hand-over to a reducer in this call, and the caller asked for it (vpd_plan_set_lazy_grads)
-    const bool lazy = p->lazy_next && !bucket_events;
+    // lazy: the caller asked for it (vpd_plan_set_lazy_grads).  With bucket events the reducer then sums the scratch ranges
+    // (vpd_plan_bucket_scratch_range) and the non-conv tensors of the flat buffer instead of the whole flat buffer
+    const bool lazy = p->lazy_next;
     p->lazy_next = false;
     p->grads_in_scratch = lazy;
     auto unpack_bucket = [&](int b) -> int {

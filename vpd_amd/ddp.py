@@ -38,6 +38,24 @@ def all_reduce_buckets(flat, ranges, group=None, async_op=False):
     return works
 
 
+def all_reduce_lazy(scratch_views, flat, small_idx, group=None, async_op=False):
+    """Lazy gradients: SUM all-reduce of every bucket's scratch view (conv weight gradients in the kernels' own layout: a sum
+    does not care) and of the other tensors of the flat buffer, gathered into one small message (BatchNorm, fc, motion head,
+    stem: ~150 k of the 21.4 M elements).  Returns (works, finish): call finish() once the works are done to scatter the
+    small message back."""
+    works = []
+    for v in scratch_views:
+        if v.numel():
+            w = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            if async_op:
+                works.append(w)
+    small = flat.index_select(0, small_idx)
+    w = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    if async_op:
+        works.append(w)
+    return works, (lambda: flat.index_copy_(0, small_idx, small))
+
+
 class GradBucketReducer:
     """Overlaps the bucket all-reduces with backward: libvpdhip records one HIP
     event per bucket on the compute stream; the comm stream waits on it and
@@ -59,21 +77,40 @@ class GradBucketReducer:
         self._ensure_events(nbuckets)
         return [e.cuda_event for e in self.events[:nbuckets]]
 
-    def reduce(self, plan):
+    def reduce(self, plan, lazy=False):
+        """lazy: the backward left the conv weight gradients in the plan's scratch (engine.backward(events, lazy=True)): the
+        bucket messages are the scratch ranges, the rest of the flat buffer travels as one small message behind the last."""
         cur = torch.cuda.current_stream(self.engine.device)
-        if os.environ.get("VPD_DDP_OVERLAP", "1") == "0":
+        flat = self.engine._grads
+        self.overlap = os.environ.get("VPD_DDP_OVERLAP", "1") != "0"
+        if not self.overlap:
             # diagnostic: no overlap -- all buckets reduced in line after backward (RCCL's persistent kernels
             # hold CUs; whether overlapping them with 1-block-per-CU conv kernels pays is a measurement, not a given)
-            all_reduce_buckets(self.engine.grads, plan.buckets, self.group, async_op=False)
+            if lazy:
+                _, finish = all_reduce_lazy(plan.scratch_views, flat, plan.small_idx, self.group, async_op=False)
+                finish()
+            else:
+                all_reduce_buckets(flat, plan.buckets, self.group, async_op=False)
             return
         works = []
         with torch.cuda.stream(self.comm_stream):
             assert len(self.events) >= len(plan.buckets), "backward() was not given this plan's bucket events"
-            for ev, (off, numel) in zip(self.events, plan.buckets):
+            finish = None
+            for b, (ev, (off, numel)) in enumerate(zip(self.events, plan.buckets)):
                 self.comm_stream.wait_event(ev)
-                works += all_reduce_buckets(self.engine.grads, [(off, numel)], self.group, async_op=True)
+                if lazy:
+                    v = plan.scratch_views[b]
+                    if v.numel():
+                        works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if b == len(plan.buckets) - 1:      # everything else, once the whole backward is done
+                        w2, finish = all_reduce_lazy([], flat, plan.small_idx, self.group, async_op=True)
+                        works += w2
+                else:
+                    works += all_reduce_buckets(flat, [(off, numel)], self.group, async_op=True)
             for w in works:
                 w.wait()                 # comm stream waits for RCCL
+            if finish is not None:
+                finish()
         cur.wait_stream(self.comm_stream)
 
     def all_reduce_scalars(self, loss_sum, count):

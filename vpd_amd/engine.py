@@ -83,6 +83,16 @@ class _Plan:
             self.buckets.append((o.value, m.value))
         self.packed_version = None
         self.graph_sizes = set()
+        # lazy gradients under data parallelism: bucket b's conv weight gradients as a view of the workspace (the kernels' own
+        # layout), and the flat-buffer positions of everything else (BatchNorm, fc, motion head, the stem conv)
+        self.scratch_views, self.small_idx = [], None
+        if train:
+            for b in range(len(self.buckets)):
+                check(L.vpd_plan_bucket_scratch_range(handle, b, C.byref(o), C.byref(m)), "vpd_plan_bucket_scratch_range")
+                self.scratch_views.append(self.workspace[o.value:o.value + 4 * m.value].view(torch.float32))
+            small = [(off_, n_) for i, (kind_, _, off_, n_, _) in enumerate(rows) if kind_ != 0 or i == 0]
+            self.small_ranges = small
+            self.small_idx = torch.cat([torch.arange(a, a + n_, dtype=torch.int64) for a, n_ in small]).to(eng.device)
 
     def bn_table(self):
         L = lib()
@@ -273,7 +283,7 @@ class StudentEngine:
 
     def backward(self, events=None, lazy=False):
         """lazy: leave the conv weight gradients in the weight-gradient kernels' scratch layout for the fused optimizer step
-        (ignored with bucket events, i.e. under data parallelism: the reducer works on the flat buffer)."""
+        (with bucket events, i.e. under data parallelism, the reducer must then be told: reduce(plan, lazy=True))."""
         if self._last is None:
             raise RuntimeError("backward() without a preceding train-mode forward with a target")
         pl, n = self._last
@@ -283,7 +293,7 @@ class StudentEngine:
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
-        if lazy and ev is None:
+        if lazy:      # (with bucket events the reducer sums the scratch ranges: GradBucketReducer.reduce(plan, lazy=True))
             check(lib().vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
         check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
                                  self._stream()), "vpd_backward")

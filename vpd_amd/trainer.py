@@ -115,8 +115,11 @@ class ModelTrainer:
         eng = self.encoder.engine
         if self._reducer is not None:
             nb = len(eng._last[0].buckets) if eng._last is not None else 0      # (backward() raises without a forward)
-            pl = eng.backward(self._reducer.event_handles(nb))
-            self._reducer.reduce(pl)
+            # lazy gradients stay on under data parallelism: a SUM all-reduce is layout-agnostic, so the reducer sums the
+            # weight-gradient scratch ranges + the small tensors of the flat buffer (VPD_DDP_LAZY=0: flat buffer, eager unpack)
+            lazy = lazy and os.environ.get("VPD_DDP_LAZY", "1") != "0"
+            pl = eng.backward(self._reducer.event_handles(nb), lazy=lazy)
+            self._reducer.reduce(pl, lazy=lazy)
         else:
             eng.backward(lazy=lazy)
         if not lazy:
