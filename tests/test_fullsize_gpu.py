@@ -230,6 +230,12 @@ from oracle import vpd_oracle as O
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 EMB_TOL, LOSS_TOL = 2e-2, 1e-2
+# TRAIN-mode embeddings (batch statistics): every conv output z is stored in bf16, its statistics are taken over the rounded
+# values and the normalised activation is rounded again -- two roundings per layer where the eval forward (BatchNorm folded
+# into the conv epilogue, applied to the fp32 accumulators) has one.  Measured with the oracle's emulate_bf16 mode (the same
+# algorithm and rounding points on the CPU) against the reference's fp32 emb_train: per-sample 0.034 mean / 0.035 max at 8
+# crops, 0.034 / 0.042 at 64 crops (ResNet-34, procedural weights); the HIP path measures 0.030-0.041 at 256 crops.
+TRAIN_EMB_TOL = 6e-2
 
 
 def _golden_build(meta):
@@ -293,7 +299,7 @@ def test_fullsize_values_match_the_reference(name):
     assert abs(l_hip - float(g["loss_train"])) <= LOSS_TOL * abs(float(g["loss_train"])), rec["loss_train"]
     ps = _per_sample_rel(emb.cpu().numpy(), g["emb_train"])
     rec["emb_train_per_sample_max"] = float(ps.max())
-    assert ps.max() <= EMB_TOL, float(ps.max())
+    assert ps.max() <= TRAIN_EMB_TOL, float(ps.max())
     if meta["level"] == "light":
         return
     # full: gradients (per-stage norms against the reference's recorded norms), running statistics after the step
