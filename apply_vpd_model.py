@@ -22,10 +22,12 @@ def get_args():
     parser.add_argument('--jitter', type=int, help='Create additional jittered features.')
     parser.add_argument('--no_flip', action='store_true', help='Do not embed horizontal flips')
     parser.add_argument('--flow_img', type=str)
+    parser.add_argument('--host_fp32', action='store_true',
+                        help='(this build) hand fp32 views across like the reference instead of u8 frames + device-side views')
     return parser.parse_args()
 
 
-def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
+def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip, host_fp32=False):
     device = 'cuda'
     model_params = load_json(os.path.join(model_dir, 'config.json'))
     emb_dim = model_params['emb_dim']
@@ -48,8 +50,11 @@ def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
         videos, tasks = list_tennis_crops(dataset_paths.TENNIS_VIDEO_DIR, dataset_paths.TENNIS_CROP_DIR)
     else:
         videos, tasks = list_crop_dir(dataset_paths.CROPS[dataset])
+    # default: decoded u8 frames cross PCIe (82 KB instead of 655 KB per frame) and the views [orig, h-flip] are built on the
+    # device; --jitter needs the host fp32 views (ColorJitter on the normalised image, single_frame.py:366-379)
+    raw_u8 = not host_fp32 and not jitter
     ds = FrameDataset(tasks, img_dim, rgb_mean_std, augment_jitter=jitter or 0, augment_flip=not no_flip,
-                      flow_img_name=flow_img)
+                      flow_img_name=flow_img, raw_u8=raw_u8)
 
     model_name = 'best_epoch' if model_epoch is None else 'epoch{:04d}'.format(model_epoch)
     print('Model name:', model_name)
@@ -64,7 +69,12 @@ def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip):
     frames_per_video = [0] * len(videos)
     for t in tasks:
         frames_per_video[t[0]] += 1
-    embed_dataset(encoder, loader, len(videos), writer=StreamingWriter(out_dir, videos, frames_per_video))
+    augmenter = None
+    if raw_u8:
+        from vpd_amd.augment import CropAugmenter
+        augmenter = CropAugmenter(device, rgb_mean_std, img_dim, use_flow)
+    embed_dataset(encoder, loader, len(videos), writer=StreamingWriter(out_dir, videos, frames_per_video),
+                  augmenter=augmenter, flip=not no_flip)
     print('Done!')
 
 

@@ -433,6 +433,18 @@ def synthetic_crops(n: int, c_in: int, hw: int, seed: int, mean_std=None) -> tor
     return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
 
 
+def synthetic_crops_u8(n: int, c_in: int, hw: int, seed: int):
+    """The decoded u8 frames synthetic_crops(n, c_in, hw, seed) is made of (same draws): rgb u8 [n, hw, hw, 3] and, for
+    c_in = 5, flow u8 [n, hw, hw, 2] -- what the crop PNGs hold before vpd_dataset/common.py:52-69 turns them into floats."""
+    rs = np.random.RandomState(seed)
+    rgb = rs.randint(0, 256, size=(n, 3, hw, hw)).astype(np.uint8)
+    flow = None
+    if c_in > 3:
+        flow = np.clip(np.round(124 + 12 * rs.standard_normal((n, c_in - 3, hw, hw))), 0, 255).astype(np.uint8)
+        flow = torch.from_numpy(np.ascontiguousarray(flow.transpose(0, 2, 3, 1)))
+    return torch.from_numpy(np.ascontiguousarray(rgb.transpose(0, 2, 3, 1))), flow
+
+
 def synthetic_targets(n: int, emb_dim: int, motion: bool, seed: int) -> torch.Tensor:
     rs = np.random.RandomState(seed)
     t = rs.standard_normal((n, emb_dim)).astype(np.float32)

@@ -121,3 +121,54 @@ def test_train_cli_default_flags_run_the_reference_recipe_on_the_device(tmp_path
     train_vpd_model.main(**vars(train_vpd_model.get_args()))
     assert calls["stage"] == 0
     assert json.load(open(tmp_path / "b" / "config.json"))["augment"].startswith("cpu")
+
+
+def test_u8_apply_path_matches_reference_golden_and_the_fp32_views(tmp_path):
+    """decoded u8 frames cross PCIe and the views are built on the device (normalise, flow decode, h-flip
+    with x-flow negation) straight into the stem's staging buffer.
+    * k = 1: the frames behind the reference-written golden pickles (tests/golden/format, k1) through the u8 path give
+      the golden embeddings within EMB_TOL (the reference's loop: apply_vpd_model.py:146-178);
+    * k = 2: the pair [orig, h-flip] of every frame equals, bit for bit, what the fp32 path gives for FrameDataset's own
+      views of the same frame in the same order (vpd_dataset/single_frame.py:377-400: flip = torch.flip(img, (2,)), flow
+      flipped with channel 0 negated)."""
+    from vpd_amd.apply import StreamingWriter, embed_dataset
+    from vpd_amd.augment import CropAugmenter
+    from vpd_amd.io import load_pickle
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    g = np.load(os.path.join(REPO, "tests", "golden", "format_case.npz"))
+    arch, D, c_in, hw = "resnet18", 32, 5, 64
+    enc = RGBF_EmbeddingModel(arch, D, True, "cuda")
+    enc.load_state_dict(O.procedural_state_dict(O.encoder_schema(arch, c_in, D), 5))
+    aug = CropAugmenter("cuda", O.DIVING48_MEAN_STD, hw, True)
+    videos = ["vidA", "vidB", "vidC"]
+    tasks = g["tasks"]
+    rgb, flow = O.synthetic_crops_u8(len(tasks), c_in, hw, 21)
+    # the u8 frames really are what the golden's float crops were made of
+    ref_f = O.synthetic_crops(len(tasks), c_in, hw, 21)
+    mk = lambda: [{"video": torch.tensor(tasks[s:s + 5, 0]), "frame": torch.tensor(tasks[s:s + 5, 1]),
+                   "rgb_u8": rgb[s:s + 5], "flow_u8": flow[s:s + 5]} for s in range(0, len(tasks), 5)]
+    fpv = [0, 0, 0]
+    for v, _ in tasks:
+        fpv[v] += 1
+    out = tmp_path / "k1"
+    embed_dataset(enc, mk(), len(videos), writer=StreamingWriter(str(out), videos, fpv), augmenter=aug, flip=False)
+    for v in videos:
+        embs = load_pickle(str(out / ("%s.emb.pkl" % v)))
+        assert all(isinstance(t[0], int) and t[1].dtype == np.float32 and t[1].shape == (D,) and t[2] == {} for t in embs)
+        dense, mask = group_by_frame(embs)
+        ref = g["dense/k1/%s" % v]
+        assert np.array_equal(mask, g["mask/k1/%s" % v])
+        assert np.linalg.norm(dense - ref) / np.linalg.norm(ref) <= 2e-2
+    # k = 2 against the fp32 views of the same frames
+    flipped = torch.flip(ref_f, (3,)).clone()
+    flipped[:, 3, :, :] *= -1                                     # x-flow of the mirrored view
+    views = torch.stack([ref_f, flipped], dim=1)                  # [n, 2, C, H, W]: [orig, flip]
+    fp32 = embed_dataset(enc, [{"video": torch.tensor(tasks[s:s + 5, 0]), "frame": torch.tensor(tasks[s:s + 5, 1]),
+                                "img": views[s:s + 5]} for s in range(0, len(tasks), 5)], len(videos))
+    u8 = embed_dataset(enc, mk(), len(videos), augmenter=aug, flip=True)
+    for a, b in zip(fp32, u8):
+        assert len(a) == len(b) > 0
+        for (fa, ea, _), (fb, eb, _) in zip(sorted(a, key=lambda t: t[0]), sorted(b, key=lambda t: t[0])):
+            assert fa == fb and ea.shape == eb.shape == (2, D)
+            assert np.array_equal(ea, eb), float(np.abs(ea - eb).max())
+            assert not np.array_equal(eb[0], eb[1])               # the flipped view is a different crop

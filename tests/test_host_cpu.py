@@ -277,3 +277,32 @@ def test_wgrad128_schedule_covers_every_task_once_and_balances():
         lower = max(sum(lens) / G, max(lens))
         assert max(load) <= 4.0 / 3.0 * lower + max(lens) * 0.34 + 1e-9, (name, max(load), lower)
         assert est.value > 0
+
+
+def test_frame_dataset_u8_items_equal_the_float_items(tmp_path):
+    """FrameDataset(raw_u8=True) reads the same PNGs as the float path: decoding its u8 item the way the reference does
+    (vpd_dataset/common.py:52-69: /255, normalise; flow channels as cv2 reads them, /255 - 0.5) gives the float item."""
+    from PIL import Image
+    from vpd_amd.data import FrameDataset, RGB_MEAN_STD
+    rs = np.random.RandomState(3)
+    d = tmp_path / "crops" / "vid0"
+    d.mkdir(parents=True)
+    tasks = []
+    for f in range(3):
+        Image.fromarray(rs.randint(0, 256, (64, 64, 3)).astype(np.uint8)).save(str(d / ("%d.png" % f)))
+        Image.fromarray(rs.randint(0, 256, (64, 64, 3)).astype(np.uint8)).save(str(d / ("%d.raft.png" % f)))
+        tasks.append((0, f, str(d / str(f))))
+    ms = RGB_MEAN_STD["diving48"]
+    fl = FrameDataset(tasks, 64, ms, augment_flip=True, flow_img_name="raft")
+    u8 = FrameDataset(tasks, 64, ms, augment_flip=True, flow_img_name="raft", raw_u8=True)
+    mean = torch.tensor(ms[0]).view(3, 1, 1)
+    std = torch.tensor(ms[1]).view(3, 1, 1)
+    for i in range(3):
+        a, b = fl[i], u8[i]
+        assert (a["video"], a["frame"]) == (b["video"], b["frame"])
+        assert b["rgb_u8"].dtype == torch.uint8 and tuple(b["rgb_u8"].shape) == (64, 64, 3) and tuple(b["flow_u8"].shape) == (64, 64, 2)
+        rgb = (b["rgb_u8"].permute(2, 0, 1).float() / 255. - mean) / std
+        flow = (b["flow_u8"].permute(2, 0, 1).double() / 255. - 0.5).float()
+        assert torch.equal(torch.cat([rgb, flow]), a["img"][0])
+    with pytest.raises(ValueError):
+        FrameDataset(tasks, 64, ms, augment_jitter=2, raw_u8=True)

@@ -53,9 +53,14 @@ class StreamingWriter:
                 self.flush(vid)
 
 
-def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, writer=None):
+def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, writer=None, augmenter=None, flip=True):
     """loader yields {'video': int[n], 'frame': int[n], 'img': f32[n,k,C,H,W]} -> list per video, or, with
     `writer` (a StreamingWriter), pickles written as videos complete (returns None).
+
+    Raw batches {'video', 'frame', 'rgb_u8': u8[n,H,W,3], 'flow_u8': u8[n,H,W,2]} (FrameDataset(raw_u8=True)) need
+    `augmenter` (a vpd_amd.augment.CropAugmenter with the model's mean / std): 82 KB per frame cross PCIe instead of the
+    655 KB of two fp32 views, and the views [orig, h-flip] (`flip`) are built on the device in the stem's staging buffer
+    (same values as FrameDataset's fp32 views, vpd_dataset/single_frame.py:377-400).
 
     The embeddings of batch i travel to a pinned host buffer asynchronously; the host turns batch i-1 into tuples
     (and pickles) while the GPU runs batch i."""
@@ -85,6 +90,38 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
     for batch in loader:
         video_ids = batch['video'].tolist() if hasattr(batch['video'], 'tolist') else list(batch['video'])
         frame_nums = batch['frame'].tolist() if hasattr(batch['frame'], 'tolist') else list(batch['frame'])
+        if 'rgb_u8' in batch:
+            if augmenter is None:
+                raise RuntimeError("raw u8 batches need embed_dataset(..., augmenter=CropAugmenter(...))")
+            assert (batch.get('flow_u8') is not None) == bool(encoder.use_flow), 'Wrong number of channels'
+            n_batch, k = batch['rgb_u8'].shape[0], (2 if flip else 1)
+            rgb = batch['rgb_u8'].to(eng.device, non_blocking=True).contiguous()
+            flow = batch['flow_u8'].to(eng.device, non_blocking=True).contiguous() if encoder.use_flow else None
+            n, hw = augmenter.stage_views(eng, rgb, flow, flip)
+            key = ('staged', n, hw)
+            ent = graphs.get(key) if use_graph else None
+            if ent is not None and not (ent[0].handle and n in ent[0].graph_sizes and eng._plans.get((hw, hw, False, False)) is ent[0]):
+                ent = None
+            if use_graph:
+                if ent is None:
+                    out = torch.empty((n, encoder.emb_dim), dtype=torch.float32, device=eng.device)
+                    ent = graphs[key] = (eng.capture_eval_graph_staged(n, hw, out), None, out)
+                    augmenter.stage_views(eng, rgb, flow, flip)      # (a larger plan may have been built: stage again)
+                pl, _, out = ent
+                eng.launch_eval_graph(pl, n)
+            else:
+                out = eng.forward_eval(None, staged=(n, hw))
+            slot ^= 1
+            if (n, slot) not in host:
+                host[(n, slot)] = torch.empty((n, encoder.emb_dim), dtype=torch.float32).pin_memory()
+            hbuf = host[(n, slot)]
+            hbuf.copy_(out, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(eng.device))
+            if inflight is not None:
+                drain(inflight)
+            inflight = (ev, hbuf, video_ids, frame_nums, n_batch, k)
+            continue
         n_batch, k, c, h, w = batch['img'].shape
         x = batch['img'].reshape(-1, c, h, w)
         if encoder.use_flow:

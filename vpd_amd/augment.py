@@ -155,3 +155,26 @@ class CropAugmenter:
         engine.stage_crops(rgb_u8, flow_u8, mask_u8, pdev, noise, self.img_dim, self.mean_std6, self.noise_sd,
                            self._scratch, train, motion)
         return n, self.img_dim
+
+    def stage_views(self, engine, rgb_u8, flow_u8, flip):
+        """Inference views of FrameDataset (vpd_dataset/single_frame.py:377-400) for n decoded frames, written straight into
+        the EVAL plan's stem staging buffer: k = 2 views per frame in the order [orig, h-flip] (x-flow negated in the flipped
+        view) when `flip`, else the frame itself.  Returns (n * k, img_dim) for forward_eval / the staged eval graph."""
+        n, h, w, _ = rgb_u8.shape
+        k = 2 if flip else 1
+        key = (n, k, h, w)
+        cache = self.__dict__.setdefault('_view_params', {})
+        if key not in cache:
+            p = identity_params(n * k, h, w)
+            if flip:
+                p['flip'][1::2] = 1
+            cache[key] = (p, torch.from_numpy(p.view(np.uint8).reshape(n * k, 64)).to(self.device))
+        p, pdev = cache[key]
+        if k == 2:
+            rgb_u8 = rgb_u8.repeat_interleave(2, dim=0)
+            flow_u8 = flow_u8.repeat_interleave(2, dim=0) if flow_u8 is not None else None
+        if self._scratch is None or self._scratch.numel() < 8 * n * k:
+            self._scratch = torch.empty(8 * max(n * k, 256), dtype=torch.float32, device=self.device)
+        engine.stage_crops(rgb_u8, flow_u8, None, pdev, None, self.img_dim, self.mean_std6, self.noise_sd, self._scratch,
+                           False, False)
+        return n * k, self.img_dim

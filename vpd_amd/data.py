@@ -50,6 +50,20 @@ def _load_png(path, img_dim):
     return np.asarray(im, dtype=np.float32)          # H, W, 3 (RGB)
 
 
+def load_rgb_u8(path, img_dim):
+    """The decoded crop as it is stored: u8 [H, W, 3] (RGB).  Normalisation happens on the device (vpd_amd.augment)."""
+    from PIL import Image
+    im = Image.open(path).convert('RGB')
+    if im.size != (img_dim, img_dim):
+        im = im.resize((img_dim, img_dim), Image.BILINEAR)
+    return np.asarray(im, dtype=np.uint8)
+
+
+def load_flow_u8(path, img_dim):
+    """u8 [H, W, 2]: the two channels load_flow keeps (cv2's BGR channels 0 and 1 of the RGB-ordered PNG), undecoded."""
+    return np.ascontiguousarray(load_rgb_u8(path, img_dim)[:, :, ::-1][:, :, :2])
+
+
 def load_rgb(path, img_dim, rgb_mean_std):
     rgb = torch.from_numpy(_load_png(path, img_dim)).permute(2, 0, 1) / 255.
     mean = torch.tensor(rgb_mean_std[0]).view(3, 1, 1)
@@ -60,7 +74,8 @@ def load_rgb(path, img_dim, rgb_mean_std):
 def load_flow(path, img_dim):
     # raft/flow.py:80-84 stores (fx, fy, 128) as RGB-ordered PNG channels read back by cv2 as BGR;
     # vpd_dataset/common.py:69 keeps cv2 channels 0 and 1
-    arr = _load_png(path, img_dim)[:, :, ::-1][:, :, :2].copy()
+    # (u8 / 255 - 0.5 in float64, rounded to fp32 once: numpy's arithmetic on the reference's uint8 array, common.py:69)
+    arr = _load_png(path, img_dim)[:, :, ::-1][:, :, :2].astype(np.float64)
     return torch.from_numpy(arr / 255. - 0.5).permute(2, 0, 1).float()
 
 
@@ -264,16 +279,29 @@ class FrameDataset(torch.utils.data.Dataset):
     """Inference items {'video', 'frame', 'img': [k, C, H, W]}: views [orig, j x jitter(orig), j x jitter(flip), flip]
     (reference vpd_dataset/single_frame.py:361-403, order of Appendix B.8)."""
 
-    def __init__(self, tasks, img_dim, rgb_mean_std, augment_jitter=0, augment_flip=False, flow_img_name=None):
+    def __init__(self, tasks, img_dim, rgb_mean_std, augment_jitter=0, augment_flip=False, flow_img_name=None, raw_u8=False):
+        """raw_u8: items are {'video', 'frame', 'rgb_u8': u8[H,W,3], 'flow_u8': u8[H,W,2]} -- the decoded PNGs as stored,
+        82 KB per frame instead of 655 KB of fp32 views; vpd_amd.apply.embed_dataset builds the views [orig, flip] on the
+        device (normalise, flow decode, h-flip with x-flow negation).  Jittered views need the host path (ColorJitter on
+        the NORMALISED image, Appendix B.8)."""
         self.jitter_count = int(augment_jitter or 0)
         self.tasks, self.img_dim, self.rgb_mean_std = tasks, img_dim, rgb_mean_std
         self.flip, self.flow_img_name = augment_flip, flow_img_name
+        self.raw_u8 = bool(raw_u8)
+        if self.raw_u8 and self.jitter_count:
+            raise ValueError('raw_u8 items carry no jittered views: use the fp32 path with --jitter')
 
     def __len__(self):
         return len(self.tasks)
 
     def __getitem__(self, idx):
         video, frame_num, prefix = self.tasks[idx]
+        if self.raw_u8:
+            item = {'video': video, 'frame': frame_num,
+                    'rgb_u8': torch.from_numpy(load_rgb_u8('{}.png'.format(prefix), self.img_dim))}
+            if self.flow_img_name is not None:
+                item['flow_u8'] = torch.from_numpy(load_flow_u8('{}.{}.png'.format(prefix, self.flow_img_name), self.img_dim))
+            return item
         img = load_rgb('{}.png'.format(prefix), self.img_dim, self.rgb_mean_std)
         imgs = [img] + [color_jitter(img) for _ in range(self.jitter_count)]
         flips = []

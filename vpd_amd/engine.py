@@ -349,6 +349,19 @@ class StudentEngine:
         pl.graph_sizes.add(n)
         return pl
 
+    def capture_eval_graph_staged(self, n, img_dim, out):
+        """hipGraph of the eval forward for n crops whose input is ALREADY in the plan's stem staging buffer (stage_crops /
+        CropAugmenter.stage_views): the graph starts at the stem convolution."""
+        pl = self.plan(img_dim, img_dim, n, False, False)
+        self._ensure_packed(pl)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        check(lib().vpd_graph_capture_eval(pl.handle, _ptr(self.params), None, n, _ptr(out), _ptr(pl.workspace),
+                                           C.c_void_p(side.cuda_stream)), "vpd_graph_capture_eval")
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        pl.graph_sizes.add(n)
+        return pl
+
     def sync_errors(self):
         """Grid-barrier time-outs counted by the train plans since their workspaces were initialised (host sync).
         Non-zero = a fused BatchNorm launch gave up waiting for its grid: results are not to be trusted."""
