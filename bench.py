@@ -205,8 +205,33 @@ def apply_block(enc, device, batches=12, warmup=3):
         eng.launch_eval_graph(pl, n)
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    # the loop as apply_vpd_model.py runs it by default: decoded u8 frames from pinned host memory (82 KB per frame), views
+    # [orig, h-flip] built on the device, hipGraph forward, D2H of the embeddings, per-video tuple lists
+    from vpd_amd.apply import embed_dataset
+    from vpd_amd.augment import CropAugmenter
+    aug = CropAugmenter(device, DIVING48_MEAN_STD, HW, True)
+    gc = torch.Generator().manual_seed(2)
+    pool = [(torch.randint(0, 256, (frames, HW, HW, 3), generator=gc, dtype=torch.uint8).pin_memory(),
+             torch.randint(100, 150, (frames, HW, HW, 2), generator=gc, dtype=torch.uint8).pin_memory()) for _ in range(2)]
+
+    def loader(nb):
+        for b in range(nb):
+            idx = torch.arange(b * frames, (b + 1) * frames)
+            yield {"video": idx // 157, "frame": idx % 157, "rgb_u8": pool[b % 2][0], "flow_u8": pool[b % 2][1]}
+    embed_dataset(enc, loader(warmup), warmup * frames // 157 + 1, augmenter=aug, flip=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    embs = embed_dataset(enc, loader(batches), batches * frames // 157 + 1, augmenter=aug, flip=True)
+    torch.cuda.synchronize(device)
+    dt_u8 = time.perf_counter() - t0
+    assert sum(len(v) for v in embs) == batches * frames
     enc.train()
     return {"tflops": batches * n / dt * FWD_FLOP_PER_CROP / 1e12,
+            "loop_host_u8": {"value": batches * n / dt_u8, "unit": "crops/s",
+                             "what": "vpd_amd.apply.embed_dataset on %d batches of %d u8 frames from pinned host memory: H2D, "
+                                     "device-side views, hipGraph forward, D2H, tuple assembly (the 1 M-crop job with one pickle "
+                                     "per video: profiles/r03_apply_bench_1M.json, tools/bench_apply.py --crops 1000000)"
+                                     % (batches, frames)},
             "frac_of_mfma_peak": batches * n / dt * FWD_FLOP_PER_CROP / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
             "workload": "configs[4]-shaped: %d hipGraph launches of %d frames x %d views (1000 crops), eval forward, "
                         "inputs resident" % (batches, frames, k),

@@ -95,9 +95,31 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
                 raise RuntimeError("raw u8 batches need embed_dataset(..., augmenter=CropAugmenter(...))")
             assert (batch.get('flow_u8') is not None) == bool(encoder.use_flow), 'Wrong number of channels'
             n_batch, k = batch['rgb_u8'].shape[0], (2 if flip else 1)
-            rgb = batch['rgb_u8'].to(eng.device, non_blocking=True).contiguous()
-            flow = batch['flow_u8'].to(eng.device, non_blocking=True).contiguous() if encoder.use_flow else None
+            # H2D on a copy stream into one of two device slots: batch i + 1 crosses PCIe while batch i's forward runs
+            cur = torch.cuda.current_stream(eng.device)
+            cp = eng.__dict__.setdefault("_apply_copy_stream", None) or torch.cuda.Stream(device=eng.device)
+            eng._apply_copy_stream = cp
+            ubuf = eng.__dict__.setdefault("_apply_u8", {})
+            uslot = eng.__dict__.get("_apply_u8_slot", 0) ^ 1
+            eng._apply_u8_slot = uslot
+            ukey = (tuple(batch['rgb_u8'].shape), uslot)
+            if ukey not in ubuf:
+                ubuf[ukey] = [torch.empty(tuple(batch['rgb_u8'].shape), dtype=torch.uint8, device=eng.device),
+                              torch.empty(tuple(batch['rgb_u8'].shape[:3]) + (2,), dtype=torch.uint8, device=eng.device)
+                              if encoder.use_flow else None, None]
+            rgb, flow, freed = ubuf[ukey]
+            with torch.cuda.stream(cp):
+                if freed is not None:
+                    cp.wait_event(freed)             # the staging launch that last read this slot is done
+                rgb.copy_(batch['rgb_u8'], non_blocking=True)
+                if flow is not None:
+                    flow.copy_(batch['flow_u8'], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(cp)
+            cur.wait_event(landed)
             n, hw = augmenter.stage_views(eng, rgb, flow, flip)
+            ubuf[ukey][2] = torch.cuda.Event()
+            ubuf[ukey][2].record(cur)
             key = ('staged', n, hw)
             ent = graphs.get(key) if use_graph else None
             if ent is not None and not (ent[0].handle and n in ent[0].graph_sizes and eng._plans.get((hw, hw, False, False)) is ent[0]):
@@ -107,6 +129,7 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
                     out = torch.empty((n, encoder.emb_dim), dtype=torch.float32, device=eng.device)
                     ent = graphs[key] = (eng.capture_eval_graph_staged(n, hw, out), None, out)
                     augmenter.stage_views(eng, rgb, flow, flip)      # (a larger plan may have been built: stage again)
+                    ubuf[ukey][2].record(cur)
                 pl, _, out = ent
                 eng.launch_eval_graph(pl, n)
             else:
