@@ -1092,6 +1092,9 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 // conv3x3_pws_kernel (conv_pws.h): persistent blocks, LDS flag hand-off.  VPD_PWS=0 restores conv3x3_ws_kernel.
 // ---------------------------------------------------------------------------
 // ring depths per tile class (NS = A + 2: two readable steps + A weight bundles in flight); -D overrides for same-box A/B builds
+#ifndef PWS_L1_DEFAULT
+#define PWS_L1_DEFAULT 0
+#endif
 #ifndef PWS_PREFER_C6
 #define PWS_PREFER_C6 0
 #endif
@@ -1554,8 +1557,13 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             static const int w64 = getenv("VPD_WS_256x64") ? atoi(getenv("VPD_WS_256x64")) : 1;
             if (w64 && t128 >= 200 && (long)((p.M + 255) / 256) * (p.Co / 64) >= 200 && halo_geom(p, 256, 416, g)) return 6;
             if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 3;    // few pixel tiles: 64-channel tiles fill the chip
-        } else if (p.Kc == 64 && p.Co == 64 && halo_geom(p, 128, 224, g)) {
-            return 0;      // 64 -> 64 channels (layer1): persistent blocks with resident weights
+        } else if (p.Kc == 64 && p.Co == 64) {
+            // 64 -> 64 channels (layer1).  VPD_PWS_L1: 256 x 64 tiles on the pipelined persistent kernel (64 x 64 wave tiles: 0.5
+            // fragment reads per MFMA instead of the 0.75 of conv3x3_c64_persistent_kernel's 32 x 64, whose LDS pipe is 75 % busy);
+            // the nine weight taps are re-streamed per tile (8 KB per K-step out of L2) instead of staying resident
+            static const int l1 = getenv("VPD_PWS_L1") ? atoi(getenv("VPD_PWS_L1")) : PWS_L1_DEFAULT;
+            if (l1 && pws_enabled(p) && halo_geom(p, 256, 416, g)) return 6;
+            if (halo_geom(p, 128, 224, g)) return 0;      // persistent blocks with resident weights
         }
     }
     return 4;

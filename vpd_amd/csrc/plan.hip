@@ -717,7 +717,8 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         flops += conv_flops(av, c.n);
     }
     const int kc = vpd_conv_kernel_class(q);
-    TimeScope ts(c.p, c.s, kc == 5 ? 7 : (kc == 6 ? 2 : kc), flops);      // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2
+    // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2 -- except layer1's 64 -> 64 convs, which stay in slot 0
+    TimeScope ts(c.p, c.s, kc == 5 ? 7 : (kc == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kc), flops);
     return vpd_launch_conv(q, c.s);
 }
 
@@ -815,7 +816,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
             q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
         }
         const int kcd = vpd_conv_kernel_class(q);
-        TimeScope ts(c.p, c.s, kcd == 6 ? 2 : kcd, conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, kcd == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kcd, conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
     if (bnb) return hipErrorInvalidValue;
