@@ -577,6 +577,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         const int lw = wave - 4;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
+        const float rWp = 1.0f / (float)Wp;
         auto issue_halo = [&](int mtile, int buf) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
             int prow0;
@@ -586,9 +587,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
 #pragma unroll
             for (int k = 0; k < HPASS; ++k) {
                 const int hp = (lw + 4 * k) * 8 + lrow;
+                // halo pixel hp = (row hr, column xp) of the padded tile keeps its 16-byte pieces XOR-ed with the COLUMN's low bits
+                // (HaloGeom::kmask; 16-pixel fragments lie inside one image row here): the MFMA waves' fragment addresses then
+                // split into a per-lane constant per tap column and a wave-uniform term (see `lo` below)
+                const int hr = vpd_fdiv(hp, rWp);
+                const int key = (hp - hr * Wp) & 7;
                 int gp = gp0 + hp;
                 gp = gp < g.total_pix ? gp : g.total_pix - 1;
-                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ (hp & 7)) << 3);
+                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ key) << 3);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
             }
         };
@@ -619,15 +625,24 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
     const int wm = wave;                                          // WN == 1
     const int fr = lane & 15;
     const int fq = lane >> 4;
-    int hbase[MI];
+    // pixel-fragment LDS byte offsets inside a halo buffer for tap column ic (K-half 0; K-half 1 = ^ 64): with the column-keyed
+    // swizzle the lane-dependent part is tap-ROW independent, so a tap's address is lo[ic][b] + (wave-uniform row term) -- one
+    // VALU add instead of five per fragment (this kernel's LDS pipe and issue slots, not its MFMAs, bound it)
+    unsigned lo[3][MI];
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = wm * WTM + b * 16 + fr;
         const int lr = m / W;
         const int xx = m - lr * W;
         const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
-        hbase[b] = hrow * Wp + xx;
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic)
+            lo[ic][b] = (unsigned)((hrow * Wp + xx) * 128) + ((((unsigned)(xx + p.taps.dx0 + ic * p.taps.dxs) & 7u) ^ (unsigned)fq) << 4);
     }
+    // weight-fragment byte offset of this lane inside a tap's [64][64] tile (row fr, K-half 0; rows a * 16 + fr: + a * 2048)
+    const unsigned wl0 = (unsigned)(fr * 128 + ((fq ^ (fr & 7)) << 4));
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    typedef const bf16x8 __attribute__((address_space(3)))* frag_t;
     // statistics stay in registers across this block's tiles: one reduction + 128 atomics per BLOCK, not per tile
     float st1[NI][4], st2[NI][4];
 #pragma unroll
@@ -653,17 +668,20 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         // 128 cycles of matrix work).
         bf16x8 af[2][NI], bfm[2][MI];
         // fragment i of step st: 0 -> af[0], 1 -> bfm[0], 2 -> bfm[1], 3.. -> af[1..] (the order the MFMAs below first need them)
+        // (row term of tap row ir: halo buffer + (dy * Wp + dx0) * 128, wave-uniform)
+        const unsigned hbb = lds0 + (unsigned)(9 * BN * 64 * 2) + (unsigned)(i & 1) * (HBUF * 2u);
+        const unsigned rowS[3] = {hbb + (unsigned)(((p.taps.dy0) * Wp + p.taps.dx0) * 128),
+                                  hbb + (unsigned)(((p.taps.dy0 + p.taps.dys) * Wp + p.taps.dx0) * 128),
+                                  hbb + (unsigned)(((p.taps.dy0 + 2 * p.taps.dys) * Wp + p.taps.dx0) * 128)};
+        const int dxs128 = p.taps.dxs * 128;
         auto ldone = [&](int st, int buf, int i) __attribute__((always_inline)) {
             const int tap = st >> 1, kk = st & 1;
-            const int chunk = kk * 4 + fq;
             if (i == 1 || i == 2) {
-                const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
-                const int r = hbase[i - 1] + toff;
-                bfm[buf][i - 1] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
+                const unsigned ad = (lo[tap % 3][i - 1] + rowS[tap / 3] + (unsigned)((tap % 3) * dxs128)) ^ (unsigned)(kk * 64);
+                bfm[buf][i - 1] = *(frag_t)(size_t)ad;
             } else {
                 const int a = i == 0 ? 0 : i - 2;
-                const int r = a * 16 + fr;
-                af[buf][a] = *reinterpret_cast<const bf16x8*>(sW + tap * BN * 64 + r * 64 + ((chunk ^ (r & 7)) << 3));
+                af[buf][a] = *(frag_t)(size_t)(lds0 + (unsigned)(tap * BN * 64 * 2 + a * 2048) + (wl0 ^ (unsigned)(kk * 64)));
             }
         };
         static_assert(NI == 4 && MI == 2, "fragment schedule below");
@@ -735,6 +753,7 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
         const int lw = wave - 8;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
+        const float rWp = 1.0f / (float)Wp;
         auto issue_halo = [&](int mtile, int buf) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
             int prow0;
@@ -743,9 +762,11 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
             const int gp0 = prow0 * Wp;
             for (int k = lw; k < NINSTR; k += 4) {
                 const int hp = k * 8 + lrow;
+                const int hr = vpd_fdiv(hp, rWp);                // column-keyed swizzle, as conv3x3_c64_persistent_kernel
+                const int key = (hp - hr * Wp) & 7;
                 int gp = gp0 + hp;
                 gp = gp < g.total_pix ? gp : g.total_pix - 1;
-                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ (hp & 7)) << 3);
+                const bf16_t* src = p.x + (size_t)gp * 64 + ((piece ^ key) << 3);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + buf * HBUF + k * 8 * 64), 16, 0, 0);
             }
         };
@@ -779,15 +800,20 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
     const int wm = wave & 3;
     const int fr = lane & 15;
     const int fq = lane >> 4;
-    int hbase[MI];
+    unsigned lo[3][MI];                                           // as in conv3x3_c64_persistent_kernel
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = grp * 128 + wm * 32 + b * 16 + fr;
         const int lr = m / W;
         const int xx = m - lr * W;
         const int hrow = g.multi ? (lr / H) * (H + 2) + (lr % H) : lr;
-        hbase[b] = hrow * Wp + xx;
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic)
+            lo[ic][b] = (unsigned)((hrow * Wp + xx) * 128) + ((((unsigned)(xx + p.taps.dx0 + ic * p.taps.dxs) & 7u) ^ (unsigned)fq) << 4);
     }
+    const unsigned wl0 = (unsigned)(fr * 128 + ((fq ^ (fr & 7)) << 4));
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    typedef const bf16x8 __attribute__((address_space(3)))* frag_t;
     float st1[NI][4], st2[NI][4];
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -802,24 +828,18 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
         for (int a = 0; a < NI; ++a)
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned hbb = lds0 + (unsigned)(9 * BN * 64 * 2) + (unsigned)(i & 1) * (HBUF * 2u);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tap % 3) * p.taps.dxs);
-            const bf16_t* cW = sW + tap * BN * 64;
+            const unsigned S = hbb + (unsigned)(((p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + p.taps.dx0 + (tap % 3) * p.taps.dxs) * 128);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 af[NI], bfm[MI];
-                const int chunk = kk * 4 + fq;
 #pragma unroll
-                for (int a = 0; a < NI; ++a) {
-                    const int r = a * 16 + fr;
-                    af[a] = *reinterpret_cast<const bf16x8*>(cW + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
+                for (int a = 0; a < NI; ++a)
+                    af[a] = *(frag_t)(size_t)(lds0 + (unsigned)(tap * BN * 64 * 2 + a * 2048) + (wl0 ^ (unsigned)(kk * 64)));
 #pragma unroll
-                for (int b = 0; b < MI; ++b) {
-                    const int r = hbase[b] + toff;
-                    bfm[b] = *reinterpret_cast<const bf16x8*>(cH + r * 64 + ((chunk ^ (r & 7)) << 3));
-                }
+                for (int b = 0; b < MI; ++b) bfm[b] = *(frag_t)(size_t)((lo[tap % 3][b] + S) ^ (unsigned)(kk * 64));
 #pragma unroll
                 for (int a = 0; a < NI; ++a)
 #pragma unroll
