@@ -63,6 +63,7 @@ CASES = {
     "c2_128x128_layer4_ragged": (403, 512, 512, 4, 4),     # 128-pixel tiles = 8 images: 50.4 tiles x 4 channel tiles
     "c3_128x64_layer4_small": (37, 512, 512, 4, 4),        # < 200 tiles of 128 x 128: 128 x 64 tiles, 4.6 x 8
     "c3_128x64_one_chunk_pair": (21, 128, 128, 4, 4),      # two 64-channel chunks only: 18 K-steps per tile
+    "c0_256x64_layer1_resident_weights": (21, 64, 64, 32, 32),   # 64 -> 64 channels: RESW variant (VPD_PWS_L1=1), 84 tiles
 }
 
 
@@ -78,7 +79,7 @@ def _run(case, env_extra):
 @pytest.mark.parametrize("case", list(CASES), ids=list(CASES))
 @pytest.mark.parametrize("blocks", ["24", "0"], ids=["few_blocks", "device_blocks"])
 def test_pws_conv_matches_reference_and_old_kernel(case, blocks):
-    new = _run(case, {"VPD_PWS": "1", "VPD_PWS_BLOCKS": blocks})
+    new = _run(case, {"VPD_PWS": "1", "VPD_PWS_BLOCKS": blocks, "VPD_PWS_L1": "1"})
     assert new["fwd"] < 4e-3 and new["dgrad"] < 4e-3 and new["acc"] < 8e-3, new
     assert new["sum"] < 1e-4 and new["sumsq"] < 1e-4, new
     assert new["repeat"], new

@@ -1155,10 +1155,10 @@ static bool pws_enabled(const ConvParams& p) {
     return on && mode != 4 && mode != 5 && (long)p.N * p.Hs < VPD_FDIV_MAX;
 }
 // EXP: an experimental variant (VPD_PWS_VAR): only the train-forward epilogue is instantiated
-template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false>
+template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false, bool RESW = false>
 static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     constexpr int WN = BN / 64, WM = NMW / WN;
-    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + 1024 + (size_t)2 * WM * BN * 4;
+    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + (RESW ? 0 : 1024) + (size_t)2 * WM * BN * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     PwsGrid sg;
     sg.MT = (p.M + BM - 1) / BM;
@@ -1202,17 +1202,17 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
 #endif
     if constexpr (EXP) {
         if (conv_ep_mode(q) != 1) return hipErrorInvalidValue;
-        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg);
+        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg);
         return hipGetLastError();
     } else {
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 3, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 6, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 7, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
-        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 8, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 3, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 6, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 7, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 8, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
         default: return hipErrorInvalidValue;
     }
 #ifdef PWS_STAMPS
@@ -1582,7 +1582,7 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             // fragment reads per MFMA instead of the 0.75 of conv3x3_c64_persistent_kernel's 32 x 64, whose LDS pipe is 75 % busy);
             // the nine weight taps are re-streamed per tile (8 KB per K-step out of L2) instead of staying resident
             static const int l1 = getenv("VPD_PWS_L1") ? atoi(getenv("VPD_PWS_L1")) : PWS_L1_DEFAULT;
-            if (l1 && pws_enabled(p) && halo_geom(p, 256, 416, g)) return 6;
+            if (l1 == 2 && pws_enabled(p) && halo_geom(p, 256, 416, g)) return 6;      // (measured negative: weights re-streamed)
             if (halo_geom(p, 128, 224, g)) return 0;      // persistent blocks with resident weights
         }
     }
@@ -1640,6 +1640,10 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     switch (vpd_conv_kernel_class(p, &g)) {
         case 0: {
             HaloGeom g2;
+            // VPD_PWS_L1=1: 256-pixel tiles, 64 x 64 wave tiles, fragment pipeline, the nine taps resident (conv_pws.h, RESW)
+            static const int l1 = getenv("VPD_PWS_L1") ? atoi(getenv("VPD_PWS_L1")) : PWS_L1_DEFAULT;
+            if (l1 == 1 && pws_enabled(p) && p.M >= 256 * 64 && halo_geom(p, 256, 344, &g2))
+                return launch_pws<256, 64, 344, 9, 4, true, false, true>(p, g2, stream);
             if (c64x2_geom(p, &g2)) return launch_c64x2(p, g2, stream);      // inference: two MFMA wave groups on 256-pixel tiles
             return launch_c64<224>(p, g, stream);
         }

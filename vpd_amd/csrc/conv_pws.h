@@ -79,7 +79,12 @@ struct PwsSched {
     static constexpr int max_inflight() { int m = 0; for (int t = 0; t < 9; ++t) m = inflight(t) > m ? inflight(t) : m; return m; }
 };
 
-template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
+// RESW (64 -> 64 channels, layer1: ONE 64-channel chunk, nine K-steps per tile, NS = 9): the nine weight taps are loaded once
+// and stay in their ring stages (stage = tap); the loaders then only move halos -- the next tile's, in the bundles behind READY
+// of taps 0 .. HT - 1, all landed in front of READY of tap 8, whose pipeline reads the next tile's first fragments.
+// conv3x3_c64_persistent_kernel keeps the weights resident too, but on 128-pixel tiles with 32 x 64 wave tiles (0.75 fragment
+// reads per MFMA: its LDS pipe is 75 % busy); here 256-pixel tiles give 64 x 64 wave tiles (0.5) and the fragment pipeline.
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE, bool RESW = false>
 __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_kernel(const ConvParams p, const HaloGeom g,
                                                                                    const PwsGrid sg) {
     constexpr int WN = BN / 64;
@@ -89,15 +94,19 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     constexpr int WSTAGE = BN * 64;                  // elements
     constexpr int HBUF = HROWS * 64;
     constexpr int W_PER = BN / 32;                   // weight-tile DMA instructions per loader wave and step
-    constexpr int HPASS = HROWS / 32;                // halo DMA instructions per loader wave and chunk
-    constexpr int A = NS - 2;                        // weight bundles beyond the two readable steps
+    constexpr int HINSTR = HROWS / 8;                // 1-KiB LDS-DMA instructions per halo
+    constexpr int HPASS = (HINSTR + 3) / 4;          // ... per loader wave (the last one may be a filler when HINSTR % 4 != 0)
+    constexpr int A = RESW ? 4 : NS - 2;             // weight bundles beyond the two readable steps (RESW: halo bundles only)
     constexpr int HT = 9 - A;                        // READYs of a chunk behind which the next chunk's halo slices may be issued
-    using SC = PwsSched<W_PER, HPASS, HT, A>;
-    static_assert(HROWS % 32 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
+    using SC = PwsSched<RESW ? 0 : W_PER, HPASS, HT, A>;
+    static_assert(HROWS % 8 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
+    static_assert(!RESW || (NS == 9 && BN == 64), "resident weights: one stage per tap");
     static_assert(EPM == 0 || EPM == 1 || EPM == 2 || EPM == 3 || EPM == 6 || EPM == 7 || EPM == 8, "epilogue mode");
     constexpr unsigned OFF_W = 2u * HBUF * 2u;                       // bytes
+    // (RESW: two 44-KB halos + nine weight taps leave exactly the statistics scratch: fillers land there, nobody reads it
+    //  before every transfer has been waited for)
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
-    constexpr unsigned OFF_RED = OFF_DUMP + 1024u;
+    constexpr unsigned OFF_RED = OFF_DUMP + (RESW ? 0u : 1024u);
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                    // [2][HBUF]
@@ -145,6 +154,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         // halo pixel hp (row hr, column xp of the padded tile) keeps its 16-byte pieces XOR-ed with key(hr, xp): HaloGeom
         const float rWp = 1.0f / (float)Wp;
         auto halo_instr = [&](int gp0, int cc, int buf, int k) __attribute__((always_inline)) {
+            if (HINSTR % 4 != 0 && lw + 4 * k >= HINSTR) { pws_dma16(p.w, lds0 + OFF_DUMP); return; }      // filler: keeps the counts
             const int hp = (lw + 4 * k) * 8 + lrow;
             const int hr = vpd_fdiv(hp, rWp);
             const int key = ((hp - hr * Wp) & g.kmask) ^ ((hr & g.rowmask) << g.kshift);
@@ -178,7 +188,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         unsigned w_st = 0;                                           // ... and its ring stage
         int w_step = 0;                                              // ... and its step index
 #pragma unroll
-        for (int k = 0; k <= A; ++k) {
+        for (int k = 0; k <= (RESW ? 8 : A); ++k) {                  // (RESW: all nine taps, once)
             if (w_step < total && !VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
             ++w_step;
             if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
@@ -194,11 +204,17 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             auto step = [&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
                 // steps s and s + 1 have landed; on the block's last chunk (bundles shrink: no next halo, no more weights) everything
-                if (has_next) pws_vmwait<SC::inflight(t)>();
-                else pws_vmwait<0>();
+                if constexpr (RESW) {
+                    // first tile: halo + all weights; afterwards only the next tile's halo is in flight, and it must be complete
+                    // in front of READY of tap 8 (the pipeline of step 8 reads the next tile's first fragments)
+                    if (c == 0 || t == 8) pws_vmwait<0>();
+                } else {
+                    if (has_next) pws_vmwait<SC::inflight(t)>();
+                    else pws_vmwait<0>();
+                }
                 if (c == 0 && t == 0) PWS_STAMP(10);                 // first two steps landed
                 if (!VPD_ABL(p, 16) || (c == 0 && t == 0)) __builtin_amdgcn_s_barrier();      // READY_s (ablation 16: one tile per block only)
-                if (w_step < total) {
+                if (!RESW && w_step < total) {
                     if (!VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
                     ++w_step;
                     if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
