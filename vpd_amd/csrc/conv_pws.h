@@ -66,6 +66,59 @@ static __device__ __forceinline__ void pws_lgkm0() {
     asm volatile("" ::: "memory");
 }
 
+// L2 touch of the lines a tile's epilogue will read (z / mask of the consuming BatchNorm, the old y of the accumulate modes, the
+// eval residual): one LDS-DMA instruction per pixel group into the 1-KiB dump -- no VGPR destination, so nothing stays reserved
+// while the K loop runs, and the MFMA waves have no other vector-memory traffic whose vmcnt order it could disturb.  Issued at
+// the start of the tile's last 64-channel chunk (~9 K-steps ahead): the epilogue's own loads then hit L2 instead of exposing an
+// HBM round trip per tile (in-step stamps: 8,300 cycles of mode-6 epilogue on 64 x 64 wave tiles against 3,700 for mode 1).
+// NEGATIVE: the step got slower with it (the epilogue's exposure is not an L2 miss; the extra DMA competes with the loaders).
+// Lane (fr, fq): pixel fr of group b; fq picks the tensor (every tensor's 64-channel slice of a pixel is one 128-byte line).
+#ifndef PWS_TOUCH
+#define PWS_TOUCH 0      // measured: -1.2 % (256 crops), -1.5 % (512), -1.6 % (apply) same-box -- profiles/r03_epilogue_touch_negative.txt
+#endif
+template <int BM, int BN, int WM, int WN, int EPM, bool ZTOO>
+static __device__ __forceinline__ void pws_epilogue_touch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
+                                                          unsigned dump) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16;
+    constexpr bool ACC = EPM == 2 || EPM == 7 || EPM == 8;
+    constexpr bool BSTM = EPM == 6 || EPM == 7 || EPM == 8;
+    if constexpr (!(ACC || BSTM || EPM == 3)) return;
+    if (EPM == 3 && !p.res) return;
+    if (EPM == 6 && !ZTOO) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 15, fq = lane >> 4;
+    const PixSplit ps = pix_split_init(p, geo);
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mtile * BM + wm * WTM + b * 16 + fr;
+        const int mc = m < geo.M ? m : geo.M - 1;
+        const void* src;
+        if constexpr (EPM == 3) {
+            int bi, yy, xx;
+            pix_split(ps, mc, bi, yy, xx);
+            src = p.res + ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC + n0 + wn * WTN + fq * 8;
+        } else {
+            size_t yoff;
+            if (ps.dense) yoff = (size_t)mc * p.yC;
+            else {
+                int bi, yy, xx;
+                pix_split(ps, mc, bi, yy, xx);
+                yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp + (xx * p.osub + geo.opw + p.ypad)) * p.yC;
+            }
+            const size_t e = yoff + n0 + wn * WTN;
+            const bf16_t* t0 = ACC ? p.y : p.bst_z;                               // (mode 2 has no z; every mode here has t0)
+            const bf16_t* t1 = (BSTM && ZTOO) ? p.bst_z : t0;
+            const bf16_t* t2 = EPM == 8 ? p.bst_z2 : t1;
+            const unsigned char* mk = BSTM ? p.bst_mask : p.acc_mask;
+            src = fq == 0 ? (const void*)(t0 + e) : fq == 1 ? (const void*)(t1 + e) : (const void*)(t2 + e);
+            if (fq == 3 && mk && (BSTM ? ZTOO : true)) src = (const void*)((size_t)(mk + (e >> 3)) & ~(size_t)15);
+        }
+        pws_dma16(src, dump);
+    }
+}
+
 // DMA instructions per loader wave in the bundle issued behind READY of tap t (the weights of step s + 1 + A and this
 // tap's share of the next chunk's halo), and the vmcnt immediates that follow from them
 template <int W_PER, int HPASS, int HT, int A>
@@ -370,6 +423,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 #pragma nounroll
         for (int row = 0; row < nrows; ++row) {
             if (BST_EARLY && row == nrows - 3) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+            if (PWS_TOUCH && row == nrows - 3) pws_epilogue_touch<BM, BN, WM, WN, EPM, !BST_EARLY>(p, mtile, n0, geo, lds0 + OFF_DUMP);
             // the next tap row: the same chunk's, or the first one of the next chunk (other halo buffer)
             const bool wrap = ir == 2;
             const unsigned nhb = wrap ? (hb == hb0 ? hb1 : hb0) : hb;
