@@ -358,7 +358,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         mat_ms = sum(v["ms"] for v in cls.values()) / max(args.profile_steps, 1)
         mat_flops = sum(v["flops"] for v in cls.values()) / max(args.profile_steps, 1)
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_source = None, None, None
         try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950 note)
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
             # rows of the dominant class only: its kernel name AND one of its tile shapes ("<256,64,416>" -> "<256, 64, 416,")
@@ -370,12 +370,15 @@ def main():
             n = sum(r["launches"] for r in rows)
             traffic = sum(r["launches"] * (2 * r["fetch_KB_per_launch"] + r["write_KB_per_launch"]) for r in rows) / n * 1024
             traffic_note = pmc["note"]
+            import socket
+            traffic_source = dict(pmc.get("source") or {}, file="profiles/pmc_traffic.json")
+            traffic_source["same_host_as_this_run"] = traffic_source.get("host") == socket.gethostname()
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"],
                     "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": kernels[dom]["tflops"] / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": traffic_note,
+                    "traffic_note": traffic_note, "traffic_source": traffic_source,
                     "whole_step_frac": value / world * flop / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12),
                     # FLOP-weighted over ALL matrix-kernel classes (= their FLOPs / their summed time); `frac` above
                     # is the single class that takes the most time

@@ -9,16 +9,20 @@ R=$PWD
 OUT=$R/gpurun_out
 ARGS="--steps 20 --warmup 5 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
-cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-python3 $R/tools/prof_summary.py $OUT/${TAG}_kernel_stats.csv 25 60 > $OUT/${TAG}_summary.txt
+export VPD_PROFILE_TAG=$TAG
+# 1. counters first: the default bench run below then reads the traffic figure collected on THIS box (roofline.traffic_source)
 PARGS="--steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o pmc --output-format csv -- python3 $R/bench.py $PARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o pmc --output-format csv -- python3 $R/bench.py $PARGS > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/pmc_traffic.json
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $OUT/${TAG}_pmc_mfma -o pmc --output-format csv -- python3 $R/bench.py $PARGS > /dev/null 2>&1
 python3 $R/tools/pmc_mfma_util.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_mfma_util.json > $OUT/${TAG}_mfma_util.txt
+# 2. the default bench line (with cpu_baseline and the apply block) and the kernel trace of the same command
+python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
+cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+python3 $R/tools/prof_summary.py $OUT/${TAG}_kernel_stats.csv 25 60 > $OUT/${TAG}_summary.txt
 python3 $R/tools/bandwidth_table.py $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_bandwidth.txt 2>/dev/null
 rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_prof
 tail -3 $OUT/${TAG}_summary.txt; head -5 $OUT/${TAG}_mfma_util.txt
