@@ -167,6 +167,9 @@ struct ConvParams {
     // gather kernel only: extra K-steps of class 0 from a second input tensor of the same geometry and channel count
     // (the data gradient of the down-sampling branch lands on the even-even pixels, i.e. on class 0 of the 3x3's)
     const bf16_t* x2; const bf16_t* w2; int Kc2;
+    // stem kernel, eval only (epilogue mode 9): scale / shift / ReLU (ep_*) and the 3x3 stride-2 max-pool applied in the
+    // epilogue; the pooled activation goes to `pool_y` (padded by 1, [N][Hs/2 + 2][Ws/2 + 2][64]) and y is not written
+    bf16_t* pool_y;
 };
 
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the

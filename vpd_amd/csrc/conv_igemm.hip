@@ -933,6 +933,16 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W0 = p.Ws, H0 = p.Hs, Wp = p.xWp, Hp = p.xHp;
     const int G = gridDim.x;
+    // Tile walk.  Plain modes: tiles blockIdx.x, + G, ...  Pooled mode (EPM 9): a block takes WHOLE IMAGES (blockIdx.x, + G, ...)
+    // top to bottom, because the pooled rows of a tile need the last conv row of the tile above it (kept in LDS).
+    constexpr bool POOL = EPM == 9;
+    const int TPI = H0 / TR;                                      // tiles per image
+    const int cnt = POOL ? ((p.N - (int)blockIdx.x + G - 1) / G) * TPI : (ntiles - (int)blockIdx.x + G - 1) / G;
+    auto tile_at = [&](int i) __attribute__((always_inline)) {
+        if (!POOL) return (int)blockIdx.x + i * G;
+        const int im = i / TPI;
+        return ((int)blockIdx.x + im * G) * TPI + (i - im * TPI);
+    };
 
     if (wave >= 4) {
         const int lw = wave - 4;
@@ -960,12 +970,12 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
         }
-        issue_rows(blockIdx.x, 0);
+        issue_rows(tile_at(0), 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // B_0
-        int i = 0;
-        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
-            if (t + G < ntiles) issue_rows(t + G, (i + 1) & 1);
+        for (int i = 0; i < cnt; ++i) {
+            if (i + 1 < cnt) issue_rows(tile_at(i + 1), (i + 1) & 1);
+            if (POOL) __builtin_amdgcn_s_barrier();               // X_i: the tile's activations are parked (pooled epilogue)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
@@ -989,9 +999,18 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
     for (int a = 0; a < NI; ++a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    // pooled mode: this lane's scale / shift of the folded BatchNorm (channels a*16 + 4*fq .. + 3)
+    float4 esc[NI], esh[NI];
+    if (POOL) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            esc[a] = *reinterpret_cast<const float4*>(p.ep_scale + a * 16 + 4 * fq);
+            esh[a] = *reinterpret_cast<const float4*>(p.ep_shift + a * 16 + 4 * fq);
+        }
+    }
     __builtin_amdgcn_s_barrier();                                 // B_0
-    int i = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+    for (int i = 0; i < cnt; ++i) {
+        const int t = tile_at(i);
         const bf16_t* cH = sH + (i & 1) * HBUF;
         f32x4 acc[NI][MI];
 #pragma unroll
@@ -1037,7 +1056,69 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
             __builtin_amdgcn_sched_barrier(0);
 #undef STEM_MFMA
         }
-        if (!lds_store) {
+        if constexpr (POOL) {
+            // Eval with the max-pool in the epilogue.  The tile's activations a = bf16(relu(bf16(acc) * scale + shift)) -- the
+            // rounding points of the two-launch path (conv stores bf16 z, stem_pool_pair_kernel rounds the activation before
+            // the maximum), so the results are bit-identical -- are parked pixel-major in one of two LDS buffers ([128 pixels]
+            // [68]: 136-byte pitch); behind barrier X every thread of the four MFMA waves produces 8 channels of one pooled
+            // pixel from the tile's rows and, for the tile's first pooled row, the LAST row of the previous tile, which still
+            // sits in the other buffer (the block walks an image top to bottom).  z is never written: 523 MB of stores and
+            // 523 MB of loads per 1,000 crops go away.
+            bf16_t* sT = reinterpret_cast<bf16_t*>(red) + 1024;
+            bf16_t* cur = sT + (i & 1) * (BM * 68);
+            const bf16_t* prev = sT + ((i & 1) ^ 1) * (BM * 68);
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int ml = wm * WTM + b * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    uint2 zv;
+                    zv.x = pack2bf(acc[a][b][0], acc[a][b][1]);
+                    zv.y = pack2bf(acc[a][b][2], acc[a][b][3]);
+                    float v0 = bf2f((unsigned short)(zv.x & 0xffff)) * esc[a].x + esh[a].x;
+                    float v1 = bf2f((unsigned short)(zv.x >> 16)) * esc[a].y + esh[a].y;
+                    float v2 = bf2f((unsigned short)(zv.y & 0xffff)) * esc[a].z + esh[a].z;
+                    float v3 = bf2f((unsigned short)(zv.y >> 16)) * esc[a].w + esh[a].w;
+                    v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; v2 = v2 > 0.f ? v2 : 0.f; v3 = v3 > 0.f ? v3 : 0.f;
+                    uint2 ov;
+                    ov.x = pack2bf(v0, v1);
+                    ov.y = pack2bf(v2, v3);
+                    *reinterpret_cast<uint2*>(cur + ml * 68 + a * 16 + 4 * fq) = ov;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // X_i
+            {
+                const int Wo = W0 >> 1, Ho = H0 >> 1;
+                const int q = tid >> 3, c8 = (tid & 7) << 3;      // pooled pixel of the tile (32 of them), channel slice
+                const int j = q / Wo, xo = q - j * Wo;            // pooled row inside the tile, pooled column
+                const int ti = i % TPI;                            // tile index inside the image
+                float best[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) best[k] = 0.f;        // activations are >= 0: 0 is the identity of the maximum
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int row = 2 * j - 1 + r;                // conv row inside the tile; -1 = last row of the previous tile
+                    if (row < 0 && ti == 0) continue;             // top border of the image
+                    const bf16_t* rp = row < 0 ? prev + (TR - 1) * W0 * 68 : cur + row * W0 * 68;
+#pragma unroll
+                    for (int cx = 0; cx < 3; ++cx) {
+                        const int x = 2 * xo - 1 + cx;
+                        if (x < 0) continue;                      // (x <= W0 - 1 always: W0 is even)
+                        const uint2 lo = *reinterpret_cast<const uint2*>(rp + x * 68 + c8);
+                        const uint2 hi = *reinterpret_cast<const uint2*>(rp + x * 68 + c8 + 4);
+                        float v[8];
+                        unpack8(uint4{lo.x, lo.y, hi.x, hi.y}, v);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) best[k] = v[k] > best[k] ? v[k] : best[k];
+                    }
+                }
+                const int img = t / TPI;
+                const int oy = ti * (TR >> 1) + j;
+                const size_t oo = ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + xo + 1) * 64 + c8;
+                *reinterpret_cast<uint4*>(p.pool_y + oo) = pack8(best);
+            }
+        } else if (!lds_store) {
             conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
         } else {
             // Coalesced store path: the accumulator layout gives a lane 4 channels of 16 different pixels (32-byte pieces of
@@ -1084,26 +1165,30 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
 // stem shape test + launch; returns false when the generic gather kernel has to take it
 static bool stem_eligible(const ConvParams& p, int* TR) {
     if (!(p.xC == 8 && p.Kc == 64 && p.Co == 64 && p.istr == 2 && p.osub == 1 && p.taps.nr == 7 && p.taps.nc == 1 &&
-          p.taps.dy0 == 0 && p.taps.dys == 1 && p.taps.dx0 == 0 && p.ypad == 0 && !p.accumulate && !p.ep_scale))
+          p.taps.dy0 == 0 && p.taps.dys == 1 && p.taps.dx0 == 0 && p.ypad == 0 && !p.accumulate && (!p.ep_scale || p.pool_y)))
         return false;
     if (p.Ws <= 0 || 128 % p.Ws != 0) return false;
     *TR = 128 / p.Ws;
     if (*TR > p.Hs || p.Hs % *TR != 0) return false;
+    // pooled eval epilogue: whole pooled rows per tile (even TR, even W), folded BatchNorm + ReLU, no statistics
+    if (p.pool_y && ((*TR & 1) || (p.Ws & 1) || !p.ep_scale || !p.ep_shift || !p.ep_relu || p.stats || p.res)) return false;
     const int rows = ((2 * *TR + 5) * p.xWp + 7) / 8;            // 128-byte LDS rows of the raw input range
     return rows <= 160 && p.M % 128 == 0;
 }
 
 static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const int ntiles = p.M / 128;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    // statistics scratch (2 KiB) + the coalesced-store staging of the four MFMA waves (4 x 32 pixels x 136 B)
-    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 + 4 * 32 * 68 * sizeof(bf16_t);
+    const int grid = p.pool_y ? (p.N < 256 ? p.N : 256) : (ntiles < 256 ? ntiles : 256);      // pooled: whole images per block
+    // statistics scratch (2 KiB) + the coalesced-store staging of the four MFMA waves (4 x 32 pixels x 136 B; pooled mode:
+    // two such tiles)
+    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 + (p.pool_y ? 2 : 1) * 4 * 32 * 68 * sizeof(bf16_t);
     const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
     ConvParams q = p;
     // dense 64-channel output (the stem's only use): stores through LDS, 1 KiB contiguous per instruction (VPD_STEM_LDS_STORE=0: direct)
     static const int lds_store_on = getenv("VPD_STEM_LDS_STORE") ? atoi(getenv("VPD_STEM_LDS_STORE")) : 1;
     const int lds_store = lds_store_on && p.ypad == 0 && p.yC == 64 && p.osub == 1 && p.yWp == p.Ws && p.yHp == p.Hs;
-    if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, lds_store);
+    if (p.pool_y) VPD_LAUNCH((conv_stem_persistent_kernel<160, 9>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, 0);
+    else if (p.stats) VPD_LAUNCH((conv_stem_persistent_kernel<160, 1>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, lds_store);
     else VPD_LAUNCH((conv_stem_persistent_kernel<160, 0>), dim3(grid), dim3(512), lds, stream, q, TR, ntiles, xelems, lds_store);
     return hipGetLastError();
 }

@@ -690,9 +690,11 @@ bool conv_pair_ok(const Ctx& c, const ConvInfo& c1, const ConvInfo& cd, bool tra
     return !train || (c.fused(c1) && c.fused(cd));
 }
 
+// pool_y / pooled: the eval stem with scale / shift / ReLU / max-pool in the conv's epilogue (ConvParams::pool_y) when the stem
+// kernel takes the shape; *pooled tells the caller whether it did (false: plain conv into y, the pooling launch follows)
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
                         const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
-                        const AltConv* alt = nullptr) {
+                        const AltConv* alt = nullptr, bf16_t* pool_y = nullptr, bool* pooled = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -715,6 +717,12 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         q.alt_stats = stats ? c.bn_rows(av.bn) : nullptr;
         q.alt_ep_scale = alt->ep_scale; q.alt_ep_shift = alt->ep_shift; q.alt_ep_relu = alt->ep_relu;
         flops += conv_flops(av, c.n);
+    }
+    if (pool_y) {
+        q.pool_y = pool_y;
+        const bool ok = vpd_conv_kernel_class(q) == 5;
+        if (!ok) { q.pool_y = nullptr; q.ep_scale = nullptr; q.ep_shift = nullptr; q.ep_relu = 0; }
+        if (pooled) *pooled = ok;
     }
     const int kc = vpd_conv_kernel_class(q);
     // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2 -- except layer1's 64 -> 64 convs, which stay in slot 0
@@ -1086,8 +1094,16 @@ int run_eval_forward(vpd_plan* p, const float* params, const float* x, int n, fl
                      float* loss_step, double* loss_accum, char* ws, hipStream_t s) {
     Ctx c{p, ws, s, params, n};
     if (x) LCHECK(vpd_launch_pack_input(x, n, p->c_in, p->H, p->W, c.b16(p->xin_off), p->xHp, p->xWp, 3, 8, s));
-    LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, false, nullptr, nullptr, nullptr, 0));
-    {
+    // stem: conv + folded BatchNorm + ReLU + max-pool in ONE launch when the stem kernel takes the shape and there are enough
+    // images for its image-per-block walk (VPD_STEM_POOL_FUSED=0: conv, then the pooling launch)
+    static const bool fuse_pool = !(getenv("VPD_STEM_POOL_FUSED") && !atoi(getenv("VPD_STEM_POOL_FUSED")));
+    bool pooled = false;
+    if (fuse_pool && n >= 64)
+        LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, false, c.bn_escale(p->stem.bn),
+                            c.bn_eshift(p->stem.bn), nullptr, 1, nullptr, c.b16(p->p0_off), &pooled));
+    else
+        LCHECK(run_conv_fwd(c, p->stem, c.b16(p->xin_off), c.b16(p->z0_off), 0, false, nullptr, nullptr, nullptr, 0));
+    if (!pooled) {
         StemPoolParams sp;
         memset(&sp, 0, sizeof sp);
         sp.z = c.b16(p->z0_off); sp.Hz = p->H0; sp.Wz = p->W0;
