@@ -328,3 +328,48 @@ def test_fullsize_values_match_the_reference(name):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "parity_fullsize_%s.json" % name), "w") as fp:
         json.dump(rec, fp, indent=1)
+
+
+_STEM_POOL_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r})
+from vpd_amd.models.rgb import RGBF_EmbeddingModel
+out = {{}}
+for arch, cin, hw, n in (("resnet34", 5, 128, 1000), ("resnet34", 5, 128, 70), ("resnet18", 3, 64, 96), ("resnet18", 5, 128, 10)):
+    enc = RGBF_EmbeddingModel(arch, 32, cin == 5, "cuda")
+    enc.reset_parameters(seed=3)
+    # non-trivial folded BatchNorm (negative scales too: the maximum must be taken AFTER scale / shift / ReLU)
+    sd = enc.state_dict()
+    g = torch.Generator().manual_seed(5)
+    sd["resnet.bn1.weight"] = torch.randn(64, generator=g)
+    sd["resnet.bn1.bias"] = torch.randn(64, generator=g) * 0.3
+    sd["resnet.bn1.running_mean"] = torch.randn(64, generator=g) * 0.2
+    sd["resnet.bn1.running_var"] = torch.rand(64, generator=g) + 0.5
+    enc.load_state_dict(sd)
+    enc.eval()
+    x = torch.randn((n, cin, hw, hw), generator=torch.Generator().manual_seed(n), dtype=torch.float32).cuda()
+    out["%s_%d_%d_%d" % (arch, cin, hw, n)] = enc.engine.forward_eval(x).cpu().numpy()
+np.savez({out!r}, **out)
+"""
+
+
+def test_stem_pool_in_the_conv_epilogue_equals_the_two_launch_path(tmp_path):
+    """Eval stem: conv + folded BatchNorm + ReLU + 3x3 stride-2 max-pool in ONE launch (conv_stem_persistent_kernel<160, 9>,
+    ConvParams::pool_y) against conv -> stem_pool_pair_kernel (VPD_STEM_POOL_FUSED=0): same rounding points, so the embeddings
+    must agree BIT FOR BIT -- at 1,000 crops (four images per block, the carried row between tiles), at 70 (fewer images than
+    CUs), at 64-pixel inputs (four conv rows = two pooled rows per tile), and below the 64-image threshold (same path).
+    Reference: models/module.py:112-116 (conv1 -> bn1 -> relu -> maxpool)."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("e%s.npz" % flag))
+        r = subprocess.run([sys.executable, "-c", _STEM_POOL_SCRIPT.format(repo=repo, out=out)],
+                           env=dict(os.environ, VPD_STEM_POOL_FUSED=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        res.append(np.load(out))
+    for k in res[0].files:
+        a, b = res[0][k], res[1][k]
+        assert np.isfinite(a).all() and np.abs(a).max() > 0, k
+        assert np.array_equal(a, b), (k, float(np.abs(a - b).max()))

@@ -971,11 +971,66 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
             }
         }
         issue_rows(tile_at(0), 0);
+        if constexpr (POOL) {
+            // Pooled eval mode: the LOADER waves also run the max-pool.  The MFMA waves park a tile's activations in LDS and go
+            // on to the next tile's MFMA loop; behind the tile's barrier the 256 loader threads (idle but for five DMA
+            // instructions per tile) reduce the parked tile to its 32 pooled pixels and store them.  Input rows are issued two
+            // tiles ahead (tile i + 2 into the buffer tile i has just been read from), so there is still ONE barrier per tile.
+            bf16_t* sT = reinterpret_cast<bf16_t*>(red) + 1024;   // [2][128 pixels][72]: parked activations (144-byte pitch)
+            bf16_t* sC = sT + 2 * BM * 72;                        // [2][32][64]: last conv row of a tile, max over each pooled column's window
+            const int ltid = tid - 256;
+            const int q = ltid >> 3, c8 = (ltid & 7) << 3;        // pooled pixel of the tile (32 of them), channel slice
+            const int Wo = W0 >> 1, Ho = H0 >> 1;
+            const int j = q / Wo, xo = q - j * Wo;                // pooled row inside the tile, pooled column
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            // activations are >= +0: bf16 bit patterns order like unsigned integers (v_pk_max_u16, two channels per instruction)
+            auto max4 = [](uint4 a, const uint4& b) __attribute__((always_inline)) {
+                us2 r;
+                r = __builtin_elementwise_max(__builtin_bit_cast(us2, a.x), __builtin_bit_cast(us2, b.x)); a.x = __builtin_bit_cast(unsigned, r);
+                r = __builtin_elementwise_max(__builtin_bit_cast(us2, a.y), __builtin_bit_cast(us2, b.y)); a.y = __builtin_bit_cast(unsigned, r);
+                r = __builtin_elementwise_max(__builtin_bit_cast(us2, a.z), __builtin_bit_cast(us2, b.z)); a.z = __builtin_bit_cast(unsigned, r);
+                r = __builtin_elementwise_max(__builtin_bit_cast(us2, a.w), __builtin_bit_cast(us2, b.w)); a.w = __builtin_bit_cast(unsigned, r);
+                return a;
+            };
+            if (cnt > 1) issue_rows(tile_at(1), 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // B_0
+            for (int i = 0; i < cnt; ++i) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // rows of tile i + 1 have landed; the carried row is written
+                __builtin_amdgcn_s_barrier();                     // B_{i+1}: tile i is parked, its input buffer is free
+                if (i + 2 < cnt) issue_rows(tile_at(i + 2), i & 1);
+                const int t = tile_at(i);
+                const int img = t / TPI, ti = t - img * TPI;      // image, tile inside the image
+                const bf16_t* cur = sT + (i & 1) * (BM * 72);
+                uint4 best = uint4{0u, 0u, 0u, 0u};
+                uint4 last = best;                                // window maximum over the tile's last conv row (threads of the last pooled row)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int row = 2 * j - 1 + r;                // conv row inside the tile; -1 = last row of the tile above
+                    if (row < 0) {
+                        if (ti != 0) best = max4(best, *reinterpret_cast<const uint4*>(sC + ((i & 1) ^ 1) * (32 * 64) + xo * 64 + c8));
+                        continue;
+                    }
+                    uint4 m3 = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int cx = 0; cx < 3; ++cx) {
+                        const int x = 2 * xo - 1 + cx;
+                        if (x < 0) continue;                      // (x <= W0 - 1 always: W0 is even)
+                        m3 = max4(m3, *reinterpret_cast<const uint4*>(cur + (row * W0 + x) * 72 + c8));
+                    }
+                    best = max4(best, m3);
+                    if (r == 2) last = m3;
+                }
+                if (2 * j + 1 == TR - 1) *reinterpret_cast<uint4*>(sC + (i & 1) * (32 * 64) + xo * 64 + c8) = last;
+                const int oy = ti * (TR >> 1) + j;
+                *reinterpret_cast<uint4*>(p.pool_y + ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + xo + 1) * 64 + c8) = best;
+            }
+            return;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // B_0
         for (int i = 0; i < cnt; ++i) {
             if (i + 1 < cnt) issue_rows(tile_at(i + 1), (i + 1) & 1);
-            if (POOL) __builtin_amdgcn_s_barrier();               // X_i: the tile's activations are parked (pooled epilogue)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
@@ -1057,16 +1112,13 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
 #undef STEM_MFMA
         }
         if constexpr (POOL) {
-            // Eval with the max-pool in the epilogue.  The tile's activations a = bf16(relu(bf16(acc) * scale + shift)) -- the
+            // Eval with the max-pool behind the conv.  The tile's activations a = bf16(relu(bf16(acc) * scale + shift)) -- the
             // rounding points of the two-launch path (conv stores bf16 z, stem_pool_pair_kernel rounds the activation before
             // the maximum), so the results are bit-identical -- are parked pixel-major in one of two LDS buffers ([128 pixels]
-            // [68]: 136-byte pitch); behind barrier X every thread of the four MFMA waves produces 8 channels of one pooled
-            // pixel from the tile's rows and, for the tile's first pooled row, the LAST row of the previous tile, which still
-            // sits in the other buffer (the block walks an image top to bottom).  z is never written: 523 MB of stores and
-            // 523 MB of loads per 1,000 crops go away.
-            bf16_t* sT = reinterpret_cast<bf16_t*>(red) + 1024;
-            bf16_t* cur = sT + (i & 1) * (BM * 68);
-            const bf16_t* prev = sT + ((i & 1) ^ 1) * (BM * 68);
+            // [72]: 144-byte pitch, 16-byte aligned for the pooling threads' b128 reads); the loader waves pool them (above)
+            // while this wave is already in the next tile's MFMA loop.  z is never written: 523 MB of stores and 523 MB of
+            // loads per 1,000 crops go away.
+            bf16_t* cur = reinterpret_cast<bf16_t*>(red) + 1024 + (i & 1) * (BM * 72);
 #pragma unroll
             for (int b = 0; b < MI; ++b) {
                 const int ml = wm * WTM + b * 16 + fr;
@@ -1083,41 +1135,10 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
                     uint2 ov;
                     ov.x = pack2bf(v0, v1);
                     ov.y = pack2bf(v2, v3);
-                    *reinterpret_cast<uint2*>(cur + ml * 68 + a * 16 + 4 * fq) = ov;
+                    *reinterpret_cast<uint2*>(cur + ml * 72 + a * 16 + 4 * fq) = ov;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                         // X_i
-            {
-                const int Wo = W0 >> 1, Ho = H0 >> 1;
-                const int q = tid >> 3, c8 = (tid & 7) << 3;      // pooled pixel of the tile (32 of them), channel slice
-                const int j = q / Wo, xo = q - j * Wo;            // pooled row inside the tile, pooled column
-                const int ti = i % TPI;                            // tile index inside the image
-                float best[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) best[k] = 0.f;        // activations are >= 0: 0 is the identity of the maximum
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int row = 2 * j - 1 + r;                // conv row inside the tile; -1 = last row of the previous tile
-                    if (row < 0 && ti == 0) continue;             // top border of the image
-                    const bf16_t* rp = row < 0 ? prev + (TR - 1) * W0 * 68 : cur + row * W0 * 68;
-#pragma unroll
-                    for (int cx = 0; cx < 3; ++cx) {
-                        const int x = 2 * xo - 1 + cx;
-                        if (x < 0) continue;                      // (x <= W0 - 1 always: W0 is even)
-                        const uint2 lo = *reinterpret_cast<const uint2*>(rp + x * 68 + c8);
-                        const uint2 hi = *reinterpret_cast<const uint2*>(rp + x * 68 + c8 + 4);
-                        float v[8];
-                        unpack8(uint4{lo.x, lo.y, hi.x, hi.y}, v);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) best[k] = v[k] > best[k] ? v[k] : best[k];
-                    }
-                }
-                const int img = t / TPI;
-                const int oy = ti * (TR >> 1) + j;
-                const size_t oo = ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + xo + 1) * 64 + c8;
-                *reinterpret_cast<uint4*>(p.pool_y + oo) = pack8(best);
-            }
         } else if (!lds_store) {
             conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, t, 0, st1, st2, geo);
         } else {
@@ -1180,8 +1201,9 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const int ntiles = p.M / 128;
     const int grid = p.pool_y ? (p.N < 256 ? p.N : 256) : (ntiles < 256 ? ntiles : 256);      // pooled: whole images per block
     // statistics scratch (2 KiB) + the coalesced-store staging of the four MFMA waves (4 x 32 pixels x 136 B; pooled mode:
-    // two such tiles)
-    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 + (p.pool_y ? 2 : 1) * 4 * 32 * 68 * sizeof(bf16_t);
+    // two parked tiles of 128 pixels x 144 B + two carried rows of 32 x 128 B)
+    const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 +
+                       (p.pool_y ? (size_t)(2 * 128 * 72 + 2 * 32 * 64) : (size_t)4 * 32 * 68) * sizeof(bf16_t);
     const long xelems = (long)p.N * p.xHp * p.xWp * 8 + 64;      // the plan allocates 256 elements of slack behind xin
     ConvParams q = p;
     // dense 64-channel output (the stem's only use): stores through LDS, 1 KiB contiguous per instruction (VPD_STEM_LDS_STORE=0: direct)
