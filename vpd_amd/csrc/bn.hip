@@ -738,6 +738,29 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
     extern __shared__ float sm[];                      // scale[C] shift[C] (rscale[C] rshift[C])
     const int C = p.C;
     float* s_sc = sm; float* s_sh = sm + C; float* s_rsc = sm + 2 * C; float* s_rsh = sm + 3 * C;
+    // The first item's operands are requested BEFORE the finalize prologue: on the small tensors (layer3 / layer4: one or two
+    // items per thread) the launch is a chain of dependent round trips -- rows -> fp64 finalize -> barrier -> z -> store --
+    // and z / the residual do not depend on the first three.
+    const int cv = C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto load_item = [&](long i, uint4& zv, uint4& rv, size_t& o, int& cc) __attribute__((always_inline)) {
+        const int m = (int)(i / cv);
+        cc = (int)(i - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        zv = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + cc);
+        if (p.res_kind == 1) rv = *reinterpret_cast<const uint4*>(p.res + ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * C + cc);
+        else if (p.res_kind == 2) rv = *reinterpret_cast<const uint4*>(p.res + (size_t)m * C + cc);
+        o = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + cc;
+    };
+    long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = it < total;
+    uint4 zc = uint4{0u, 0u, 0u, 0u}, rc = zc; size_t oo = 0; int c = 0;
+    if (have) load_item(it, zc, rc, oo, c);
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
         float mu, r, sc, sh; double var;
         bn_finalize_channel(f.rows, C, ch, f.count, f.eps, f.gamma[ch], f.beta[ch], &mu, &r, &sc, &sh, &var);
@@ -764,29 +787,24 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
         }
     }
     __syncthreads();
-    const int cv = C >> 3;
-    const long total = (long)p.M * cv;
-    const int HW = p.H * p.W;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(it / cv);
-        const int c = (int)(it - (long)m * cv) << 3;
-        const int b = m / HW;
-        const int r = m - b * HW;
-        const int y = r / p.W;
-        const int x = r - y * p.W;
+    while (have) {
+        // the next item's operands are requested before this one is computed (two items in flight per thread)
+        const long nx = it + stride;
+        const bool hn = nx < total;
+        uint4 zn = zc, rn = rc; size_t on = oo; int cn = c;
+        if (hn) load_item(nx, zn, rn, on, cn);
         float v[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c), v);
+        unpack8(zc, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = v[j] * s_sc[c + j] + s_sh[c + j];
         if (p.res_kind == 1) {
             float rr[8];
-            const size_t ro = ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * C + c;
-            unpack8(*reinterpret_cast<const uint4*>(p.res + ro), rr);
+            unpack8(rc, rr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j];
         } else if (p.res_kind == 2) {
             float rr[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.res + (size_t)m * C + c), rr);
+            unpack8(rc, rr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rr[j] * s_rsc[c + j] + s_rsh[c + j];
         }
@@ -794,7 +812,6 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
         }
-        const size_t oo = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + c;
         const uint4 ov = pack8(v);
         *reinterpret_cast<uint4*>(p.out + oo) = ov;
         if (p.mask_out) {      // bit j = the STORED bf16 value is > 0 (values are >= 0 after the ReLU: non-zero bits)
@@ -807,6 +824,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
             }
             p.mask_out[it] = (unsigned char)bits;      // it = m * (C / 8) + c / 8
         }
+        it = nx; have = hn; zc = zn; rc = rn; oo = on; c = cn;
     }
 }
 
@@ -1013,6 +1031,29 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
     extern __shared__ float sm[];                      // A[C] B[C] D[C] (A2[C] B2[C] D2[C])
     const int C = p.C;
     float* sA = sm; float* sB = sm + C; float* sD = sm + 2 * C;
+    // as in bn_fwd_fused_kernel: the first item's operands are requested before the coefficient prologue, the next item's
+    // before the current one is computed
+    const int cv = C >> 3;
+    const long total = (long)p.M * cv;
+    const int HW = p.H * p.W;
+    const long stride = (long)gridDim.x * blockDim.x;
+    auto load_item = [&](long i, uint4& gv, uint4& zv, uint4& z2v, unsigned& bits, size_t& o, int& cc) __attribute__((always_inline)) {
+        const int m = (int)(i / cv);
+        cc = (int)(i - (long)m * cv) << 3;
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int y = r / p.W;
+        const int x = r - y * p.W;
+        gv = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + cc);
+        zv = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + cc);
+        if (PAIR) z2v = *reinterpret_cast<const uint4*>(f.z2 + (size_t)m * C + cc);
+        bits = p.mask_bits[i];                                     // i = m * (C / 8) + c / 8
+        o = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + cc;
+    };
+    long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = it < total;
+    uint4 gc = uint4{0u, 0u, 0u, 0u}, zc = gc, z2c = gc; unsigned bc = 0; size_t oo = 0; int c = 0;
+    if (have) load_item(it, gc, zc, z2c, bc, oo, c);
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
         bn_bwd_apply_coef(f.rows, C, ch, f.count, f.gamma[ch], f.mean[ch], f.rstd[ch], sA, sB, sD, f.dgamma, f.dbeta,
                           blockIdx.x == 0);
@@ -1021,33 +1062,27 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
                               sD + 3 * C, f.dgamma2, f.dbeta2, blockIdx.x == 0);
     }
     __syncthreads();
-    const int cv = C >> 3;
-    const long total = (long)p.M * cv;
-    const int HW = p.H * p.W;
-    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(it / cv);
-        const int c = (int)(it - (long)m * cv) << 3;
-        const int b = m / HW;
-        const int r = m - b * HW;
-        const int y = r / p.W;
-        const int x = r - y * p.W;
+    while (have) {
+        const long nx = it + stride;
+        const bool hn = nx < total;
+        uint4 gn = gc, zn = zc, z2n = z2c; unsigned bn_ = bc; size_t on = oo; int cn = c;
+        if (hn) load_item(nx, gn, zn, z2n, bn_, on, cn);
         float g[8], z[8], o[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c), g);
-        unpack8(*reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c), z);
-        const unsigned bits = p.mask_bits[it];                     // it = m * (C / 8) + c / 8
+        unpack8(gc, g);
+        unpack8(zc, z);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
+            g[j] = ((bc >> j) & 1u) ? g[j] : 0.f;
             o[j] = sA[c + j] * g[j] + sB[c + j] * z[j] + sD[c + j];
         }
-        const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
         *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
         if (PAIR) {      // same g, the branch's own z and coefficients, same padded geometry
-            unpack8(*reinterpret_cast<const uint4*>(f.z2 + (size_t)m * C + c), z);
+            unpack8(z2c, z);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = sA[3 * C + c + j] * g[j] + sB[3 * C + c + j] * z[j] + sD[3 * C + c + j];
             *reinterpret_cast<uint4*>(f.dz2 + oo) = pack8(o);
         }
+        it = nx; have = hn; gc = gn; zc = zn; z2c = z2n; bc = bn_; oo = on; c = cn;
     }
 }
 
