@@ -85,6 +85,33 @@ static __device__ __forceinline__ void conv_acc_prefetch(const ConvParams& p, in
             f.old[a][b] = *reinterpret_cast<const uint2*>(p.y + (size_t)mc * p.yC + n0 + wn * WTN + a * 16 + 4 * fq);
     }
 }
+// Eval epilogue (EPM 3) with a residual: the residual fragments of the tile, requested ahead of the epilogue (the persistent
+// kernels: before or during the tile's MFMA loop) -- inside the epilogue they are one exposed round trip per tile.
+template <int NI, int MI>
+struct ResFrag {
+    uint2 r[NI][MI];
+};
+template <int BM, int BN, int WM, int WN>
+static __device__ __forceinline__ void conv_res_prefetch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
+                                                         ResFrag<BN / WN / 16, BM / WM / 16>& f, int wave_base = 0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = (threadIdx.x >> 6) - wave_base;
+    const int wm = wave % WM, wn = wave / WM;
+    const int fr = lane & 15, fq = lane >> 4;
+    const PixSplit ps = pix_split_init(p, geo);
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = mtile * BM + wm * WTM + b * 16 + fr;
+        const int mc = m < geo.M ? m : geo.M - 1;
+        int bi, yy, xx;
+        pix_split(ps, mc, bi, yy, xx);
+        const size_t roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            f.r[a][b] = *reinterpret_cast<const uint2*>(p.res + roff + n0 + wn * WTN + a * 16 + 4 * fq);
+    }
+}
 // (at most 4 pixel groups at a time: 8 of them are 64 registers on top of 128 accumulators)
 #define VPD_BST_MB(MI) ((MI) > 4 ? 4 : (MI))
 template <int BM, int BN, int WM, int WN>
@@ -159,7 +186,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                                                           float (&s2)[BN / WN / 16][4], const ConvGeo& geo, int wave_base,
                                                           BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& own,
                                                           const AccFrag<BN / WN / 16, BM / WM / 16>* accf,
-                                                          BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& pr) {
+                                                          BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& pr,
+                                                          const ResFrag<BN / WN / 16, BM / WM / 16>* resf = nullptr) {
     constexpr int WTM = BM / WM;
     constexpr int WTN = BN / WN;
     constexpr int MI = WTM / 16;
@@ -229,7 +257,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (p.res) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + roff + n);
+                    const uint2 rv = resf ? resf->r[a][b] : *reinterpret_cast<const uint2*>(p.res + roff + n);
                     v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
                     v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
                 }
@@ -297,6 +325,16 @@ static __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 
     BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> own;
     BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
     conv_epilogue_impl<BM, BN, WM, WN, EPM, false>(p, acc, mtile, n0, s1, s2, geo, wave_base, own, nullptr, pr);
+}
+// ... eval epilogue with the residual fragments fetched by the caller (conv_res_prefetch; p.res != null)
+template <int BM, int BN, int WM, int WN, int EPM>
+static __device__ __forceinline__ void conv_epilogue_res_pre(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                             int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                             float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
+                                                             const ResFrag<BN / WN / 16, BM / WM / 16>& resf, int wave_base = 0) {
+    BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> own;
+    BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, false>(p, acc, mtile, n0, s1, s2, geo, wave_base, own, nullptr, pr, &resf);
 }
 // ... with the consuming BatchNorm's z fragments / mask bits fetched by the caller (EPM 6 / 7 only)
 template <int BM, int BN, int WM, int WN, int EPM>

@@ -829,6 +829,10 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
 #pragma unroll
             for (int b = 0; b < MI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
         const unsigned hbb = lds0 + (unsigned)(9 * BN * 64 * 2) + (unsigned)(i & 1) * (HBUF * 2u);
+        // eval with a residual: its fragments are requested before the tile's nine K-steps instead of inside the epilogue
+        ResFrag<NI, MI> resf;
+        const bool res_pre = EPM == 3 && p.res != nullptr;
+        if (res_pre) conv_res_prefetch<128, BN, 4, 1>(p, 2 * t + grp, 0, geo, resf, grp * 4);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const unsigned S = hbb + (unsigned)(((p.taps.dy0 + (tap / 3) * p.taps.dys) * Wp + p.taps.dx0 + (tap % 3) * p.taps.dxs) * 128);
@@ -848,7 +852,8 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
             }
         }
         // this group's 128 pixels are output tile 2t + grp of the 128-pixel tiling
-        conv_epilogue<128, BN, 4, 1, EPM>(p, acc, 2 * t + grp, 0, st1, st2, geo, grp * 4);
+        if (res_pre) conv_epilogue_res_pre<128, BN, 4, 1, EPM>(p, acc, 2 * t + grp, 0, st1, st2, geo, resf, grp * 4);
+        else conv_epilogue<128, BN, 4, 1, EPM>(p, acc, 2 * t + grp, 0, st1, st2, geo, grp * 4);
         __builtin_amdgcn_s_barrier();                             // B_{i+1}
     }
     if (EPM == 1) {

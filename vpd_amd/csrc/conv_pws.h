@@ -73,6 +73,9 @@ static __device__ __forceinline__ void pws_lgkm0() {
 // HBM round trip per tile (in-step stamps: 8,300 cycles of mode-6 epilogue on 64 x 64 wave tiles against 3,700 for mode 1).
 // NEGATIVE: the step got slower with it (the epilogue's exposure is not an L2 miss; the extra DMA competes with the loaders).
 // Lane (fr, fq): pixel fr of group b; fq picks the tensor (every tensor's 64-channel slice of a pixel is one 128-byte line).
+#ifndef PWS_RES_EARLY
+#define PWS_RES_EARLY 1      // eval: residual fragments requested at the start of a tile's last chunk
+#endif
 #ifndef PWS_TOUCH
 #define PWS_TOUCH 0      // measured: -1.2 % (256 crops), -1.5 % (512), -1.6 % (apply) same-box -- profiles/r03_epilogue_touch_negative.txt
 #endif
@@ -420,9 +423,14 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         // tile has no registers for them) they cost the data gradients ~2 us of exposed memory latency per tile (in-step stamps:
         // 8,400 cycles of epilogue against 3,700 for the plain forward store).  Mode 8 has no registers left for it.
         BstFrag<NI, VPD_BST_MB(MI)> bst;
+        // eval with a residual (mode 3): its fragments likewise, where the registers are there (not on the eight-wave tile)
+        constexpr bool RES_EARLY = PIPE && EPM == 3 && PWS_RES_EARLY;
+        ResFrag<NI, MI> resf;
+        const bool res_pre = RES_EARLY && p.res != nullptr;
 #pragma nounroll
         for (int row = 0; row < nrows; ++row) {
             if (BST_EARLY && row == nrows - 3) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+            if (RES_EARLY && res_pre && row == nrows - 3) conv_res_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, resf);
             if (PWS_TOUCH && row == nrows - 3) pws_epilogue_touch<BM, BN, WM, WN, EPM, !BST_EARLY>(p, mtile, n0, geo, lds0 + OFF_DUMP);
             // the next tap row: the same chunk's, or the first one of the next chunk (other halo buffer)
             const bool wrap = ir == 2;
@@ -475,6 +483,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         if (EPM == 8) conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr);
         if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
+        else if (RES_EARLY && res_pre) conv_epilogue_res_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, resf);
         else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
         if (job == 0) PWS_STAMP(4);                                  // first tile's epilogue issued
     }
