@@ -33,7 +33,10 @@ def timeit(fn, iters=50):
 
 
 out = []
-for name, ci, co, hw in (("l2", 128, 128, 16), ("l3", 256, 256, 8), ("l4", 512, 512, 4)):
+LAYERS = (("l1", 64, 64, 32), ("l2", 128, 128, 16), ("l3", 256, 256, 8), ("l4", 512, 512, 4))
+if os.environ.get("BENCH_PWS_LAYERS"):
+    LAYERS = tuple(t for t in LAYERS if t[0] in os.environ["BENCH_PWS_LAYERS"].split(","))
+for name, ci, co, hw in LAYERS:
     x = torch.randn(B * (hw + 2) * (hw + 2) * ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(9 * co * ci, device="cuda") * 0.05).to(torch.bfloat16)
     y = torch.zeros(B * hw * hw * co, device="cuda", dtype=torch.bfloat16)
