@@ -396,6 +396,44 @@ def format_case(ref):
     return res
 
 
+WELLCOND_ARCHS = ["resnet18", "resnet34", "resnet50"]
+WC_SAMPLES = 512
+
+
+def wellcond_case(ref, arch):
+    """Gradients of the REFERENCE student (models/rgb.py:46-70 + models/module.py ResNet, train mode, sum-MSE:
+    train_vpd_model.py:79-91) in the well-conditioned regime of tests/test_model_gpu.py: reference initialisation
+    (oracle.reference_init_state_dict, seed 3) with the last BatchNorm gamma of every residual branch scaled to 0.1, summed over
+    three 8-crop batches, each from fresh running statistics.  Stored: WC_SAMPLES evenly spaced elements of every parameter's
+    summed gradient (sample_idx), its norm, and the three losses -- the HIP gradients are compared with the reference's
+    OWN numbers here, not with the oracle's restatement of them."""
+    _, ref_rgb, _, ref_train, _, _ = ref
+    sd = O.reference_init_state_dict(arch, 5, 32, 3)
+    last = ".bn3.weight" if O.arch_expansion(arch) == 4 else ".bn2.weight"
+    for k in sd:
+        if k.endswith(last):
+            sd[k] = sd[k] * 0.1
+    out = {"meta": json.dumps(dict(arch=arch, c_in=5, emb_dim=32, n=8, hw=128, batches=3, init_seed=3, last_bn_scale=0.1,
+                                   crop_seeds=[5, 15, 25], target_seeds=[6, 16, 26], samples=WC_SAMPLES))}
+    acc, losses = {}, []
+    for b in range(3):
+        enc = ref_rgb.RGBF_EmbeddingModel(arch, 32, True, "cpu")
+        enc.load_state_dict(sd)
+        enc.train()
+        img, tgt = O.synthetic_crops(8, 5, 128, 5 + 10 * b), O.synthetic_targets(8, 32, False, 6 + 10 * b)
+        loss = torch.nn.functional.mse_loss(enc(img), tgt, reduction="sum")
+        loss.backward()
+        losses.append(float(loss.item()))
+        for k, q in enc.named_parameters():
+            acc[k] = acc.get(k, 0.0) + q.grad.detach().double()
+    out["losses"] = np.asarray(losses, np.float64)
+    for k, g in acc.items():
+        flat = g.reshape(-1)
+        out["gnorm/" + k] = np.float64(flat.norm().item())
+        out["gsamp/" + k] = flat[torch.from_numpy(sample_idx(flat.numel(), WC_SAMPLES))].numpy().astype(np.float32)
+    return out
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -418,6 +456,10 @@ def main():
         with open(os.path.join(OUT, "init_stats.json"), "w") as fp:
             json.dump(init_case(ref), fp, indent=0, sort_keys=True)
         print("wrote init_stats.json")
+    for arch in WELLCOND_ARCHS:
+        if not only or "wellcond" in only.split(","):
+            np.savez_compressed(os.path.join(OUT, "wc_grads_%s.npz" % arch), **wellcond_case(ref, arch))
+            print("wrote wc_grads_" + arch)
     if not only:
         np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
         np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))

@@ -409,6 +409,59 @@ def test_batchnorm_backward_sums_on_a_bottleneck_student(tmp_path):
     assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
 
 
+def _wc_sample_idx(numel, k=512):
+    return np.unique(np.linspace(0, numel - 1, k).astype(np.int64))      # oracle/gen_golden.py::sample_idx
+
+
+# Gate of test_backward_matches_the_reference_gradients: HIP (bf16 operands) against the REFERENCE's fp32 gradients, per stage
+WC_COS_MIN, WC_PROJ_TOL = 0.95, 0.06
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet34", "resnet50"])
+def test_backward_matches_the_reference_gradients(arch):
+    """VERDICT r2 (parity soft spot 1): the HIP gradients against numbers the REFERENCE itself produced -- not the oracle's
+    restatement: tests/golden/wc_grads_<arch>.npz holds 512 evenly spaced elements of every parameter's gradient from the
+    reference's own modules (oracle/gen_golden.py::wellcond_case: models/rgb.py:46-70, models/module.py:35-130, sum-MSE
+    train_vpd_model.py:87), summed over three 8-crop batches, in the well-conditioned regime (last BatchNorm gamma of every
+    residual branch x 0.1) where bf16 rounding noise is small against the gradient.  Per network stage, on the sampled
+    coordinates (10-20 k per stage: the sampling error of a projection is ~1e-3): cosine >= 0.95 and projection
+    <g_hip, g_ref> / |g_ref|^2 = 1 +- 6 % (fp32 reference vs bf16 path; the same-precision gate is the emulation test below),
+    losses within 5e-3."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    g = np.load(os.path.join(GOLDEN, "wc_grads_%s.npz" % arch))
+    sd = O.reference_init_state_dict(arch, 5, 32, 3)
+    last = ".bn3.weight" if O.arch_expansion(arch) == 4 else ".bn2.weight"
+    for k in sd:
+        if k.endswith(last):
+            sd[k] = sd[k] * 0.1
+    enc = RGBF_EmbeddingModel(arch, 32, True, "cuda")
+    tr = ModelTrainer(enc, False)
+    acc, losses = {}, []
+    for b in range(3):
+        enc.load_state_dict(sd)                               # fresh running statistics, as in the golden
+        enc.train()
+        img, tgt = O.synthetic_crops(8, 5, 128, 5 + 10 * b), O.synthetic_targets(8, 32, False, 6 + 10 * b)
+        loss = tr._forward_loss(img, tgt, train=True)
+        losses.append(loss.item())
+        loss.backward()
+        torch.cuda.synchronize()
+        for n, q in enc.named_parameters():
+            acc[n] = acc.get(n, 0.0) + q.grad.detach().cpu().double()
+    for lh, lr in zip(losses, g["losses"]):
+        assert abs(lh - lr) <= 5e-3 * lr, (losses, g["losses"])
+    stage = {}
+    for n in acc:
+        ref = g["gsamp/" + n].astype(np.float64)
+        mine = acc[n].reshape(-1)[torch.from_numpy(_wc_sample_idx(acc[n].numel()))].numpy()
+        v = stage.setdefault(_group_of(n), [0.0, 0.0, 0.0])
+        v[0] += float((mine * ref).sum()); v[1] += float((ref * ref).sum()); v[2] += float((mine * mine).sum())
+    res = {k: (round(v[0] / (v[1] * v[2]) ** 0.5, 4), round(v[0] / v[1], 4)) for k, v in stage.items()}      # (cos, projection)
+    _dump("reference_grads_%s" % arch, {"arch": arch, "columns": ["cos", "projection"], "hip_vs_reference": res})
+    print(res)
+    assert all(c >= WC_COS_MIN and abs(pj - 1) <= WC_PROJ_TOL for c, pj in res.values()), res
+
+
 _BUSY_SCRIPT = r"""
 import sys, json, numpy as np, torch
 sys.path.insert(0, {repo!r})
