@@ -95,3 +95,60 @@ def test_bucketed_sum_all_reduce_world2(N):
     rel = np.linalg.norm(got - exp.numpy()) / np.linalg.norm(exp.numpy())
     assert rel < 1e-4, rel      # fp32 CPU conv reductions differ slightly with the thread count
     assert abs(stats[0] - loss_sum) < 1e-6 * abs(loss_sum) and int(stats[1]) == N
+
+
+def _lazy_worker(rank, world, port, q, async_op):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vpd_amd.ddp import all_reduce_lazy
+    g = torch.Generator().manual_seed(100 + rank)
+    # the plan's layout in miniature: one workspace, three bucket ranges of conv gradients in the kernels' own layout (one of
+    # them empty: a bucket without 3x3 convs), and a flat gradient buffer whose non-conv tensors are scattered through it
+    ws = torch.randn(5000, generator=g)
+    views = [ws[100:1300], ws[2000:2000], ws[2600:4999]]
+    flat = torch.randn(3000, generator=g)
+    small_idx = torch.cat([torch.arange(0, 64), torch.arange(1000, 1130), torch.arange(2990, 3000)])
+    before_ws, before_flat = ws.clone(), flat.clone()
+    works, finish = all_reduce_lazy(views, flat, small_idx, None, async_op=async_op)
+    for w in works:
+        w.wait()
+    finish()
+    if rank == 0:
+        q.put((ws.numpy(), flat.numpy(), before_ws.numpy(), before_flat.numpy()))
+    else:
+        q.put((None, None, before_ws.numpy(), before_flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("async_op", [False, True], ids=["blocking", "async"])
+def test_lazy_gradient_all_reduce_world2(async_op):
+    """Round 3: under data parallelism the conv weight gradients are summed where the weight-gradient kernels left them
+    (per-bucket views of the workspace) and everything else travels as ONE gathered message (vpd_amd/ddp.py::all_reduce_lazy).
+    Two gloo ranks: the views and exactly the indexed elements of the flat buffer hold the SUM over ranks (the loss is a sum
+    over crops: train_vpd_model.py:87), every other element is untouched."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + int(async_op)
+    procs = [ctx.Process(target=_lazy_worker, args=(r, world, port, q, async_op)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got = [o for o in outs if o[0] is not None][0]
+    ws_sum = outs[0][2] + outs[1][2]
+    flat_sum = outs[0][3] + outs[1][3]
+    ws, flat, ws0, flat0 = got
+    for a, b in ((100, 1300), (2600, 4999)):
+        assert np.array_equal(ws[a:b], ws_sum[a:b])
+    for a, b in ((0, 100), (1300, 2600), (4999, 5000)):
+        assert np.array_equal(ws[a:b], ws0[a:b])                  # outside the bucket ranges: rank 0's own values
+    idx = np.concatenate([np.arange(0, 64), np.arange(1000, 1130), np.arange(2990, 3000)])
+    mask = np.zeros(3000, bool)
+    mask[idx] = True
+    assert np.array_equal(flat[mask], flat_sum[mask])
+    assert np.array_equal(flat[~mask], flat0[~mask])
