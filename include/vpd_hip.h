@@ -160,6 +160,14 @@ int vpd_plan_stage_crops(vpd_plan_t* plan, const unsigned char* rgb_u8, const un
                          int height, int width, const float* mean_std6, float noise_sd, float* scratch,
                          void* workspace, void* stream);
 
+/* Inference views of decoded u8 frames (apply_vpd_model.py:94-118 builds them through FrameDataset,
+ * vpd_dataset/single_frame.py:377-400): view 0 = the frame, view 1 (k_views == 2) = its horizontal flip with the x-flow
+ * negated; normalised like vpd_plan_stage_crops with identity parameters (bit-identical), no resize (height / width must be
+ * the plan's), written to the stem staging buffer as n_frames * k_views crops in the order [f0 v0, f0 v1, f1 v0, ...].
+ * Follow with vpd_forward_eval / vpd_graph_capture_eval with x == NULL. */
+int vpd_plan_stage_views(vpd_plan_t* plan, const unsigned char* rgb_u8, const unsigned char* flow_u8, int n_frames,
+                         int k_views, int height, int width, const float* mean_std6, void* workspace, void* stream);
+
 int vpd_graph_capture_eval(vpd_plan_t* plan, const float* params, const float* x, int n, float* emb_out,
                            void* workspace, void* stream);
 int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);

@@ -172,3 +172,29 @@ def test_u8_apply_path_matches_reference_golden_and_the_fp32_views(tmp_path):
             assert fa == fb and ea.shape == eb.shape == (2, D)
             assert np.array_equal(ea, eb), float(np.abs(ea - eb).max())
             assert not np.array_equal(eb[0], eb[1])               # the flipped view is a different crop
+
+
+@pytest.mark.parametrize("c_in", [5, 3])
+def test_table_driven_view_staging_equals_the_general_pipeline(c_in, monkeypatch):
+    """vpd_plan_stage_views (one table look-up per byte; apply path) against vpd_plan_stage_crops with identity parameters
+    (the train-time kernel: per-pixel divisions), k = 1 and k = 2: the embeddings must agree bit for bit -- the tables hold
+    the same expressions evaluated for every possible byte (vpd_dataset/common.py:52-69, single_frame.py:377-400)."""
+    from vpd_amd.augment import CropAugmenter
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    hw, n = 128, 37
+    enc = RGBF_EmbeddingModel("resnet18", 32, c_in == 5, "cuda")
+    enc.reset_parameters(seed=2)
+    enc.eval()
+    aug = CropAugmenter("cuda", O.DIVING48_MEAN_STD, hw, c_in == 5)
+    rgb, flow = O.synthetic_crops_u8(n, 5, hw, 33)
+    rgb = rgb.cuda()
+    flow = flow.cuda() if c_in == 5 else None
+    for flip in (False, True):
+        embs = []
+        for fast in ("1", "0"):
+            monkeypatch.setenv("VPD_FAST_VIEWS", fast)
+            staged = aug.stage_views(enc.engine, rgb, flow, flip)
+            assert staged == (n * (2 if flip else 1), hw)
+            embs.append(enc.engine.forward_eval(None, staged=staged).cpu().numpy().copy())
+        assert np.isfinite(embs[0]).all() and np.abs(embs[0]).max() > 0
+        assert np.array_equal(embs[0], embs[1]), float(np.abs(embs[0] - embs[1]).max())

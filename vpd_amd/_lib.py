@@ -44,6 +44,7 @@ SIGNATURES = {
                                     C.c_float, vp, vp, vp]),
     "vpd_plan_stage_crops": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                        C.c_float, vp, vp, vp]),
+    "vpd_plan_stage_views": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), vp, vp]),
     "vpd_graph_capture_eval": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp]),
     "vpd_graph_launch_eval": (C.c_int, [vp, C.c_int, vp]),
     "vpd_plan_sync_errors": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint)]),

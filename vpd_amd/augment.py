@@ -17,6 +17,8 @@ mixes Python's and torch's generators, so there is no reference random stream to
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -162,6 +164,11 @@ class CropAugmenter:
         view) when `flip`, else the frame itself.  Returns (n * k, img_dim) for forward_eval / the staged eval graph."""
         n, h, w, _ = rgb_u8.shape
         k = 2 if flip else 1
+        if h == self.img_dim and w == self.img_dim and w % 4 == 0 and os.environ.get("VPD_FAST_VIEWS", "1") != "0":
+            # frames already have the model's size (the apply path): the dedicated table-driven kernel, no parameter
+            # records, no duplicated frames (VPD_FAST_VIEWS=0: the general pipeline with identity parameters, below)
+            engine.stage_views(rgb_u8, flow_u8, k, self.mean_std6)
+            return n * k, self.img_dim
         key = (n, k, h, w)
         cache = self.__dict__.setdefault('_view_params', {})
         if key not in cache:

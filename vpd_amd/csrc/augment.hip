@@ -300,3 +300,68 @@ hipError_t vpd_launch_augment(const unsigned char* rgb, const unsigned char* flo
     hipLaunchKernelGGL(aug_apply_kernel, dim3((out_dim + AUG_ROWS - 1) / AUG_ROWS, N), dim3(128), 0, s, g);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------
+// Inference views of decoded u8 frames (vpd_dataset/single_frame.py:377-400: [frame, h-flipped frame], no resize, no jitter):
+// the generic kernel above spends ~200 instructions per pixel on byte loads and fp32 / fp64 divisions (244 us per 1,000 views
+// of 128 x 128: 1.4 TB/s).  A u8 channel takes 256 values, so the normalisation is a table: each block evaluates the SAME
+// expressions as source_pixel() once per possible byte ((u / 255 - mean) / std in fp32; u / 255 - 0.5 in double, rounded to
+// float), rounds to bf16 as aug_store() does, and the pixels are five LDS look-ups -- bit-identical output, memory-bound.
+// One thread produces four consecutive output pixels of one view (64 bytes of the staging row).
+// ---------------------------------------------------------------------------
+struct ViewArgs {
+    const unsigned char* rgb; const unsigned char* flow;      // [F][H][W][3], [F][H][W][2] or null
+    int F, K, H, W;                                           // K views per frame: view k = 1 is the h-flip
+    float mean[3], std[3];
+    bf16_t* xin; int xHp, xWp, xpad;                          // [F*K][xHp][xWp][8]
+};
+__global__ __launch_bounds__(256) void aug_views_kernel(const ViewArgs g) {
+    __shared__ unsigned short lut[5][256];
+    {
+        const int t = threadIdx.x;                            // blockDim.x == 256
+        const float c = (float)t / 255.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lut[k][t] = f2bf((c - g.mean[k]) / g.std[k]);
+        const float f = (float)((double)t / 255.0 - 0.5);
+        lut[3][t] = f2bf(f);                                  // x-flow (the flipped view negates it: sign bit)
+        lut[4][t] = lut[3][t];
+    }
+    __syncthreads();
+    const int view = blockIdx.y;
+    const int frame = view / g.K;
+    const bool flip = (view - frame * g.K) == 1;
+    const int q = blockIdx.x * 256 + threadIdx.x;             // quad of output pixels inside the view
+    const int wq = g.W >> 2;
+    if (q >= g.H * wq) return;
+    const int y = q / wq, x0 = (q - y * wq) << 2;
+    const size_t row = ((size_t)frame * g.H + y) * g.W;
+    bf16_t* dst = g.xin + (((size_t)view * g.xHp + y + g.xpad) * g.xWp + x0 + g.xpad) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int xs = flip ? g.W - 1 - (x0 + i) : x0 + i;
+        const unsigned char* pr = g.rgb + (row + xs) * 3;
+        uint4 o;
+        o.x = (unsigned)lut[0][pr[0]] | ((unsigned)lut[1][pr[1]] << 16);
+        unsigned fx = 0, fy = 0;
+        if (g.flow) {
+            const unsigned char* pf = g.flow + (row + xs) * 2;
+            fx = lut[3][pf[0]];
+            if (flip) fx ^= 0x8000u;
+            fy = lut[4][pf[1]];
+        }
+        o.y = (unsigned)lut[2][pr[2]] | (fx << 16);
+        o.z = fy;
+        o.w = 0u;
+        *reinterpret_cast<uint4*>(dst + i * 8) = o;
+    }
+}
+hipError_t vpd_launch_views(const unsigned char* rgb, const unsigned char* flow, int F, int K, int H, int W,
+                            const float* mean_std6, bf16_t* xin, int xHp, int xWp, int xpad, hipStream_t s) {
+    ViewArgs g;
+    g.rgb = rgb; g.flow = flow; g.F = F; g.K = K; g.H = H; g.W = W;
+    for (int i = 0; i < 3; ++i) { g.mean[i] = mean_std6[i]; g.std[i] = mean_std6[3 + i]; }
+    g.xin = xin; g.xHp = xHp; g.xWp = xWp; g.xpad = xpad;
+    const int quads = H * (W / 4);
+    hipLaunchKernelGGL(aug_views_kernel, dim3((quads + 255) / 256, F * K), dim3(256), 0, s, g);
+    return hipGetLastError();
+}

@@ -169,3 +169,5 @@ hipError_t vpd_launch_augment(const unsigned char* rgb, const unsigned char* flo
                               const float* noise, const vpd_aug_params* params, int N, int H, int W, int out_dim,
                               const float* mean_std6, float noise_sd, float* out_nchw, bf16_t* xin, int xHp, int xWp,
                               int xpad, float* cmean_scratch, hipStream_t s);
+hipError_t vpd_launch_views(const unsigned char* rgb, const unsigned char* flow, int F, int K, int H, int W,
+                            const float* mean_std6, bf16_t* xin, int xHp, int xWp, int xpad, hipStream_t s);

@@ -1664,6 +1664,23 @@ extern "C" int vpd_plan_stage_crops(vpd_plan_t* p, const unsigned char* rgb_u8, 
     return 0;
 }
 
+extern "C" int vpd_plan_stage_views(vpd_plan_t* p, const unsigned char* rgb_u8, const unsigned char* flow_u8, int n_frames,
+                                    int k_views, int height, int width, const float* mean_std6, void* workspace,
+                                    void* stream) {
+    if (n_frames < 0 || (k_views != 1 && k_views != 2)) return fail("k_views must be 1 (frame) or 2 (frame, h-flip)");
+    if (check_call(p, workspace, n_frames * k_views)) return -1;
+    if (!rgb_u8 || !mean_std6) return fail("null argument");
+    if (height != p->H || width != p->W) return fail("inference views are not resized: the frames must have the plan's size");
+    if (width % 4) return fail("width must be a multiple of 4");
+    if ((p->c_in == 5) != (flow_u8 != nullptr)) return fail("flow_u8 must be given exactly when the plan has 5 input channels");
+    if (p->c_in != 3 && p->c_in != 5) return fail("inference views: 3 or 5 input channels");
+    if (n_frames == 0) return 0;
+    char* ws = (char*)workspace;
+    LCHECK(vpd_launch_views(rgb_u8, flow_u8, n_frames, k_views, height, width, mean_std6,
+                            reinterpret_cast<bf16_t*>(ws + p->xin_off), p->xHp, p->xWp, 3, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam_v, long long numel,
                               double lr, double beta1, double beta2, double eps, double weight_decay, int step,
                               void* stream) {

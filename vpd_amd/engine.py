@@ -255,6 +255,16 @@ class StudentEngine:
                                          _ptr(pl.workspace), self._stream()), "vpd_plan_stage_crops")
         return pl
 
+    def stage_views(self, rgb_u8, flow_u8, k_views, mean_std6):
+        """Inference views [frame, h-flip] of decoded u8 frames straight into the EVAL plan's stem staging buffer
+        (vpd_plan_stage_views: table-driven normalisation, bit-identical to stage_crops with identity parameters)."""
+        n, h, w, _ = rgb_u8.shape
+        pl = self.plan(h, w, n * k_views, False, False)
+        ms = (C.c_float * 6)(*mean_std6)
+        check(lib().vpd_plan_stage_views(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), n, k_views, h, w, ms,
+                                         _ptr(pl.workspace), self._stream()), "vpd_plan_stage_views")
+        return pl
+
     def forward_train(self, x, target=None, motion=False, accumulate_loss=True, staged=None):
         if staged is not None:      # (n, img_dim): the batch is already in the staging buffer (stage_crops)
             n, h = staged
