@@ -66,6 +66,8 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
     (and pickles) while the GPU runs batch i."""
     eng = encoder.engine
     encoder.eval()
+    if os.environ.get("VPD_APPLY_GRAPH", "1") == "0":
+        use_graph = False
     all_embs = None if writer is not None else [list() for _ in range(n_videos)]
     # captured graphs (and the pinned staging buffers) live on the engine: a second call with the same batch shape replays
     # them instead of paying capture + instantiation again (tens of milliseconds: as much as several 1,000-crop batches)
