@@ -336,20 +336,38 @@ __global__ __launch_bounds__(256) void aug_views_kernel(const ViewArgs g) {
     const int y = q / wq, x0 = (q - y * wq) << 2;
     const size_t row = ((size_t)frame * g.H + y) * g.W;
     bf16_t* dst = g.xin + (((size_t)view * g.xHp + y + g.xpad) * g.xWp + x0 + g.xpad) * 8;
+    // the four source pixels are one aligned 12-byte (RGB) and one aligned 8-byte (flow) block -- of the mirrored position in
+    // the flipped view, read back to front: five dword loads per thread instead of twenty byte loads
+    const int xb = flip ? g.W - 4 - x0 : x0;
+    const unsigned* pr = reinterpret_cast<const unsigned*>(g.rgb + (row + xb) * 3);
+    const unsigned r0 = pr[0], r1 = pr[1], r2 = pr[2];
+    unsigned f0 = 0, f1 = 0;
+    if (g.flow) {
+        const unsigned* pf = reinterpret_cast<const unsigned*>(g.flow + (row + xb) * 2);
+        f0 = pf[0]; f1 = pf[1];
+    }
+    const unsigned long long rlo = (unsigned long long)r0 | ((unsigned long long)r1 << 32);      // bytes 0..7 of the RGB block
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int xs = flip ? g.W - 1 - (x0 + i) : x0 + i;
-        const unsigned char* pr = g.rgb + (row + xs) * 3;
+        const int j = flip ? 3 - i : i;                       // pixel of the block that lands at output position x0 + i
+        const unsigned cr = j * 3 < 8 ? (unsigned)(rlo >> (j * 24)) & 0xffu : (r2 >> ((j * 3 - 8) * 8)) & 0xffu;
+        unsigned cg, cb;
+        {
+            const int bg = j * 3 + 1, bb = j * 3 + 2;
+            cg = bg < 8 ? (unsigned)(rlo >> (bg * 8)) & 0xffu : (r2 >> ((bg - 8) * 8)) & 0xffu;
+            cb = bb < 8 ? (unsigned)(rlo >> (bb * 8)) & 0xffu : (r2 >> ((bb - 8) * 8)) & 0xffu;
+        }
         uint4 o;
-        o.x = (unsigned)lut[0][pr[0]] | ((unsigned)lut[1][pr[1]] << 16);
+        o.x = (unsigned)lut[0][cr] | ((unsigned)lut[1][cg] << 16);
         unsigned fx = 0, fy = 0;
         if (g.flow) {
-            const unsigned char* pf = g.flow + (row + xs) * 2;
-            fx = lut[3][pf[0]];
+            const unsigned fw = j < 2 ? f0 : f1;
+            const unsigned ux = (fw >> ((j & 1) * 16)) & 0xffu, uy = (fw >> ((j & 1) * 16 + 8)) & 0xffu;
+            fx = lut[3][ux];
             if (flip) fx ^= 0x8000u;
-            fy = lut[4][pf[1]];
+            fy = lut[4][uy];
         }
-        o.y = (unsigned)lut[2][pr[2]] | (fx << 16);
+        o.y = (unsigned)lut[2][cb] | (fx << 16);
         o.z = fy;
         o.w = 0u;
         *reinterpret_cast<uint4*>(dst + i * 8) = o;
