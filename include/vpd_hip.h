@@ -122,7 +122,9 @@ int vpd_plan_adamw_step(vpd_plan_t* plan, float* params, const float* grads, flo
  * otherwise).  Under data parallelism (bucket events given) a lazy backward leaves bucket b's conv gradients in the workspace
  * range vpd_plan_bucket_scratch_range(plan, b) (byte offset into the workspace, fp32 count): a SUM all-reduce is layout-
  * agnostic (train_vpd_model.py:87: the loss is a sum over crops), so the reducer sums that range and the non-conv tensors
- * (+ the stem) of the flat buffer; bucket b's event is recorded when both are final. */
+ * (+ the stem) of the flat buffer; bucket b's event is recorded when both are final.  While vpd_plan_grads_pending() == 1 an
+ * all-reduce of the FLAT buffer's bucket ranges is invalid: the conv ranges of `grads` are stale and vpd_plan_adamw_step reads
+ * the scratch -- a reducer must pick its buffers by vpd_plan_grads_pending(), not by its caller's word (vpd_amd/ddp.py does). */
 int vpd_plan_set_lazy_grads(vpd_plan_t* plan, int on);
 int vpd_plan_bucket_scratch_range(const vpd_plan_t* plan, int bucket, long long* ws_byte_offset, long long* numel);
 int vpd_plan_grads_pending(const vpd_plan_t* plan);

@@ -396,6 +396,35 @@ def format_case(ref):
     return res
 
 
+def reader_case(ref):
+    """Row f4's reader: pickles with REPEATED frame numbers (tennis: several crops of one frame), gaps, leading empty
+    frames and a single-frame video, written with the reference's store_pickle and densified by the reference's own
+    load_embs / group_by_frame (action_dataset/load.py:16-64), raw and row-normalised."""
+    _, _, _, _, ref_io, ref_load = ref
+    rdir = os.path.join(OUT, "reader")
+    os.makedirs(rdir, exist_ok=True)
+    rng = np.random.default_rng(77)
+    vids = {"rally_a": ([2, 2, 3, 7, 7, 7, 9], (16,)),            # 1-D embeddings, a frame seen 2x and 3x, gaps of 4 and 2
+            "rally_b": ([4, 6, 6, 11, 12, 12], (2, 16)),           # [K, D] embeddings, four leading empty frames
+            "one": ([5], (16,)),                                    # a single embedded frame
+            "zero_row": ([0, 3], (16,))}                            # an all-zero embedding: normalize_rows leaves it alone
+    for name, (frames, shape) in vids.items():
+        embs = [(int(f), rng.standard_normal(shape).astype(np.float32), {}) for f in frames]
+        if name == "zero_row":
+            embs[0] = (0, np.zeros(shape, np.float32), {})
+        ref_io.store_pickle(os.path.join(rdir, name + ".emb.pkl"), embs)
+    with open(os.path.join(rdir, "not_an_embedding.txt"), "w") as fp:      # load_embs must skip other files
+        fp.write("x\n")
+    res = {}
+    for norm in (False, True):
+        d = ref_load.load_embs(rdir, norm)
+        assert sorted(d) == sorted(vids)
+        for name, (dense, mask) in d.items():
+            res["dense/%d/%s" % (norm, name)] = dense
+            res["mask/%d/%s" % (norm, name)] = mask
+    return res
+
+
 WELLCOND_ARCHS = ["resnet18", "resnet34", "resnet50"]
 WC_SAMPLES = 512
 
@@ -460,6 +489,9 @@ def main():
         if not only or "wellcond" in only.split(","):
             np.savez_compressed(os.path.join(OUT, "wc_grads_%s.npz" % arch), **wellcond_case(ref, arch))
             print("wrote wc_grads_" + arch)
+    if not only or "reader" in only.split(","):
+        np.savez_compressed(os.path.join(OUT, "reader_case.npz"), **reader_case(ref))
+        print("wrote reader_case")
     if not only:
         np.savez_compressed(os.path.join(OUT, "adamw_injected.npz"), **adamw_case(ref))
         np.savez_compressed(os.path.join(OUT, "format_case.npz"), **format_case(ref))

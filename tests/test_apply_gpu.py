@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import vpd_oracle as O
-from tests.test_host_cpu import group_by_frame
+from vpd_amd.load import group_by_frame
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

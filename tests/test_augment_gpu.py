@@ -187,3 +187,22 @@ def test_trainer_draws_a_fresh_noise_key_per_batch():
     p2["seed"] = (p["seed"][0][0] ^ 1, p["seed"][0][1])
     b = aug(rgb.cuda(), flow.cuda(), mask.cuda(), p2)
     assert float((a[:, :3] - b[:, :3]).abs().max()) > 0.05 and torch.equal(a[:, 3:], b[:, 3:])
+
+
+def test_staging_calls_reject_more_rows_than_a_grid_holds():
+    """One grid row per view / crop: beyond gridDim.y = 65535 the staging entry points fail with a message,
+    not with an opaque launch error."""
+    import ctypes as C
+    from vpd_amd._lib import VpdHipError, check, lib
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+    pl = enc.engine.plan(64, 64, 4, False, False)
+    ms = (C.c_float * 6)(*[0.5] * 6)
+    one = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    with pytest.raises(VpdHipError, match="65535"):
+        check(lib().vpd_plan_stage_views(pl.handle, p(one), p(one), 32768, 2, 64, 64, ms, p(pl.workspace), None), "stage_views")
+    # the largest legal row count is refused for the plan's size, not for the grid
+    with pytest.raises(VpdHipError) as e:
+        check(lib().vpd_plan_stage_views(pl.handle, p(one), p(one), 65535, 1, 64, 64, ms, p(pl.workspace), None), "stage_views")
+    assert "65535" not in str(e.value)

@@ -38,6 +38,18 @@ def test_bucket_reducer_world1_matches_plain_run():
             opt.step()
             traj = [tr.epoch([{"img": img, "emb": tgt}], optimizer=opt, scaler=sc) for _ in range(2)]
             res.append((g.cpu().numpy(), traj))
+            if use_group:
+                # the reducer takes its mode from the plan: a caller's word that disagrees is an error, not a
+                # silent all-reduce of stale ranges
+                tr._forward_loss(img, tgt, train=True)
+                pl = enc.engine.backward(tr._reducer.event_handles(len(enc.engine._last[0].buckets)), lazy=True)
+                with pytest.raises(RuntimeError):
+                    tr._reducer.reduce(pl, lazy=False)
+                tr._reducer.reduce(pl)                      # lazy, as the plan says
+                enc.engine.materialize_grads()
+                torch.cuda.synchronize()
+                rel2 = float((enc.engine.grads - g).norm() / g.norm())
+                assert rel2 < 2.0 and np.isfinite(rel2)     # (two optimizer steps later: same order of magnitude, finite)
         # BN statistics and the generic weight-gradient kernel use fp32 atomics (summation order varies run to run,
         # measured 1e-6 .. 3e-5 on these gradients): a tight tolerance, not bitwise
         rel = np.linalg.norm(res[0][0] - res[1][0]) / np.linalg.norm(res[0][0])

@@ -12,29 +12,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, "tests", "golden", "format")
 
 
-def group_by_frame(embs):
-    """Test-side restatement of the downstream reader (reference action_dataset/load.py:16-43)."""
-    num_frames = max(x[0] for x in embs) + 1
-    shp = embs[0][1].shape
-    dense = np.zeros((num_frames, *shp)) if len(shp) == 2 else np.zeros((num_frames, shp[-1]))
-    counts = np.zeros(num_frames)
-    for i, e, _ in embs:
-        dense[i] += e
-        counts[i] += 1
-    frames = sorted({x[0] for x in embs})
-    prev = frames[0]
-    for fr in frames[1:]:
-        gap = fr - prev
-        for i in range(1, gap):
-            a = i / gap
-            dense[prev + i] = a * dense[prev] + (1. - a) * dense[fr]
-        prev = fr
-    return dense, counts > 0
-
-
-def test_reference_written_pickles_match_our_reader_restatement():
+def test_reference_written_pickles_match_the_product_reader():
+    """vpd_amd.load.group_by_frame (row f4, reference action_dataset/load.py:16-43) on pickles the reference wrote, against
+    the dense arrays the reference's own group_by_frame made of them."""
     g = np.load(os.path.join(REPO, "tests", "golden", "format_case.npz"))
     from vpd_amd.io import load_pickle
+    from vpd_amd.load import group_by_frame
     for tag in ("k1", "k2"):
         for vid in ("vidA", "vidB", "vidC"):
             embs = load_pickle(os.path.join(GOLDEN, "%s.%s.emb.pkl" % (vid, tag)))
@@ -43,7 +26,32 @@ def test_reference_written_pickles_match_our_reader_restatement():
             assert all(isinstance(t[0], int) and t[1].dtype == np.float32 and t[2] == {} for t in embs)
             assert embs[0][1].shape == ((2, 32) if tag == "k2" else (32,))
             dense, mask = group_by_frame(embs)
-            assert np.allclose(dense, g["dense/%s/%s" % (tag, vid)]) and np.array_equal(mask, g["mask/%s/%s" % (tag, vid)])
+            assert np.array_equal(dense, g["dense/%s/%s" % (tag, vid)]) and np.array_equal(mask, g["mask/%s/%s" % (tag, vid)])
+
+
+def test_reader_averages_repeated_frames_and_blends_gaps_like_the_reference(capsys):
+    """Repeated frame numbers are averaged (load.py:29-32), gaps blended with the reference's weights (:34-42), leading
+    frames stay zero, other files of the directory are skipped, norm=True L2-normalises rows and leaves all-zero rows
+    alone (:46-64): bit for bit the arrays the reference's load_embs produced (tests/golden/reader_case.npz)."""
+    from vpd_amd.load import group_by_frame, load_embs, normalize_rows
+    g = np.load(os.path.join(REPO, "tests", "golden", "reader_case.npz"))
+    rdir = os.path.join(REPO, "tests", "golden", "reader")
+    for norm in (False, True):
+        d = load_embs(rdir, norm)
+        assert sorted(d) == ["one", "rally_a", "rally_b", "zero_row"]
+        for name, (dense, mask) in d.items():
+            want = g["dense/%d/%s" % (norm, name)]
+            assert dense.dtype == np.float64 and dense.shape == want.shape
+            assert np.array_equal(dense, want), (norm, name, np.abs(dense - want).max())
+            assert np.array_equal(mask, g["mask/%d/%s" % (norm, name)])
+    assert "Loading embs:" in capsys.readouterr().out
+    # the properties themselves, on a hand-made list: frame 1 seen twice -> mean; frames 2, 3 blended; frame 0 empty
+    e = lambda v: np.full(4, v, np.float32)
+    dense, mask = group_by_frame([(1, e(2.0), {}), (1, e(4.0), {}), (4, e(9.0), {})])
+    assert mask.tolist() == [False, True, False, False, True]
+    assert np.array_equal(dense[0], np.zeros(4)) and np.array_equal(dense[1], e(3.0))
+    assert np.allclose(dense[2], 1 / 3 * 3.0 + 2 / 3 * 9.0) and np.allclose(dense[3], 2 / 3 * 3.0 + 1 / 3 * 9.0)
+    assert np.array_equal(normalize_rows(np.zeros((2, 3))), np.zeros((2, 3)))
 
 
 def test_config_and_loss_json_schema():
@@ -306,3 +314,41 @@ def test_frame_dataset_u8_items_equal_the_float_items(tmp_path):
         assert torch.equal(torch.cat([rgb, flow]), a["img"][0])
     with pytest.raises(ValueError):
         FrameDataset(tasks, 64, ms, augment_jitter=2, raw_u8=True)
+
+
+def test_no_test_video_holds_the_reference_test_split_out(tmp_path, monkeypatch, capsys):
+    """--no_test_video (train_vpd_model.py:125-156): the prefixes are the reference's (action_dataset/eval.py:3-43) and the
+    loaders drop every teacher pickle that starts with one of them; fx / diving48 derive theirs from the label files."""
+    sys.path.insert(0, REPO)
+    import train_vpd_model
+    from vpd_amd.data import RGB_MEAN_STD
+    from vpd_amd.splits import FS_TEST_PREFIXES, get_test_prefixes
+    assert FS_TEST_PREFIXES == ("men_olympic_short_program_2018", "men_world_short_program_2018",
+                                "women_olympic_short_program_2018", "women_world_short_program_2018")
+    t = get_test_prefixes("tennis")
+    assert len(t) == 12 and "front__usopen_2019_womens_osaka_gauff" in t and "wimbledon_2019_mens_semifinal_federer_nadal" in t
+    emb_dir = tmp_path / "embs"
+    emb_dir.mkdir()
+    rs = np.random.RandomState(0)
+    for name in ("men_world_short_program_2018_03", "men_world_short_program_2017_03"):
+        with open(emb_dir / (name + ".emb.pkl"), "wb") as fp:
+            pickle.dump([(f, rs.randn(2, 8).astype(np.float32), {"kp_score": 0.9}) for f in range(6)], fp)
+    kw = {"img_dim": 32, "flow_img_name": None, "embed_time": False, "rgb_mean_std": RGB_MEAN_STD["fs"], "target_len": 10,
+          "split_seed": 1}
+    tr, va, D = train_vpd_model.load_dataset("fs", dict(kw), str(emb_dir), None, True)
+    assert {x[0] for x in tr.data + va.data} == {"men_world_short_program_2017_03"}
+    assert "Excluded: men_world_short_program_2018_03" in capsys.readouterr().out
+    tr, va, D = train_vpd_model.load_dataset("fs", dict(kw), str(emb_dir), None, False)
+    assert len({x[0] for x in tr.data + va.data}) == 2
+    # label-file driven splits
+    gym = tmp_path / "gym99_val_element.txt"
+    gym.write_text("vidA_E_000100_000200_A_0010_0020 5\nvidB_E_000300_000400_A_0001_0002 7\n")
+    monkeypatch.setenv("VPD_GYM99_VAL_FILE", str(gym))
+    assert get_test_prefixes("fx") == ("vidA_E_000100_000200", "vidB_E_000300_000400")
+    dv = tmp_path / "Diving48_V2_test.json"
+    dv.write_text(json.dumps([{"vid_name": "a", "start_frame": 0, "end_frame": 5}, {"vid_name": "b", "start_frame": 0, "end_frame": 5}]))
+    monkeypatch.setenv("VPD_DIVING48_TEST_FILE", str(dv))
+    assert get_test_prefixes("diving48") == ("a", "b")
+    monkeypatch.setenv("VPD_DIVING48_TEST_FILE", str(tmp_path / "absent.json"))
+    with pytest.raises(FileNotFoundError):
+        get_test_prefixes("diving48")

@@ -768,6 +768,35 @@ def test_embed_contract_and_errors():
         enc3.embed(x)
 
 
+def test_pretrained_backbone_from_a_local_checkpoint(tmp_path, monkeypatch):
+    """pretrained=True (reference models/rgb.py:57-61) with the torchvision-format checkpoint read from disk: backbone tensors as
+    they are, the 3-channel stem turned into its channel mean over 5 channels (add_flow_to_model, :19-23), the 1000-way fc
+    replaced by a fresh embedding layer (replace_last_layer, :40-43); without a checkpoint the flag fails with instructions."""
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    monkeypatch.setenv("VPD_PRETRAINED_WEIGHTS", str(tmp_path))
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path / "no_hub"))
+    with pytest.raises(FileNotFoundError):
+        RGBF_EmbeddingModel("resnet18", 32, True, "cuda", pretrained=True)
+    ref = O.procedural_state_dict(O.encoder_schema("resnet18", 3, 1000), 41)
+    tv = {k[len("resnet."):]: v for k, v in ref.items()}            # torchvision names: conv1.weight, layer1.0.bn1.running_var, fc.*
+    assert tv["fc.weight"].shape == (1000, 512) and tv["conv1.weight"].shape == (64, 3, 7, 7)
+    torch.save(tv, str(tmp_path / "resnet18-deadbeef.pth"))
+    enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda", pretrained=True)
+    sd = enc.state_dict()
+    stem = tv["conv1.weight"].mean(dim=1, keepdim=True).expand(-1, 5, -1, -1)
+    assert torch.equal(sd["resnet.conv1.weight"].cpu(), stem)
+    for k in ("layer1.0.conv1.weight", "layer4.1.bn2.weight", "layer3.0.downsample.1.running_var", "bn1.running_mean"):
+        assert torch.equal(sd["resnet." + k].cpu(), tv[k]), k
+    assert sd["resnet.fc.weight"].shape == (32, 512) and float(sd["resnet.fc.weight"].abs().max()) <= 1 / np.sqrt(512) + 1e-6
+    # the forward uses them: eval embeddings == the oracle's with the same tensors
+    x = O.synthetic_crops(3, 5, 64, 8)
+    want = O.embed({k: v.cpu() for k, v in sd.items()}, x, "resnet18", True)
+    got = enc.embed(x)
+    assert (np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)).max() <= 2e-2
+    enc3 = RGBF_EmbeddingModel("resnet18", 32, False, "cuda", pretrained=True)      # 3 channels: the stem as it is
+    assert torch.equal(enc3.state_dict()["resnet.conv1.weight"].cpu(), tv["conv1.weight"])
+
+
 def test_ragged_batches_and_graph():
     """Ragged last batch (20000 mod B) and the hipGraph-captured eval forward give the same embeddings."""
     from vpd_amd.models.rgb import RGBF_EmbeddingModel

@@ -56,8 +56,9 @@ def get_moving_avg_loss(losses, n, key):
 def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
     if dataset == 'penn':
         raise NotImplementedError('PennDataset reads a hard-coded private path in the reference (out of scope)')
-    if no_test_video:
-        raise NotImplementedError('--no_test_video needs the reference action_dataset split lists (out of scope)')
+    if no_test_video:          # hold the downstream test videos out of distillation (train_vpd_model.py:125-156)
+        from vpd_amd.splits import get_test_prefixes
+        dataset_kwargs['exclude_prefixes'] = get_test_prefixes(dataset)
     if emb_dir is None:
         emb_dir = os.path.join(dataset_paths.ROOT[dataset], 'embs')
     if dataset == 'tennis':          # per-player crop directories, split over clips (train_vpd_model.py:121-128)

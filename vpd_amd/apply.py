@@ -2,8 +2,10 @@
 batches of BATCH_SIZE frames x k views -> embed -> per-video sorted list of
 (frame:int, f32[k,D] or f32[D], {}) -> <video>.emb.pkl.  The eval forward is
 hipGraph-captured per batch shape; embeddings leave the GPU once per batch."""
+import gc
 import os
 
+import numpy as np
 import torch
 
 from .io import store_pickle
@@ -37,6 +39,13 @@ class StreamingWriter:
         self.pending[video_id].append(item)
         self.remaining[video_id] -= 1
         if self.remaining[video_id] == 0:
+            self.flush(video_id)
+
+    def add_many(self, video_id, items):
+        """A run of one video's frames out of one batch (embed_dataset hands over runs, not frames)."""
+        self.pending[video_id].extend(items)
+        self.remaining[video_id] -= len(items)
+        if self.remaining[video_id] <= 0:
             self.flush(video_id)
 
     def flush(self, video_id):
@@ -77,27 +86,32 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
     def drain(job):
         ev, hbuf, video_ids, frame_nums, n_batch, k = job
         ev.synchronize()
-        embs = hbuf.numpy().reshape((n_batch, k, -1))
-        for i in range(n_batch):
-            item = (frame_nums[i], embs[i, :, :].copy() if k > 1 else embs[i, 0, :].copy(), {})
+        # ONE copy of the batch out of the pinned buffer; a frame's embedding is a view of it (pickled, a view stores just its
+        # own bytes).  The (frame, emb, {}) tuples of the reference's format (apply_vpd_model.py:166-169) come out of one zip
+        # and travel per run of equal video ids, not frame by frame: per-frame copy / tuple / add() calls were 0.35 ms of host
+        # time per 500-frame batch.
+        block = hbuf.numpy().reshape((n_batch, k, -1)).copy()
+        items = list(zip(frame_nums, block if k > 1 else block[:, 0, :], [{} for _ in range(n_batch)]))
+        vid = np.asarray(video_ids)
+        cuts = [0] + (np.flatnonzero(vid[1:] != vid[:-1]) + 1).tolist() + [n_batch] if n_batch else [0]
+        for a, b in zip(cuts[:-1], cuts[1:]):
             if writer is not None:
-                writer.add(video_ids[i], item)
+                writer.add_many(video_ids[a], items[a:b])
             else:
-                all_embs[video_ids[i]].append(item)
+                all_embs[video_ids[a]].extend(items[a:b])
         if progress_cb is not None:
             progress_cb(n_batch)
 
-    # The loop creates three container objects per frame (tuple, array, dict) that cannot form cycles; left on, the cyclic
-    # collector's full passes over a torch-sized heap take 75-90 ms each (measured: one such pass inside a 12-batch run
-    # turns 270 k crops/s into 95 k) while the GPU idles.  Reference counting frees everything here.
-    import gc
-    gc_was_on = gc.isenabled()
-    gc.disable()
+    # The loop creates three container objects per frame (tuple, view, dict) that cannot form cycles, while a FULL pass of the
+    # cyclic collector over a torch-sized heap takes 75-90 ms (measured: one such pass inside a 12-batch run turns 270 k
+    # crops/s into 95 k) with the GPU idle behind it.  gc.freeze() parks everything allocated so far in the permanent
+    # generation: the collector stays ON for the whole job (hours for a large data set: cycles made by the loader, its
+    # workers or the writer are still collected), its passes only walk what the job itself has allocated since.
+    gc.freeze()
     try:
         return _embed_loop(encoder, eng, loader, graphs, host, drain, writer, all_embs, augmenter, flip, use_graph)
     finally:
-        if gc_was_on:
-            gc.enable()
+        gc.unfreeze()
 
 
 def _embed_loop(encoder, eng, loader, graphs, host, drain, writer, all_embs, augmenter, flip, use_graph):

@@ -151,7 +151,7 @@ struct ConvParams {
     // ... and of a SECOND BatchNorm fed with the same g (the 1x1 branch of a down-sampling block: same gradient, same ReLU
     // mask): sum g * z2 (and sum g again) into `stats2`.  conv3x3_ws_kernel, accumulate mode only (epilogue mode 8).
     const bf16_t* bst_z2; double* stats2;
-    unsigned* err;                              // sticky time-out counter of the flag-synchronised kernels (conv_pws.h) or null
+    unsigned* err;                              // -DPWS_STAMPS builds: 16 x u64 s_memtime stamps per block (conv_pws.h); else unused
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
     ConvBnBwd bnb;                              // conv3x3_ws_kernel only

@@ -1745,6 +1745,10 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         if (kc < 2 || kc > 3) return hipErrorInvalidValue;        // the caller asks vpd_conv_bnbwd_ok first
     }
     if (p0.bst_z && !vpd_conv_takes_bn_sums(p0)) return hipErrorInvalidValue;      // (the caller asks first)
+    // epilogue modes 6 / 7 / 8 are selected by bst_z alone, and their statistics flush (with its workgroup barriers, which the
+    // loader waves of the warp-specialised kernels match one for one) runs only with rows to add to
+    if (p0.bst_z && (!p0.stats || !p0.bst_mask)) return hipErrorInvalidValue;
+    if (p0.bst_z2 && !p0.stats2) return hipErrorInvalidValue;
     ConvParams p = p0;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     p.ablate = ablate;

@@ -1,4 +1,5 @@
-// Persistent warp-specialised 3x3 stride-1 convolution with point-to-point LDS flags (round 3).
+// Persistent warp-specialised 3x3 stride-1 convolution, barrier-synchronised (round 3; the point-to-point LDS flag ring it was
+// first built with lost to the barrier it replaced, see below -- ConvParams::err is only used by -DPWS_STAMPS builds).
 //
 // conv3x3_ws_kernel (conv_igemm.hip) is one tile per block with one workgroup barrier per 64-deep K-step: its four MFMA
 // waves meet the four loader waves ~36-72 times per tile, all four MFMA waves then hit the LDS together, nothing of the

@@ -1653,6 +1653,7 @@ extern "C" int vpd_plan_stage_crops(vpd_plan_t* p, const unsigned char* rgb_u8, 
                                     const unsigned char* mask_u8, const float* noise, const vpd_aug_params* params,
                                     int n, int height, int width, const float* mean_std6, float noise_sd,
                                     float* scratch, void* workspace, void* stream) {
+    if (n > 65535) return fail("more than 65535 crops per staging call");      // (aug_apply_kernel: one grid row per crop)
     if (check_call(p, workspace, n)) return -1;
     if (!rgb_u8 || !params || !mean_std6 || !scratch) return fail("null argument");
     if (p->H != p->W) return fail("the input pipeline resizes to a square img_dim");
@@ -1668,6 +1669,8 @@ extern "C" int vpd_plan_stage_views(vpd_plan_t* p, const unsigned char* rgb_u8, 
                                     int k_views, int height, int width, const float* mean_std6, void* workspace,
                                     void* stream) {
     if (n_frames < 0 || (k_views != 1 && k_views != 2)) return fail("k_views must be 1 (frame) or 2 (frame, h-flip)");
+    // (aug_views_kernel: one grid row per view; a launch fails opaquely beyond gridDim.y = 65535)
+    if ((long)n_frames * k_views > 65535) return fail("n_frames * k_views exceeds 65535 views per staging call");
     if (check_call(p, workspace, n_frames * k_views)) return -1;
     if (!rgb_u8 || !mean_std6) return fail("null argument");
     if (height != p->H || width != p->W) return fail("inference views are not resized: the frames must have the plan's size");

@@ -77,9 +77,18 @@ class GradBucketReducer:
         self._ensure_events(nbuckets)
         return [e.cuda_event for e in self.events[:nbuckets]]
 
-    def reduce(self, plan, lazy=False):
-        """lazy: the backward left the conv weight gradients in the plan's scratch (engine.backward(events, lazy=True)): the
-        bucket messages are the scratch ranges, the rest of the flat buffer travels as one small message behind the last."""
+    def reduce(self, plan, lazy=None):
+        """Which buffers travel is the PLAN's state, not the caller's choice: after a lazy backward (engine.backward(events,
+        lazy=True)) the conv weight gradients are in the plan's scratch (vpd_plan_grads_pending() == 1) and the bucket
+        messages are the scratch ranges, the rest of the flat buffer travelling as one small message behind the last;
+        otherwise the flat buffer's bucket ranges.  `lazy`, if given, must agree with the plan (a flat-buffer all-reduce
+        after a lazy backward would sum stale conv ranges and leave the scratch the optimizer reads unreduced)."""
+        from ._lib import lib
+        pending = bool(lib().vpd_plan_grads_pending(plan.handle))
+        if lazy is not None and bool(lazy) != pending:
+            raise RuntimeError("GradBucketReducer.reduce(lazy=%s) but the plan's last backward was %s" %
+                               (lazy, "lazy (gradients pending in the scratch)" if pending else "eager (flat buffer complete)"))
+        lazy = pending
         cur = torch.cuda.current_stream(self.engine.device)
         flat = self.engine._grads
         self.overlap = os.environ.get("VPD_DDP_OVERLAP", "1") != "0"

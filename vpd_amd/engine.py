@@ -92,6 +92,11 @@ class _Plan:
                 self.scratch_views.append(self.workspace[o.value:o.value + 4 * m.value].view(torch.float32))
             small = [(off_, n_) for i, (kind_, _, off_, n_, _) in enumerate(rows) if kind_ != 0 or i == 0]
             self.small_ranges = small
+            # the C side is the source of truth: together the scratch views (every conv but the stem) and the small ranges
+            # must cover the flat parameter buffer exactly once
+            conv_numel = sum(n_ for i, (kind_, _, _, n_, _) in enumerate(rows) if kind_ == 0 and i != 0)
+            assert sum(v.numel() for v in self.scratch_views) == conv_numel, "bucket scratch ranges != conv weight tensors"
+            assert conv_numel + sum(n_ for _, n_ in small) == self.param_numel, "small ranges + conv tensors != param_numel"
             self.small_idx = torch.cat([torch.arange(a, a + n_, dtype=torch.int64) for a, n_ in small]).to(eng.device)
 
     def bn_table(self):
@@ -107,6 +112,8 @@ class _Plan:
         if self.handle:
             lib().vpd_plan_destroy(self.handle)
             self.handle = None
+        # whoever still holds this _Plan (apply's graph table, a reducer's last plan) must not pin its workspace
+        self.workspace, self.scratch_views, self.small_idx = None, [], None
 
     def __del__(self):
         try:

@@ -11,6 +11,22 @@ from ..engine import StudentEngine
 from .module import ENCODER_ARCH, attach_views
 
 
+def find_imagenet_weights(model_arch):
+    """The checkpoint torchvision would download for `model_arch`: $VPD_PRETRAINED_WEIGHTS (a file, or a directory holding
+    <arch>*.pth), else torch hub's cache (~/.cache/torch/hub/checkpoints/<arch>-<hash>.pth).  There is no download here."""
+    import glob
+    import os
+    cand = []
+    env = os.environ.get("VPD_PRETRAINED_WEIGHTS")
+    if env:
+        cand += [env] if os.path.isfile(env) else sorted(glob.glob(os.path.join(env, model_arch + "*.pth")))
+    cand += sorted(glob.glob(os.path.join(torch.hub.get_dir(), "checkpoints", model_arch + "-*.pth")))
+    if not cand:
+        raise FileNotFoundError("--pretrained: no ImageNet state_dict for %s; set VPD_PRETRAINED_WEIGHTS to the torchvision "
+                                "checkpoint (or to a directory holding %s*.pth)" % (model_arch, model_arch))
+    return cand[0]
+
+
 class RGBF_EmbeddingModel(nn.Module):
     """Basic embedding model with single frame features (HIP / MI355X)."""
 
@@ -24,8 +40,9 @@ class RGBF_EmbeddingModel(nn.Module):
             raise NotImplementedError("EfficientNet students are out of scope (SURVEY.md 2.1 #3)")
         if model_arch not in ENCODER_ARCH:
             raise KeyError(model_arch)
-        if pretrained:
-            raise NotImplementedError("ImageNet weights need network access; load a state_dict instead")
+        # pretrained: the reference asks torchvision for ImageNet weights (models/rgb.py:57-58, a download); here the SAME
+        # checkpoint file is read from disk -- VPD_PRETRAINED_WEIGHTS, else torchvision's hub cache -- see load_imagenet_backbone
+        weights = find_imagenet_weights(model_arch) if pretrained else None
         self.device = device
         self.use_flow = use_flow
         self.emb_dim = emb_dim
@@ -49,6 +66,34 @@ class RGBF_EmbeddingModel(nn.Module):
             mod.register_buffer("running_var", rv)
             mod.register_buffer("num_batches_tracked", eng.num_batches_tracked[i])
         self.reset_parameters()
+        if weights is not None:
+            self.load_imagenet_backbone(torch.load(weights, map_location="cpu"))
+
+    def load_imagenet_backbone(self, sd):
+        """What `pretrained=True` does in the reference (models/rgb.py:57-61), from a torchvision-format state_dict
+        (`conv1.weight`, `layer1.0.bn1.running_mean`, ..., `fc.weight [1000, F]`): every backbone tensor is taken as it
+        is, the 3-channel stem becomes its channel mean expanded to the input channels when they are not 3
+        (add_flow_to_model, :19-23), and the 1000-way fc is dropped -- the embedding layer keeps its fresh nn.Linear
+        initialisation (replace_last_layer, :40-43)."""
+        own = super().state_dict()
+        new = {}
+        for k, v in sd.items():
+            if k.startswith("fc."):
+                continue
+            key = "resnet." + k
+            if key not in own:
+                raise KeyError("unexpected tensor in the ImageNet state_dict: " + k)
+            if k == "conv1.weight" and self.in_channels != v.shape[1]:
+                v = v.mean(dim=1, keepdim=True).expand(-1, self.in_channels, -1, -1).contiguous()
+            if tuple(v.shape) != tuple(own[key].shape):
+                raise ValueError("shape of %s: %s, expected %s" % (k, tuple(v.shape), tuple(own[key].shape)))
+            new[key] = v
+        missing = [k for k in own if k not in new and not k.startswith("resnet.fc.")]
+        if missing:
+            raise KeyError("the ImageNet state_dict lacks " + ", ".join(missing[:4]))
+        new["resnet.fc.weight"], new["resnet.fc.bias"] = own["resnet.fc.weight"], own["resnet.fc.bias"]
+        self.load_state_dict(new)
+        self.engine.mark_weights_changed()
 
     @property
     def engine(self):
