@@ -46,19 +46,75 @@ static __device__ __forceinline__ void pix_split(const PixSplit& s, int mc, int&
     }
 }
 
+// ---- 16-byte epilogue accesses (round 4; cdna_hip_programming.md T21 for the 16x16 fragment) ----
+// A lane (fr, fq) of the swapped-operand 16x16 MFMA holds, for channel group a, the four channels 16a + 4fq .. + 3 of pixel fr:
+// 8 bytes, so a 64-channel wave tile used to leave (and read z / old y / the residual) as 16 eight-byte instructions per
+// lane, each touching 32 bytes of 16 different pixels -- store-ISSUE-bound (in-step stamps: 3,600 ticks of epilogue for the
+// plain forward store, 8,300 with the BatchNorm-sum loads).  v_permlane16_swap_b32 exchanges the odd lane rows of one register
+// with the even rows of another: applied to the packed registers X (group a) and Y (group a + 1) it leaves lane row fq with
+// 8 CONSECUTIVE channels of group a + (fq & 1), starting at channel (fq >> 1) * 8, in (X, Y) -- one 16-byte access per lane and
+// PAIR of groups, 64 contiguous bytes per pixel and instruction.  The exchange is an involution: data loaded 16 bytes wide in
+// that layout is brought back to the MFMA layout by the same two swaps.
+static __device__ __forceinline__ void frag_pair_swap(uint2& X, uint2& Y) {
+    auto r0 = __builtin_amdgcn_permlane16_swap(X.x, Y.x, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(X.y, Y.y, false, false);
+    X.x = r0[0]; Y.x = r0[1];
+    X.y = r1[0]; Y.y = r1[1];
+}
+// element offset, inside the wave's channel range, of this lane's 16 bytes of the pair (a, a + 1), a even
+static __device__ __forceinline__ int frag_pair_chan(int a, int fq) { return (a + (fq & 1)) * 16 + (fq >> 1) * 8; }
+// One pixel's fragments of a bf16 tensor for NI channel groups, as loaded: pairs 16 bytes wide in the exchanged layout, a
+// trailing odd group 8 bytes wide in the MFMA layout.  `base` = the pixel's first channel of this wave's channel range.
+template <int NI>
+struct FragRow {
+    uint4 q[(NI + 1) / 2];
+};
+template <int NI>
+static __device__ __forceinline__ void frag_row_load(FragRow<NI>& f, const bf16_t* base, int fq) {
+#pragma unroll
+    for (int a = 0; a + 1 < NI; a += 2) f.q[a / 2] = *reinterpret_cast<const uint4*>(base + frag_pair_chan(a, fq));
+    if constexpr ((NI & 1) != 0) {
+        const uint2 t = *reinterpret_cast<const uint2*>(base + (NI - 1) * 16 + 4 * fq);
+        f.q[NI / 2] = uint4{t.x, t.y, 0u, 0u};
+    }
+}
+// ... back to the MFMA layout: v[a] = channels 16a + 4fq .. + 3 (call once the loads have landed)
+template <int NI>
+static __device__ __forceinline__ void frag_row_unpack(const FragRow<NI>& f, uint2 (&v)[NI]) {
+#pragma unroll
+    for (int a = 0; a + 1 < NI; a += 2) {
+        v[a] = uint2{f.q[a / 2].x, f.q[a / 2].y};
+        v[a + 1] = uint2{f.q[a / 2].z, f.q[a / 2].w};
+        frag_pair_swap(v[a], v[a + 1]);
+    }
+    if constexpr ((NI & 1) != 0) v[NI - 1] = uint2{f.q[NI / 2].x, f.q[NI / 2].y};
+}
+// ... and the store of NI packed groups (MFMA layout in, clobbered)
+template <int NI>
+static __device__ __forceinline__ void frag_row_store(bf16_t* base, uint2 (&v)[NI], int fq, bool valid) {
+#pragma unroll
+    for (int a = 0; a + 1 < NI; a += 2) {
+        frag_pair_swap(v[a], v[a + 1]);
+        if (valid) *reinterpret_cast<uint4*>(base + frag_pair_chan(a, fq)) = uint4{v[a].x, v[a].y, v[a + 1].x, v[a + 1].y};
+    }
+    if constexpr ((NI & 1) != 0) {
+        if (valid) *reinterpret_cast<uint2*>(base + (NI - 1) * 16 + 4 * fq) = v[NI - 1];
+    }
+}
+
 // EPM 6 / 7: this lane's z fragments and ReLU bits of the consuming BatchNorm (ConvParams::bst_z / bst_mask), fetched ahead
 // of their use -- all loads of a tile in flight together (inside the epilogue the stores to y keep hipcc from hoisting
 // them), and in the persistent kernel before the tile's MFMA loop, which hides their latency altogether.
 template <int NI, int MI>
 struct BstFrag {
-    uint2 z[NI][MI];
+    FragRow<NI> z[MI];
     unsigned long long bits[MI];
 };
 // Accumulate modes (EPM 2 / 7) of the persistent kernel: the old values of y and their ReLU bits (ConvParams::acc_mask),
 // requested before the tile's MFMA loop like the fragments above (y dense, ypad 0).
 template <int NI, int MI>
 struct AccFrag {
-    uint2 old[NI][MI];
+    FragRow<NI> old[MI];
     unsigned long long bits[MI];
 };
 template <int BM, int BN, int WM, int WN>
@@ -80,16 +136,14 @@ static __device__ __forceinline__ void conv_acc_prefetch(const ConvParams& p, in
             else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
             else f.bits[b] = *reinterpret_cast<const unsigned short*>(mp);
         }
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            f.old[a][b] = *reinterpret_cast<const uint2*>(p.y + (size_t)mc * p.yC + n0 + wn * WTN + a * 16 + 4 * fq);
+        frag_row_load<NI>(f.old[b], p.y + (size_t)mc * p.yC + n0 + wn * WTN, fq);
     }
 }
 // Eval epilogue (EPM 3) with a residual: the residual fragments of the tile, requested ahead of the epilogue (the persistent
 // kernels: before or during the tile's MFMA loop) -- inside the epilogue they are one exposed round trip per tile.
 template <int NI, int MI>
 struct ResFrag {
-    uint2 r[NI][MI];
+    FragRow<NI> r[MI];
 };
 template <int BM, int BN, int WM, int WN>
 static __device__ __forceinline__ void conv_res_prefetch(const ConvParams& p, int mtile, int n0, const ConvGeo& geo,
@@ -107,9 +161,7 @@ static __device__ __forceinline__ void conv_res_prefetch(const ConvParams& p, in
         int bi, yy, xx;
         pix_split(ps, mc, bi, yy, xx);
         const size_t roff = ((size_t)(bi * p.rHp + yy + p.rpad) * p.rWp + (xx + p.rpad)) * p.rC;
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            f.r[a][b] = *reinterpret_cast<const uint2*>(p.res + roff + n0 + wn * WTN + a * 16 + 4 * fq);
+        frag_row_load<NI>(f.r[b], p.res + roff + n0 + wn * WTN, fq);
     }
 }
 // (at most 4 pixel groups at a time: 8 of them are 64 registers on top of 128 accumulators)
@@ -140,16 +192,14 @@ static __device__ __forceinline__ void conv_bst_prefetch(const ConvParams& p, in
         if (WTN == 64) f.bits[b] = *reinterpret_cast<const unsigned long long*>(mp);
         else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
         else f.bits[b] = *reinterpret_cast<const unsigned short*>(mp);
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            f.z[a][b] = *reinterpret_cast<const uint2*>(p.bst_z + yoff + n0 + wn * WTN + a * 16 + 4 * fq);
+        frag_row_load<NI>(f.z[b], p.bst_z + yoff + n0 + wn * WTN, fq);
     }
 }
 
 // Mode 8: the second BatchNorm's z fragments and its per-lane sum g * z2
 template <int NI, int MI>
 struct BstPair {
-    uint2 z2[NI][MI];
+    FragRow<NI> z2[MI];
     float s3[NI][4];
 };
 template <int BM, int BN, int WM, int WN>
@@ -172,9 +222,7 @@ static __device__ __forceinline__ void conv_bst2_prefetch(const ConvParams& p, i
             pix_split(ps, mc, bi, yy, xx);
             yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph) * p.yWp + (xx * p.osub + geo.opw)) * p.yC;
         }
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            f.z2[a][b] = *reinterpret_cast<const uint2*>(p.bst_z2 + yoff + n0 + wn * WTN + a * 16 + 4 * fq);
+        frag_row_load<NI>(f.z2[b], p.bst_z2 + yoff + n0 + wn * WTN, fq);
     }
 }
 
@@ -219,6 +267,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
             esh[a] = *reinterpret_cast<const float4*>(p.ep_shift + n0 + wn * WTN + a * 16 + 4 * fq);
         }
     }
+    const int nw = n0 + wn * WTN;                 // first channel of this wave's range
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         // (PRE: the caller fetched the first MB groups; the second half of an 8-group tile is fetched here)
@@ -240,16 +289,31 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
         unsigned long long mbits = 0;
         if (APRE) mbits = accf->bits[b];
         if (!APRE && do_acc && p.acc_mask && valid) {
-            const unsigned char* mp = p.acc_mask + (size_t)mc * (p.yC >> 3) + ((n0 + wn * WTN) >> 3);
+            const unsigned char* mp = p.acc_mask + (size_t)mc * (p.yC >> 3) + (nw >> 3);
             if (WTN == 64) mbits = *reinterpret_cast<const unsigned long long*>(mp);
             else if (WTN == 32) mbits = *reinterpret_cast<const unsigned*>(mp);
             else mbits = *reinterpret_cast<const unsigned short*>(mp);
         }
         const BstFrag<NI, MB>& bf = own;
         const unsigned long long bbits = do_bst ? bf.bits[b % MB] : 0ull;      // ReLU bits of the consuming BatchNorm's activation
+        bf16_t* const dpix = p.y + yoff + nw;
+        // this pixel's fragments of the other tensors, 16 bytes wide, then back in the MFMA layout
+        uint2 resv[NI], oldv[NI], zv[NI], z2v[NI];
+        if (do_eval && p.res) {
+            FragRow<NI> t;
+            if (!resf) frag_row_load<NI>(t, p.res + roff + nw, fq);
+            frag_row_unpack<NI>(resf ? resf->r[b] : t, resv);
+        }
+        if (do_acc) {
+            FragRow<NI> t;
+            if (!APRE) frag_row_load<NI>(t, dpix, fq);      // (rows beyond M re-read row M - 1: in bounds, never stored)
+            frag_row_unpack<NI>(APRE ? accf->old[b] : t, oldv);
+        }
+        if (do_bst) frag_row_unpack<NI>(bf.z[b % MB], zv);
+        if (do_pair) frag_row_unpack<NI>(pr.z2[b % MB], z2v);
+        uint2 ovs[NI];
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
             float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
             if (do_eval) {
                 const float4 sc = esc[a];
@@ -257,7 +321,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
                 v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
                 if (p.res) {
-                    const uint2 rv = resf ? resf->r[a][b] : *reinterpret_cast<const uint2*>(p.res + roff + n);
+                    const uint2 rv = resv[a];
                     v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
                     v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
                 }
@@ -266,9 +330,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                     for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
                 }
             }
-            bf16_t* dst = p.y + yoff + n;
-            if (do_acc && valid) {
-                const uint2 ov = APRE ? accf->old[a][b] : *reinterpret_cast<const uint2*>(dst);
+            if (do_acc) {
+                const uint2 ov = oldv[a];
                 float o0 = bf2f((unsigned short)(ov.x & 0xffff)), o1 = bf2f((unsigned short)(ov.x >> 16));
                 float o2 = bf2f((unsigned short)(ov.y & 0xffff)), o3 = bf2f((unsigned short)(ov.y >> 16));
                 if (APRE || p.acc_mask) {      // y dense [M][yC]: channel n0 + wn*WTN + k of pixel m = bit k of mbits (APRE: all ones without a mask)
@@ -281,12 +344,10 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
             uint2 ov;
             ov.x = pack2bf(v[0], v[1]);
             ov.y = pack2bf(v[2], v[3]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(dst) = ov;
-            }
+            ovs[a] = ov;
             if (do_bst && valid) {
                 // g = stored d * mask; sum g and sum g * z (the BatchNorm backward's finalize turns the latter into sum g * xhat)
-                const uint2 zr = bf.z[a][b % MB];
+                const uint2 zr = zv[a];
                 const unsigned bits = (unsigned)(bbits >> (a * 16 + 4 * fq));
                 const float q0 = (bits & 1u) ? bf2f((unsigned short)(ov.x & 0xffff)) : 0.f;
                 const float q1 = (bits & 2u) ? bf2f((unsigned short)(ov.x >> 16)) : 0.f;
@@ -297,7 +358,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 s1[a][2] += q2; s2[a][2] += q2 * bf2f((unsigned short)(zr.y & 0xffff));
                 s1[a][3] += q3; s2[a][3] += q3 * bf2f((unsigned short)(zr.y >> 16));
                 if (do_pair) {
-                    const uint2 z2 = pr.z2[a][b % MB];
+                    const uint2 z2 = z2v[a];
                     pr.s3[a][0] += q0 * bf2f((unsigned short)(z2.x & 0xffff));
                     pr.s3[a][1] += q1 * bf2f((unsigned short)(z2.x >> 16));
                     pr.s3[a][2] += q2 * bf2f((unsigned short)(z2.y & 0xffff));
@@ -314,6 +375,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 s1[a][3] += q3; s2[a][3] += q3 * q3;
             }
         }
+        frag_row_store<NI>(dpix, ovs, fq, valid);
     }
 
 }
