@@ -125,18 +125,26 @@ static __device__ __forceinline__ void conv_acc_prefetch(const ConvParams& p, in
     const int wave = threadIdx.x >> 6;
     const int wm = wave % WM, wn = wave / WM;
     const int fr = lane & 15, fq = lane >> 4;
+    const PixSplit ps = pix_split_init(p, geo);
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = mtile * BM + wm * WTM + b * 16 + fr;
         const int mc = m < geo.M ? m : geo.M - 1;
         f.bits[b] = ~0ull;
-        if (p.acc_mask) {
+        if (p.acc_mask) {      // (a mask implies a dense y)
             const unsigned char* mp = p.acc_mask + (size_t)mc * (p.yC >> 3) + ((n0 + wn * WTN) >> 3);
             if (WTN == 64) f.bits[b] = *reinterpret_cast<const unsigned long long*>(mp);
             else if (WTN == 32) f.bits[b] = *reinterpret_cast<const unsigned*>(mp);
             else f.bits[b] = *reinterpret_cast<const unsigned short*>(mp);
         }
-        frag_row_load<NI>(f.old[b], p.y + (size_t)mc * p.yC + n0 + wn * WTN, fq);
+        size_t yoff;
+        if (ps.dense) yoff = (size_t)mc * p.yC;
+        else {
+            int bi, yy, xx;
+            pix_split(ps, mc, bi, yy, xx);
+            yoff = ((size_t)(bi * p.yHp + yy * p.osub + geo.oph + p.ypad) * p.yWp + (xx * p.osub + geo.opw + p.ypad)) * p.yC;
+        }
+        frag_row_load<NI>(f.old[b], p.y + yoff + n0 + wn * WTN, fq);
     }
 }
 // Eval epilogue (EPM 3) with a residual: the residual fragments of the tile, requested ahead of the epilogue (the persistent
@@ -297,85 +305,99 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
         const BstFrag<NI, MB>& bf = own;
         const unsigned long long bbits = do_bst ? bf.bits[b % MB] : 0ull;      // ReLU bits of the consuming BatchNorm's activation
         bf16_t* const dpix = p.y + yoff + nw;
-        // this pixel's fragments of the other tensors, 16 bytes wide, then back in the MFMA layout
-        uint2 resv[NI], oldv[NI], zv[NI], z2v[NI];
-        if (do_eval && p.res) {
-            FragRow<NI> t;
-            if (!resf) frag_row_load<NI>(t, p.res + roff + nw, fq);
-            frag_row_unpack<NI>(resf ? resf->r[b] : t, resv);
-        }
-        if (do_acc) {
-            FragRow<NI> t;
-            if (!APRE) frag_row_load<NI>(t, dpix, fq);      // (rows beyond M re-read row M - 1: in bounds, never stored)
-            frag_row_unpack<NI>(APRE ? accf->old[b] : t, oldv);
-        }
-        if (do_bst) frag_row_unpack<NI>(bf.z[b % MB], zv);
-        if (do_pair) frag_row_unpack<NI>(pr.z2[b % MB], z2v);
-        uint2 ovs[NI];
+        // this pixel's fragments of the other tensors: 16 bytes wide as loaded, brought back to the MFMA layout pair by pair
+        // (one pair's worth of temporaries live at a time: the eight-wave tile has 168 registers)
+        FragRow<NI> rest, oldt;
+        if (do_eval && p.res && !resf) frag_row_load<NI>(rest, p.res + roff + nw, fq);
+        if (do_acc && !APRE) frag_row_load<NI>(oldt, dpix, fq);      // (rows beyond M re-read row M - 1: in bounds, never stored)
+        const FragRow<NI>& resr = (do_eval && p.res && resf) ? resf->r[b] : rest;
+        const FragRow<NI>& oldr = APRE ? accf->old[b] : oldt;
 #pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            if (do_eval) {
-                const float4 sc = esc[a];
-                const float4 sh = esh[a];
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-                if (p.res) {
-                    const uint2 rv = resv[a];
-                    v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
-                    v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
-                }
-                if (p.ep_relu) {
+        for (int a0 = 0; a0 < NI; a0 += 2) {
+            const bool pair = a0 + 1 < NI;
+            uint2 resv[2], oldv[2], zv[2], z2v[2], ovs[2];
+            auto unpack2 = [&](const FragRow<NI>& f, uint2 (&v)[2]) __attribute__((always_inline)) {
+                v[0] = uint2{f.q[a0 / 2].x, f.q[a0 / 2].y};
+                v[1] = uint2{f.q[a0 / 2].z, f.q[a0 / 2].w};
+                if (pair) frag_pair_swap(v[0], v[1]);
+            };
+            if (do_eval && p.res) unpack2(resr, resv);
+            if (do_acc) unpack2(oldr, oldv);
+            if (do_bst) unpack2(bf.z[b % MB], zv);
+            if (do_pair) unpack2(pr.z2[b % MB], z2v);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            for (int ai = 0; ai < 2; ++ai) {
+                const int a = a0 + ai;
+                if (a >= NI) break;
+                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                if (do_eval) {
+                    const float4 sc = esc[a];
+                    const float4 sh = esh[a];
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                    v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                    if (p.res) {
+                        const uint2 rv = resv[ai];
+                        v[0] += bf2f((unsigned short)(rv.x & 0xffff)); v[1] += bf2f((unsigned short)(rv.x >> 16));
+                        v[2] += bf2f((unsigned short)(rv.y & 0xffff)); v[3] += bf2f((unsigned short)(rv.y >> 16));
+                    }
+                    if (p.ep_relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+                    }
+                }
+                if (do_acc) {
+                    const uint2 ov = oldv[ai];
+                    float o0 = bf2f((unsigned short)(ov.x & 0xffff)), o1 = bf2f((unsigned short)(ov.x >> 16));
+                    float o2 = bf2f((unsigned short)(ov.y & 0xffff)), o3 = bf2f((unsigned short)(ov.y >> 16));
+                    if (APRE || p.acc_mask) {      // y dense [M][yC]: channel n0 + wn*WTN + k of pixel m = bit k of mbits (APRE: all ones without a mask)
+                        const unsigned bits = (unsigned)(mbits >> (a * 16 + 4 * fq));
+                        o0 = (bits & 1u) ? o0 : 0.f; o1 = (bits & 2u) ? o1 : 0.f;
+                        o2 = (bits & 4u) ? o2 : 0.f; o3 = (bits & 8u) ? o3 : 0.f;
+                    }
+                    v[0] += o0; v[1] += o1; v[2] += o2; v[3] += o3;
+                }
+                uint2 ov;
+                ov.x = pack2bf(v[0], v[1]);
+                ov.y = pack2bf(v[2], v[3]);
+                ovs[ai] = ov;
+                if (do_bst && valid) {
+                    // g = stored d * mask; sum g and sum g * z (the BatchNorm backward's finalize turns the latter into sum g * xhat)
+                    const uint2 zr = zv[ai];
+                    const unsigned bits = (unsigned)(bbits >> (a * 16 + 4 * fq));
+                    const float q0 = (bits & 1u) ? bf2f((unsigned short)(ov.x & 0xffff)) : 0.f;
+                    const float q1 = (bits & 2u) ? bf2f((unsigned short)(ov.x >> 16)) : 0.f;
+                    const float q2 = (bits & 4u) ? bf2f((unsigned short)(ov.y & 0xffff)) : 0.f;
+                    const float q3 = (bits & 8u) ? bf2f((unsigned short)(ov.y >> 16)) : 0.f;
+                    s1[a][0] += q0; s2[a][0] += q0 * bf2f((unsigned short)(zr.x & 0xffff));
+                    s1[a][1] += q1; s2[a][1] += q1 * bf2f((unsigned short)(zr.x >> 16));
+                    s1[a][2] += q2; s2[a][2] += q2 * bf2f((unsigned short)(zr.y & 0xffff));
+                    s1[a][3] += q3; s2[a][3] += q3 * bf2f((unsigned short)(zr.y >> 16));
+                    if (do_pair) {
+                        const uint2 z2 = z2v[ai];
+                        pr.s3[a][0] += q0 * bf2f((unsigned short)(z2.x & 0xffff));
+                        pr.s3[a][1] += q1 * bf2f((unsigned short)(z2.x >> 16));
+                        pr.s3[a][2] += q2 * bf2f((unsigned short)(z2.y & 0xffff));
+                        pr.s3[a][3] += q3 * bf2f((unsigned short)(z2.y >> 16));
+                    }
+                }
+                if (do_stats && valid) {
+                    // statistics are taken over the bf16-rounded values actually stored
+                    const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
+                    const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
+                    s1[a][0] += q0; s2[a][0] += q0 * q0;
+                    s1[a][1] += q1; s2[a][1] += q1 * q1;
+                    s1[a][2] += q2; s2[a][2] += q2 * q2;
+                    s1[a][3] += q3; s2[a][3] += q3 * q3;
                 }
             }
-            if (do_acc) {
-                const uint2 ov = oldv[a];
-                float o0 = bf2f((unsigned short)(ov.x & 0xffff)), o1 = bf2f((unsigned short)(ov.x >> 16));
-                float o2 = bf2f((unsigned short)(ov.y & 0xffff)), o3 = bf2f((unsigned short)(ov.y >> 16));
-                if (APRE || p.acc_mask) {      // y dense [M][yC]: channel n0 + wn*WTN + k of pixel m = bit k of mbits (APRE: all ones without a mask)
-                    const unsigned bits = (unsigned)(mbits >> (a * 16 + 4 * fq));
-                    o0 = (bits & 1u) ? o0 : 0.f; o1 = (bits & 2u) ? o1 : 0.f;
-                    o2 = (bits & 4u) ? o2 : 0.f; o3 = (bits & 8u) ? o3 : 0.f;
-                }
-                v[0] += o0; v[1] += o1; v[2] += o2; v[3] += o3;
-            }
-            uint2 ov;
-            ov.x = pack2bf(v[0], v[1]);
-            ov.y = pack2bf(v[2], v[3]);
-            ovs[a] = ov;
-            if (do_bst && valid) {
-                // g = stored d * mask; sum g and sum g * z (the BatchNorm backward's finalize turns the latter into sum g * xhat)
-                const uint2 zr = zv[a];
-                const unsigned bits = (unsigned)(bbits >> (a * 16 + 4 * fq));
-                const float q0 = (bits & 1u) ? bf2f((unsigned short)(ov.x & 0xffff)) : 0.f;
-                const float q1 = (bits & 2u) ? bf2f((unsigned short)(ov.x >> 16)) : 0.f;
-                const float q2 = (bits & 4u) ? bf2f((unsigned short)(ov.y & 0xffff)) : 0.f;
-                const float q3 = (bits & 8u) ? bf2f((unsigned short)(ov.y >> 16)) : 0.f;
-                s1[a][0] += q0; s2[a][0] += q0 * bf2f((unsigned short)(zr.x & 0xffff));
-                s1[a][1] += q1; s2[a][1] += q1 * bf2f((unsigned short)(zr.x >> 16));
-                s1[a][2] += q2; s2[a][2] += q2 * bf2f((unsigned short)(zr.y & 0xffff));
-                s1[a][3] += q3; s2[a][3] += q3 * bf2f((unsigned short)(zr.y >> 16));
-                if (do_pair) {
-                    const uint2 z2 = z2v[a];
-                    pr.s3[a][0] += q0 * bf2f((unsigned short)(z2.x & 0xffff));
-                    pr.s3[a][1] += q1 * bf2f((unsigned short)(z2.x >> 16));
-                    pr.s3[a][2] += q2 * bf2f((unsigned short)(z2.y & 0xffff));
-                    pr.s3[a][3] += q3 * bf2f((unsigned short)(z2.y >> 16));
-                }
-            }
-            if (do_stats && valid) {
-                // statistics are taken over the bf16-rounded values actually stored
-                const float q0 = bf2f((unsigned short)(ov.x & 0xffff)), q1 = bf2f((unsigned short)(ov.x >> 16));
-                const float q2 = bf2f((unsigned short)(ov.y & 0xffff)), q3 = bf2f((unsigned short)(ov.y >> 16));
-                s1[a][0] += q0; s2[a][0] += q0 * q0;
-                s1[a][1] += q1; s2[a][1] += q1 * q1;
-                s1[a][2] += q2; s2[a][2] += q2 * q2;
-                s1[a][3] += q3; s2[a][3] += q3 * q3;
+            // the pair leaves 16 bytes wide (64 contiguous bytes per pixel and instruction); a trailing odd group 8 bytes wide
+            if (pair) {
+                frag_pair_swap(ovs[0], ovs[1]);
+                if (valid) *reinterpret_cast<uint4*>(dpix + frag_pair_chan(a0, fq)) = uint4{ovs[0].x, ovs[0].y, ovs[1].x, ovs[1].y};
+            } else if (valid) {
+                *reinterpret_cast<uint2*>(dpix + a0 * 16 + 4 * fq) = ovs[0];
             }
         }
-        frag_row_store<NI>(dpix, ovs, fq, valid);
     }
 
 }
@@ -426,6 +448,16 @@ static __device__ __forceinline__ void conv_epilogue_acc_pre(const ConvParams& p
                                                              const AccFrag<BN / WN / 16, BM / WM / 16>& accf) {
     BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)> pr;
     conv_epilogue_impl<BM, BN, WM, WN, EPM, EPM == 7, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, &accf, pr);
+}
+// ... mode 8: the old values, both BatchNorms' fragments fetched by the caller
+template <int BM, int BN, int WM, int WN, int EPM>
+static __device__ __forceinline__ void conv_epilogue_acc_pre2(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
+                                                              int mtile, int n0, float (&s1)[BN / WN / 16][4],
+                                                              float (&s2)[BN / WN / 16][4], const ConvGeo& geo,
+                                                              BstFrag<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& bst,
+                                                              BstPair<BN / WN / 16, VPD_BST_MB(BM / WM / 16)>& pr,
+                                                              const AccFrag<BN / WN / 16, BM / WM / 16>& accf) {
+    conv_epilogue_impl<BM, BN, WM, WN, EPM, true, true>(p, acc, mtile, n0, s1, s2, geo, 0, bst, &accf, pr);
 }
 
 // Reduce the per-lane partial statistics over the 16 pixel lanes and the WM pixel-waves, then ONE atomic per

@@ -197,6 +197,7 @@ struct HaloGeom {
     int total_pix; // N * (H+2) * (W+2): clamp for the last (ragged) tile
     // conv3x3_pws_kernel only: swizzle key of halo pixel (row hr, column xp of the padded tile) = (xp & kmask) ^ ((hr & rowmask) << kshift)
     int kmask, kshift, rowmask;
+    float rH, rW, rWp;   // correctly rounded 1 / H, 1 / W, 1 / (W + 2) from the host (vpd_fdiv)
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -1281,6 +1282,7 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
     if (lanes >= 8) lanes &= ~7;
     sg.lanes = lanes;
     sg.xcd = lanes % 8 == 0;
+    sg.rNT = 1.0f / (float)sg.NT; sg.rlanes = 1.0f / (float)lanes;
     const dim3 grid(lanes * sg.NT), block((NMW + 4) * 64);
     ConvParams q = p;
 #ifdef PWS_STAMPS
@@ -1295,10 +1297,9 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, dstamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost);
         const char* names[16] = {"entry", "setup done", "first READY", "K loop done", "epilogue issued", "tiles done", "stats flushed",
-                                 "stores drained", "L entry", "L halo issued", "L first landed", "L done", "", "", "", ""};
+                                 "stores drained", "L entry", "L halo issued", "L first landed", "L done", "L origin known", "L weights issued", "all epilogues", ""};
         fprintf(stderr, "[pws stamps %s, %d blocks] cycles from the consumer's entry (median / max over blocks)\n", tag, nb);
-        for (int k = 1; k < 12; ++k) {
-            if (k == 8) continue;
+        for (int k = 1; k < 15; ++k) {
             std::vector<long long> d;
             for (int b = 0; b < nb; ++b) if (h[b * 16 + k] && h[b * 16]) d.push_back((long long)(h[b * 16 + k] - h[b * 16]));
             if (d.empty()) continue;
@@ -1621,6 +1622,7 @@ static bool halo_geom(const ConvParams& p, int BM, int hrows_max, HaloGeom* g) {
     // opposite halves of the eight 16-byte pieces of a bank row); W = 4: two column bits + the row parity
     if (W >= 8) { g->kmask = 7; g->kshift = 0; g->rowmask = 0; }
     else { g->kmask = 3; g->kshift = 2; g->rowmask = 1; }
+    g->rH = 1.0f / (float)H; g->rW = 1.0f / (float)W; g->rWp = 1.0f / (float)(W + 2);
     return g->NHP <= hrows_max;
 }
 

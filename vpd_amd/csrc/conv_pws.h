@@ -40,6 +40,9 @@ struct PwsGrid {
     int NT;         // channel tiles
     int MT;         // pixel tiles
     int xcd;        // 1: blocks b, b + 8, ... (one XCD under round-robin placement) take the channel tiles of ONE lane group
+    // IEEE reciprocals from the host (vpd_fdiv needs the correctly rounded 1 / d; in the kernel `1.0f / x` is a 12-instruction
+    // division sequence behind a kernel-argument round trip -- three of them stood in front of the first LDS-DMA)
+    float rNT, rlanes;
 };
 
 // -DPWS_STAMPS (diagnostic builds only; tools/probe): ConvParams::err points at 16 x u64 per block; MFMA wave 0 stamps
@@ -60,6 +63,25 @@ static __device__ __forceinline__ void pws_vmwait() {
 static __device__ __forceinline__ void pws_dma16(const void* gsrc, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
+// ... with the wave-uniform part of the source address in SGPRs and a 32-bit per-lane byte offset (the SADDR form): the loaders'
+// per-lane offsets are constants of the launch, so a transfer costs them no vector ALU instruction at all
+static __device__ __forceinline__ void pws_dma16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+// Kernel arguments live in memory the host has just written: the first scalar load of every 64-byte line of them is a miss that
+// goes all the way out (~1 us under load), and hipcc loads them group by group as the control flow needs them -- three dependent
+// round trips stood in front of the loaders' first transfer.  One dword of every line at once, one wait: the compiler's own
+// loads behind it hit the scalar cache.
+template <int NBYTES>
+static __device__ __forceinline__ void pws_kernarg_touch() {
+    const char __attribute__((address_space(4)))* ka =
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (int o = 0; o < NBYTES; o += 64) acc |= *reinterpret_cast<const volatile unsigned __attribute__((address_space(4)))*>(ka + o);
+    acc |= *reinterpret_cast<const volatile unsigned __attribute__((address_space(4)))*>(ka + ((NBYTES - 4) & ~3));
+    asm volatile("" ::"s"(acc));
+}
 // s_waitcnt lgkmcnt(0) as the BUILTIN (vmcnt / expcnt fields at their maxima): hipcc's wait-count pass sees it and does
 // not wait again for the fragments it covers
 static __device__ __forceinline__ void pws_lgkm0() {
@@ -76,6 +98,13 @@ static __device__ __forceinline__ void pws_lgkm0() {
 // Lane (fr, fq): pixel fr of group b; fq picks the tensor (every tensor's 64-channel slice of a pixel is one 128-byte line).
 #ifndef PWS_RES_EARLY
 #define PWS_RES_EARLY 1      // eval: residual fragments requested at the start of a tile's last chunk
+#endif
+#ifndef PWS_BST_EARLY4
+#define PWS_BST_EARLY4 0     // 64 x 64 wave tiles too: z fragments + mask bits of modes 6 / 7 requested one chunk ahead -- 40 registers
+                             // the K loop does not have: 35 (mode 6) / 31 (mode 7) spilled dwords with the round-4 epilogue
+#endif
+#ifndef PWS_ACC_PRE
+#define PWS_ACC_PRE 1        // accumulate modes: the old values of y of a whole tile requested before its epilogue
 #endif
 #ifndef PWS_TOUCH
 #define PWS_TOUCH 0      // measured: -1.2 % (256 crops), -1.5 % (512), -1.6 % (apply) same-box -- profiles/r03_epilogue_touch_negative.txt
@@ -165,10 +194,9 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
     constexpr unsigned OFF_RED = OFF_DUMP + (RESW ? 0u : 1024u);
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sH = reinterpret_cast<bf16_t*>(smem);                    // [2][HBUF]
-    bf16_t* sW = reinterpret_cast<bf16_t*>(smem + OFF_W);            // [NS][WSTAGE]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][HBUF] halos, [NS][WSTAGE] weight ring, dump, scratch
     unsigned char* red = smem + OFF_RED;
+    pws_kernarg_touch<sizeof(ConvParams) + sizeof(HaloGeom) + sizeof(PwsGrid)>();
 
     const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     const int tid = threadIdx.x;
@@ -184,12 +212,12 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     int lane0, nt;
     {
         const int b = blockIdx.x;
-        const float rNT = 1.0f / (float)sg.NT;
+        const float rNT = sg.rNT;
         if (sg.xcd) { const int k = b >> 3; const int q = vpd_fdiv(k, rNT); nt = k - q * sg.NT; lane0 = q * 8 + (b & 7); }
         else { lane0 = vpd_fdiv(b, rNT); nt = b - lane0 * sg.NT; }
     }
     const int n0 = nt * BN;
-    const int njobs = lane0 < sg.MT ? vpd_fdiv(sg.MT - lane0 + sg.lanes - 1, 1.0f / (float)sg.lanes) : 0;
+    const int njobs = lane0 < sg.MT ? vpd_fdiv(sg.MT - lane0 + sg.lanes - 1, sg.rlanes) : 0;
     if (njobs == 0) return;                                          // (whole block, before any barrier)
     const int total = njobs * nsteps;                                // K-steps of this block = READY barriers
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;            // LDS byte address of the dynamic segment
@@ -199,46 +227,57 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const int lw = wave - NMW;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
+        // A transfer's source = a wave-uniform base in SGPRs (tile / chunk / tap) + a per-lane byte offset that is a constant of
+        // the launch: hoff[k] for the k-th halo instruction of this wave (halo pixel hp = (lw + 4k) * 8 + lrow, row hr, column xp
+        // of the padded tile: hp * Ci elements + the 16-byte piece XOR-ed with key(hr, xp), HaloGeom), wrow[k] for its k-th weight
+        // row.  They are computed once, in the prologue, each right in front of its first use.
+        unsigned hoff[HPASS];
+        auto halo_off = [&](int k) __attribute__((always_inline)) {
+            const int hp = (lw + 4 * k) * 8 + lrow;
+            const int hr = vpd_fdiv(hp, g.rWp);
+            const int key = ((hp - hr * Wp) & g.kmask) ^ ((hr & g.rowmask) << g.kshift);
+            return (unsigned)(hp * Ci * 2 + ((piece ^ key) << 4));
+        };
         // first padded pixel of a tile's halo (gr0 = its first global output row b * H + y; < 2^21 for every shape the
-        // launcher admits, so the float-reciprocal division is exact)
-        const float rH = 1.0f / (float)H;
+        // launcher admits, so the float-reciprocal division is exact); wave-uniform, brought to an SGPR
         auto tile_gp0 = [&](int mtile) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
-            const int b = vpd_fdiv(gr0, rH);
+            const int b = vpd_fdiv(gr0, g.rH);
             const int prow0 = g.multi ? b * (H + 2) : b * (H + 2) + (gr0 - b * H);
-            return prow0 * Wp;
+            return __builtin_amdgcn_readfirstlane(prow0 * Wp);
         };
-        // halo pixel hp (row hr, column xp of the padded tile) keeps its 16-byte pieces XOR-ed with key(hr, xp): HaloGeom
-        const float rWp = 1.0f / (float)Wp;
         auto halo_instr = [&](int gp0, int cc, int buf, int k) __attribute__((always_inline)) {
             if (HINSTR % 4 != 0 && lw + 4 * k >= HINSTR) { pws_dma16(p.w, lds0 + OFF_DUMP); return; }      // filler: keeps the counts
-            const int hp = (lw + 4 * k) * 8 + lrow;
-            const int hr = vpd_fdiv(hp, rWp);
-            const int key = ((hp - hr * Wp) & g.kmask) ^ ((hr & g.rowmask) << g.kshift);
-            int gp = gp0 + hp;
-            gp = gp < g.total_pix ? gp : g.total_pix - 1;
-            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ key) << 3);
-            pws_dma16(src, lds0 + (unsigned)buf * (HBUF * 2u) + (unsigned)(lw + 4 * k) * 1024u);
+            const unsigned dst = lds0 + (unsigned)buf * (HBUF * 2u) + (unsigned)(lw + 4 * k) * 1024u;
+            if (gp0 + HINSTR * 8 <= g.total_pix) {               // (wave-uniform) the whole halo lies inside the tensor
+                pws_dma16s(reinterpret_cast<const char*>(p.x) + ((size_t)gp0 * Ci + cc * 64) * 2, hoff[k], dst);
+            } else {                                             // the tensor's last tile: rows beyond it re-read its last pixel
+                const int hp = (lw + 4 * k) * 8 + lrow;
+                const int gp = gp0 + hp < g.total_pix ? gp0 + hp : g.total_pix - 1;
+                const unsigned swz = (hoff[k] - (unsigned)(hp * Ci * 2)) >> 1;       // (piece ^ key) << 3, in elements
+                pws_dma16(p.x + (size_t)gp * Ci + cc * 64 + swz, dst);
+            }
         };
-        // per-lane element offset of this wave's W_PER weight rows inside a [Co][Ci] tap slice
-        int wrow[W_PER];
+        // per-lane byte offset of this wave's W_PER weight rows inside a [Co][Ci] tap slice
+        unsigned wrow[W_PER];
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
             const int n = (lw + 4 * i) * 8 + lrow;
-            wrow[i] = (n0 + n) * Ci + ((piece ^ (n & 7)) << 3);
+            wrow[i] = (unsigned)(((n0 + n) * Ci + ((piece ^ (n & 7)) << 3)) * 2);
         }
         auto issue_w = [&](int tap, int cc, unsigned stg) __attribute__((always_inline)) {
             const int wsl = p.taps.w0 + (tap / 3) * p.taps.wrs + (tap % 3) * p.taps.wcs;
-            const bf16_t* wbp = p.w + (size_t)wsl * p.Co * Ci + cc * 64;
+            const char* wbp = reinterpret_cast<const char*>(p.w) + ((size_t)wsl * p.Co * Ci + cc * 64) * 2;
 #pragma unroll
             for (int k = 0; k < W_PER; ++k)
-                pws_dma16(wbp + wrow[k], lds0 + OFF_W + stg * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
+                pws_dma16s(wbp, wrow[k], lds0 + OFF_W + stg * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
         };
         // prologue: the first tile's first halo, then the weights of steps 0 .. A (retired in this order)
         {
             const int gp0 = tile_gp0(lane0);
+            PWS_STAMP(12);                                           // first tile's origin known
 #pragma unroll
-            for (int k = 0; k < HPASS; ++k) halo_instr(gp0, 0, 0, k);
+            for (int k = 0; k < HPASS; ++k) { hoff[k] = halo_off(k); halo_instr(gp0, 0, 0, k); }
         }
         PWS_STAMP(9);                                                // first halo issued
         int w_tap = 0, w_cc = 0;                                     // tap / chunk-in-tile of the next weight bundle
@@ -251,6 +290,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
             if (++w_st == NS) w_st = 0;
         }
+        PWS_STAMP(13);                                               // first weight bundles issued
         const int total_chunks = njobs * nchunks;
         int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0; // the chunk whose halo is issued during this chunk
         for (int c = 0; c < total_chunks; ++c) {
@@ -311,7 +351,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     // arithmetic (5 VALU per fragment) plus the tap bookkeeping took ~85 instruction slots per 32-MFMA step.
     unsigned lo[3][MI];
     {
-        const float rW = 1.0f / (float)W, rH = 1.0f / (float)H;
+        const float rW = g.rW, rH = g.rH;
 #pragma unroll
         for (int b = 0; b < MI; ++b) {
             const int m = wm * WTM + b * 16 + fr;
@@ -339,7 +379,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     constexpr bool BST = EPM == 6 || EPM == 7 || EPM == 8;
-    constexpr bool BST_EARLY = PIPE && MI <= 2 && (EPM == 6 || EPM == 7);      // (64 x 64 wave tiles: 40 more registers spill)
+    constexpr bool BST_EARLY = PIPE && (EPM == 6 || EPM == 7) && (MI <= 2 || PWS_BST_EARLY4);
     BstPair<NI, VPD_BST_MB(MI)> pr;
     if (EPM == 8) {
 #pragma unroll
@@ -482,7 +522,15 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         if (VPD_ABL(p, 8)) continue;
         if (BST && !BST_EARLY) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
         if (EPM == 8) conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr);
-        if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
+        // accumulate modes: ALL old values of the tile requested up front (inside the epilogue the stores to y keep every
+        // pixel group's reload of y behind the previous group's stores: four exposed round trips per tile on 64 x 64 wave tiles)
+        constexpr bool ACC_PRE = PWS_ACC_PRE && NMW == 4 && (EPM == 2 || EPM == 7 || (EPM == 8 && MI <= 2));
+        AccFrag<NI, MI> accf;
+        if constexpr (ACC_PRE) conv_acc_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, accf);
+        if constexpr (ACC_PRE && EPM == 8) conv_epilogue_acc_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr, accf);
+        else if constexpr (ACC_PRE && EPM == 7) conv_epilogue_acc_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, accf);
+        else if constexpr (ACC_PRE && EPM == 2) conv_epilogue_acc_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, accf);
+        else if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
         else if (RES_EARLY && res_pre) conv_epilogue_res_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, resf);
         else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
@@ -490,6 +538,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
     }
     PWS_STAMP(5);                                                    // all tiles done
     __builtin_amdgcn_s_barrier();                                    // END
+    PWS_STAMP(14);                                                   // every wave's epilogue issued
     if constexpr (EPM == 1 || BST) {
         conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, n0, red);
         if constexpr (EPM == 8) {
@@ -498,6 +547,8 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         }
     }
     PWS_STAMP(6);                                                    // statistics flushed
+#ifdef PWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PWS_STAMP(7);                                                    // stores drained (diagnostic wait)
+#endif
 }
