@@ -556,7 +556,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
 // One barrier per 128-pixel tile.
 // ---------------------------------------------------------------------------
 template <int HROWS, int EPM>
-__global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles) {
+__global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles, int per) {
     constexpr int BM = 128, BN = 64, WM = 4, WN = 1;
     constexpr int WTM = BM / WM;
     constexpr int MI = WTM / 16, NI = 4;
@@ -572,13 +572,19 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.Ws, H = p.Hs, Wp = W + 2;
-    const int G = gridDim.x;
+    // Tile walk of a block.  per > 0: `per` CONSECUTIVE tiles (round 4) -- vertically adjacent 128-pixel tiles share two of their
+    // six halo rows, and walked by one block the second read of those rows hits the XCD's L2 a few microseconds after the first;
+    // strided over the grid (per == 0: tiles b, b + G, ...) the neighbours run at the same time on other XCDs and both
+    // reads go out to memory (1.6 x the activation bytes instead of ~1.1 x).
+    const int G = per > 0 ? 1 : gridDim.x;
+    const int tbeg = per > 0 ? blockIdx.x * per : blockIdx.x;
+    const int tend = per > 0 ? (tbeg + per < ntiles ? tbeg + per : ntiles) : ntiles;
 
     if (wave >= 4) {
         const int lw = wave - 4;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
-        const float rWp = 1.0f / (float)Wp;
+        const float rWp = g.rWp;
         auto issue_halo = [&](int mtile, int buf) __attribute__((always_inline)) {
             const int gr0 = mtile * g.TR;
             int prow0;
@@ -610,12 +616,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
         }
-        issue_halo(blockIdx.x, 0);
+        if (tbeg < tend) issue_halo(tbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // B_0
         int i = 0;
-        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
-            if (t + G < ntiles && !VPD_ABL(p, 4)) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
+        for (int t = tbeg; t < tend; t += G, ++i) {
+            if (t + G < tend && !VPD_ABL(p, 4)) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     __builtin_amdgcn_s_barrier();                                 // B_0
     int i = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+    for (int t = tbeg; t < tend; t += G, ++i) {
         const bf16_t* cH = sH + (i & 1) * HBUF;
         f32x4 acc[NI][MI];
 #pragma unroll
@@ -734,7 +740,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
 // ---------------------------------------------------------------------------
 #define C64X2_HPIX 344                           // halo pixels staged per tile (multiple of 8: one LDS-DMA instruction each)
 template <int EPM>
-__global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles) {
+__global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const ConvParams p, const HaloGeom g, int ntiles, int per) {
     constexpr int BN = 64;
     constexpr int MI = 2, NI = 4;                                 // per wave: 32 pixels x 64 channels
     constexpr int HBUF = C64X2_HPIX * 64;
@@ -748,7 +754,10 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = p.Ws, H = p.Hs, Wp = W + 2;
-    const int G = gridDim.x;
+    // (tile walk as in conv3x3_c64_persistent_kernel: per > 0 = `per` consecutive tiles per block)
+    const int G = per > 0 ? 1 : gridDim.x;
+    const int tbeg = per > 0 ? blockIdx.x * per : blockIdx.x;
+    const int tend = per > 0 ? (tbeg + per < ntiles ? tbeg + per : ntiles) : ntiles;
 
     if (wave >= 8) {
         const int lw = wave - 8;
@@ -781,12 +790,12 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sW + t * BN * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
         }
-        issue_halo(blockIdx.x, 0);
+        if (tbeg < tend) issue_halo(tbeg, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // B_0
         int i = 0;
-        for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
-            if (t + G < ntiles) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
+        for (int t = tbeg; t < tend; t += G, ++i) {
+            if (t + G < tend) issue_halo(t + G, (i + 1) & 1);   // buffer last read in tile i-1, finished before B_i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                         // B_{i+1}
         }
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
         for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     __builtin_amdgcn_s_barrier();                                 // B_0
     int i = 0;
-    for (int t = blockIdx.x; t < ntiles; t += G, ++i) {
+    for (int t = tbeg; t < tend; t += G, ++i) {
         const bf16_t* cH = sH + (i & 1) * HBUF;
         f32x4 acc[NI][MI];
 #pragma unroll
@@ -881,14 +890,17 @@ static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
 }
 static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 255) / 256;
-    const int grid = ntiles < 256 ? ntiles : 256;
+    int grid = ntiles < 256 ? ntiles : 256;
+    static const int contig = getenv("VPD_C64_CONTIG") ? atoi(getenv("VPD_C64_CONTIG")) : 1;
+    const int per = contig ? (ntiles + grid - 1) / grid : 0;
+    if (per > 0) grid = (ntiles + per - 1) / per;
     const size_t lds = ((size_t)9 * 64 + 2 * C64X2_HPIX) * 64 * sizeof(bf16_t);
     ConvParams q = p;
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<0>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
-        case 1: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<1>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
-        case 2: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<2>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
-        default: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<3>), dim3(grid), dim3(768), lds, stream, q, g, ntiles); break;
+        case 0: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<0>), dim3(grid), dim3(768), lds, stream, q, g, ntiles, per); break;
+        case 1: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<1>), dim3(grid), dim3(768), lds, stream, q, g, ntiles, per); break;
+        case 2: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<2>), dim3(grid), dim3(768), lds, stream, q, g, ntiles, per); break;
+        default: VPD_LAUNCH((conv3x3_c64x2_persistent_kernel<3>), dim3(grid), dim3(768), lds, stream, q, g, ntiles, per); break;
     }
     return hipGetLastError();
 }
@@ -896,18 +908,22 @@ static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream
 template <int HROWS>
 static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 127) / 128;
-    const int grid = ntiles < 256 ? ntiles : 256;
+    int grid = ntiles < 256 ? ntiles : 256;
+    // consecutive tiles per block (VPD_C64_CONTIG=0: strided); the grid shrinks to the blocks that get tiles
+    static const int contig = getenv("VPD_C64_CONTIG") ? atoi(getenv("VPD_C64_CONTIG")) : 1;
+    const int per = contig ? (ntiles + grid - 1) / grid : 0;
+    if (per > 0) grid = (ntiles + per - 1) / per;
     const size_t lds = ((size_t)9 * 64 + 2 * HROWS) * 64 * sizeof(bf16_t) + 2048;
     ConvParams q = p;
     // (the accumulate modes fetch the old values of y by dense pixel index ahead of the MFMA loop: conv_acc_prefetch)
     if (q.accumulate && (q.ypad != 0 || q.osub != 1 || q.yC != q.Co)) return hipErrorInvalidValue;
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 2: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 6: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 6>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        case 7: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 7>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
-        default: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles); break;
+        case 0: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 0>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
+        case 1: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 1>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
+        case 2: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 2>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
+        case 6: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 6>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
+        case 7: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 7>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
+        default: VPD_LAUNCH((conv3x3_c64_persistent_kernel<HROWS, 3>), dim3(grid), dim3(512), lds, stream, q, g, ntiles, per); break;
     }
     return hipGetLastError();
 }
@@ -1271,7 +1287,7 @@ static bool pws_enabled(const ConvParams& p) {
 template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false, bool RESW = false>
 static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     constexpr int WN = BN / 64, WM = NMW / WN;
-    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + (RESW ? 0 : 1024) + (size_t)2 * WM * BN * 4;
+    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + (RESW ? 0 : 1024) + (size_t)3 * WM * BN * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     PwsGrid sg;
     sg.MT = (p.M + BM - 1) / BM;
@@ -1758,10 +1774,9 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     switch (vpd_conv_kernel_class(p, &g)) {
         case 0: {
             HaloGeom g2;
-            // VPD_PWS_L1=1: 256-pixel tiles, 64 x 64 wave tiles, fragment pipeline, the nine taps resident (conv_pws.h, RESW)
-            static const int l1 = getenv("VPD_PWS_L1") ? atoi(getenv("VPD_PWS_L1")) : PWS_L1_DEFAULT;
-            if (l1 == 1 && pws_enabled(p) && p.M >= 256 * 64 && halo_geom(p, 256, 344, &g2))
-                return launch_pws<256, 64, 344, 9, 4, true, false, true>(p, g2, stream);
+            // (VPD_PWS_L1=1, round 3: 256-pixel tiles with the nine taps resident on the pipelined kernel -- measured slower, 30.2 vs
+            //  25.9 us, profiles/r03_layer1_resident_weights_negative.txt; its instantiation went when the block's running
+            //  statistics took the LDS words its filler transfers used to land in)
             if (c64x2_geom(p, &g2)) return launch_c64x2(p, g2, stream);      // inference: two MFMA wave groups on 256-pixel tiles
             return launch_c64<224>(p, g, stream);
         }
@@ -1793,6 +1808,15 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
             if (pws_enabled(p)) {
                 if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 4, true, true>(p, g, stream);
                 if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 3, 4, true, true>(p, g, stream);
+                // 16 x 16 images (layer2): a 256-pixel tile's halo is 18 x 18 = 324 pixels, not the 400 of layer3's four 8 x 8
+                // images -- the 22 KB the two smaller halo buffers leave go to a deeper weight ring.  The K loop is bound by the
+                // loaders' bytes in flight (~42 KB per CU at ~1 us of L2 latency = the measured 39 GB/s), not by their issue rate.
+                static const int l2ns = getenv("VPD_PWS_L2NS") ? atoi(getenv("VPD_PWS_L2NS")) : 7;
+                HaloGeom g3;
+                if (l2ns > 5 && halo_geom(p, 256, 328, &g3)) {
+                    if (l2ns >= 9) return launch_pws<256, 64, 328, 9, 4, true>(p, g3, stream);
+                    return launch_pws<256, 64, 328, 7, 4, true>(p, g3, stream);
+                }
                 return launch_pws<256, 64, 416, PWS_NS_C6, 4, true>(p, g, stream);
             }
             return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB

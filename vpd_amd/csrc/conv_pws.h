@@ -100,8 +100,10 @@ static __device__ __forceinline__ void pws_lgkm0() {
 #define PWS_RES_EARLY 1      // eval: residual fragments requested at the start of a tile's last chunk
 #endif
 #ifndef PWS_BST_EARLY4
-#define PWS_BST_EARLY4 0     // 64 x 64 wave tiles too: z fragments + mask bits of modes 6 / 7 requested one chunk ahead -- 40 registers
-                             // the K loop does not have: 35 (mode 6) / 31 (mode 7) spilled dwords with the round-4 epilogue
+#define PWS_BST_EARLY4 0     // 64 x 64 wave tiles too: z fragments + mask bits of modes 6 / 7 requested one chunk ahead (40 registers: they
+                             // fit, 248 / 250 VGPRs, since the statistics partials are tile-local).  MEASURED NEGATIVE, same box, kernel trace:
+                             // mode 6 26.3 vs 25.4 us, mode 7 28.5 vs 28.1 (profiles/r04_early_z_negative.txt) -- 32 KB of HBM-cold z per
+                             // block requested inside the K loop sit in the CU's memory queue in front of the loaders' L2-hit transfers
 #endif
 #ifndef PWS_ACC_PRE
 #define PWS_ACC_PRE 1        // accumulate modes: the old values of y of a whole tile requested before its epilogue
@@ -332,8 +334,6 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         pws_vmwait<0>();
         PWS_STAMP(11);                                               // loader done
         __builtin_amdgcn_s_barrier();                                // END
-        if (EPM == 1 || EPM == 6 || EPM == 7 || EPM == 8) __builtin_amdgcn_s_barrier();      // inside conv_stats_flush
-        if (EPM == 8) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }         // second flush
         return;
     }
 
@@ -373,19 +373,27 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const int r = wn * 64 + fr;
         wa0 = (unsigned)(r * 128 + ((fq ^ (r & 7)) << 4));
     }
-    float st1[NI][4], st2[NI][4];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
     constexpr bool BST = EPM == 6 || EPM == 7 || EPM == 8;
+    constexpr bool STATS = EPM == 1 || BST;
     constexpr bool BST_EARLY = PIPE && (EPM == 6 || EPM == 7) && (MI <= 2 || PWS_BST_EARLY4);
     BstPair<NI, VPD_BST_MB(MI)> pr;
-    if (EPM == 8) {
+    // Per-channel sums (statistics of the stored values; modes 6 / 7 / 8: sum g, sum g * z, sum g * z2): the per-lane partials
+    // live only inside a tile's epilogue -- across the K loop they were 32 registers that the early request of the z fragments
+    // (40) needs.  At the end of every tile they are reduced over the 16 pixel lanes and added to the block's running sums in
+    // LDS, [WM][3][BN] floats with exactly one owner lane per word (fr == 0 of the wave that holds the channel), always in tile
+    // order: the result does not depend on timing.  Single-tile blocks do the same work as before.
+    float* const redf = reinterpret_cast<float*>(red);
+    auto red_word = [&](int which, int a, int j) __attribute__((always_inline)) {
+        return (wm * 3 + which) * BN + wn * 64 + a * 16 + 4 * fq + j;
+    };
+    if (STATS && fr == 0) {
 #pragma unroll
         for (int a = 0; a < NI; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pr.s3[a][j] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                redf[red_word(0, a, j)] = 0.f; redf[red_word(1, a, j)] = 0.f;
+                if (EPM == 8) redf[red_word(2, a, j)] = 0.f;
+            }
     }
 
     unsigned stage = 0;                                              // ring stage of the step being consumed
@@ -520,6 +528,11 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
         if (VPD_ABL(p, 8)) continue;
+        float st1[NI][4], st2[NI][4];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; if (EPM == 8) pr.s3[a][j] = 0.f; }
         if (BST && !BST_EARLY) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
         if (EPM == 8) conv_bst2_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, pr);
         // accumulate modes: ALL old values of the tile requested up front (inside the epilogue the stores to y keep every
@@ -534,16 +547,45 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
         else if (RES_EARLY && res_pre) conv_epilogue_res_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, resf);
         else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+        if constexpr (STATS) {
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u = row16_sum(st1[a][j]), v = row16_sum(st2[a][j]);
+                    const float w = EPM == 8 ? row16_sum(pr.s3[a][j]) : 0.f;
+                    if (fr == 0) {      // (the owner lane: LDS float add, no return value)
+                        atomicAdd(&redf[red_word(0, a, j)], u);
+                        atomicAdd(&redf[red_word(1, a, j)], v);
+                        if (EPM == 8) atomicAdd(&redf[red_word(2, a, j)], w);
+                    }
+                }
+        }
         if (job == 0) PWS_STAMP(4);                                  // first tile's epilogue issued
     }
     PWS_STAMP(5);                                                    // all tiles done
+    if constexpr (STATS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS adds are done
     __builtin_amdgcn_s_barrier();                                    // END
     PWS_STAMP(14);                                                   // every wave's epilogue issued
-    if constexpr (EPM == 1 || BST) {
-        conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, blockIdx.x, n0, red);
-        if constexpr (EPM == 8) {
-            __builtin_amdgcn_s_barrier();                            // the first flush has read the scratch
-            conv_stats_flush<BM, BN, WM, WN>(p, st1, pr.s3, blockIdx.x, n0, red, p.stats2);
+    if constexpr (STATS) {
+        // the block's sums over its WM pixel-waves, then ONE fp64 atomic per channel and block into the BatchNorm's accumulator
+        // rows (conv_stats_flush: the rows are fp64 so that the blocks' arrival order cannot reach the fp32 results)
+        if (tid < 2 * BN) {
+            const int which = tid / BN;
+            const int c = tid - which * BN;
+            const int rmask = (p.stat_rows ? p.stat_rows : VPD_STAT_ROWS) - 1;
+            if (p.stats) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) t += redf[(w * 3 + which) * BN + c];
+                atomicAdd(&p.stats[((size_t)(blockIdx.x & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
+            }
+            if (EPM == 8 && p.stats2) {      // the second BatchNorm: sum g again, sum g * z2
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) t += redf[(w * 3 + (which ? 2 : 0)) * BN + c];
+                atomicAdd(&p.stats2[((size_t)(blockIdx.x & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
+            }
         }
     }
     PWS_STAMP(6);                                                    // statistics flushed
