@@ -64,17 +64,61 @@ def train_flop_per_crop(arch, c_in, hw, emb_dim):
     return 2 * (3 * macs - stem)
 
 
-def synthetic_batch(n, device, seed):
-    """Diving48-shaped crops in the reference's value ranges (vpd_dataset/common.py:52-69):
-    RGB ~ U{0..255}/255 normalised with the diving48 mean/std; flow = clip(round(124+12 N(0,1)))/255 - 0.5."""
+def synthetic_batch(n, device, seed, c_in=C_IN, mean_std=DIVING48_MEAN_STD, target_dim=EMB_DIM):
+    """Synthetic crops in the reference's value ranges (vpd_dataset/common.py:52-69): RGB ~ U{0..255}/255 normalised with
+    the data set's mean/std; the other c_in - 3 channels are flow planes, clip(round(124+12 N(0,1)))/255 - 0.5; random
+    teacher targets (2 * emb_dim wide with the motion head: train_vpd_model.py:61-65)."""
     g = torch.Generator(device=device).manual_seed(seed)
     rgb = torch.randint(0, 256, (n, 3, HW, HW), generator=g, device=device).float() / 255.0
-    mean = torch.tensor(DIVING48_MEAN_STD[0], device=device).view(1, 3, 1, 1)
-    std = torch.tensor(DIVING48_MEAN_STD[1], device=device).view(1, 3, 1, 1)
-    flow = (124 + 12 * torch.randn((n, 2, HW, HW), generator=g, device=device)).round().clamp(0, 255) / 255.0 - 0.5
+    mean = torch.tensor(mean_std[0], device=device).view(1, 3, 1, 1)
+    std = torch.tensor(mean_std[1], device=device).view(1, 3, 1, 1)
+    flow = (124 + 12 * torch.randn((n, c_in - 3, HW, HW), generator=g, device=device)).round().clamp(0, 255) / 255.0 - 0.5
     img = torch.cat([(rgb - mean) / std, flow], dim=1).contiguous()
-    emb = torch.randn((n, EMB_DIM), generator=g, device=device)
+    emb = torch.randn((n, target_dim), generator=g, device=device)
     return img, emb
+
+
+# BASELINE.json configs run under their own names (--config); per-GPU batch so that N GPUs give the config's global batch
+BENCH_CONFIGS = {
+    "c2": dict(what="configs[1]: Diving48-shaped synthetic crops 128x128, %s student (5-ch RGB+flow), emb_dim 128, sum-MSE + AdamW",
+               c_in=5, motion=False, norm="diving48", batch=256),
+    "c3": dict(what="configs[2]: --motion two-stream (6-ch RGB+flow input), %s student, emb_dim 128 + motion head, sum-MSE + AdamW "
+                    "(global batch 512 on 2 GPUs)", c_in=6, motion=True, norm="diving48", batch=256),
+    "c4": dict(what="configs[3]: figure-skating-shaped crops 128x128 (fs normalisation), %s student (5-ch), emb_dim 128 + motion "
+                    "head, sum-MSE + AdamW (global batch 4096 on 8 GPUs)", c_in=5, motion=True, norm="fs", batch=512),
+}
+
+
+def rccl_probe(eng, pl, world, device, iters=10):
+    """Self-validation of the multi-GPU leg: what the communicator says it is, and the bus bandwidth of a SUM
+    all-reduce of each gradient bucket's size, alone on the device (2 (N-1)/N x bytes / time: RCCL's convention)."""
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    info = {"backend": backend, "world_size": dist.get_world_size(), "rank0_device": str(device)}
+    if backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    buckets = []
+    for b, (off, numel) in enumerate(pl.buckets):
+        if numel == 0:
+            continue
+        buf = torch.zeros(numel, dtype=torch.float32, device=device)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / iters
+        buckets.append({"bucket": b, "MB": numel * 4 / 1e6, "ms": ms,
+                        "busbw_GBps": 2.0 * (world - 1) / world * numel * 4 / (ms * 1e-3) / 1e9})
+    info["allreduce_per_bucket"] = buckets
+    return info
 
 
 def host_cpu():
@@ -218,7 +262,7 @@ def spawn_ranks(n, argv):
         raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
-def apply_block(enc, device, batches=12, warmup=3):
+def apply_block(enc, device, batches=30, warmup=4):
     """Inference twin (BASELINE configs[4]): 1,000-crop batches (500 frames x 2 views, apply_vpd_model.py:15) of the
     eval forward as ONE hipGraph launch per batch, inputs resident; the timed region is `batches` launches."""
     frames, k = 500, 2
@@ -262,8 +306,9 @@ def apply_block(enc, device, batches=12, warmup=3):
             "loop_host_u8": {"value": batches * n / dt_u8, "unit": "crops/s",
                              "what": "vpd_amd.apply.embed_dataset on %d batches of %d u8 frames from pinned host memory: H2D, "
                                      "device-side views, hipGraph forward, D2H, tuple assembly (the 1 M-crop job with one pickle "
-                                     "per video: profiles/r03_apply_bench_1M.json, tools/bench_apply.py --crops 1000000)"
+                                     "per video: profiles/r04_apply_bench_1M.json, tools/bench_apply.py --crops 1000000)"
                                      % (batches, frames)},
+            "loop_vs_graph": dt / dt_u8,      # the whole loop's rate as a fraction of the bare graph launches' (same batches)
             "frac_of_mfma_peak": batches * n / dt * FWD_FLOP_PER_CROP / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS,
             "workload": "configs[4]-shaped: %d hipGraph launches of %d frames x %d views (1000 crops), eval forward, "
                         "inputs resident" % (batches, frames, k),
@@ -277,13 +322,20 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps; the median is reported")
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="crops per GPU per step")
+    ap.add_argument("--batch", type=int, default=None, help="crops per GPU per step (default: the config's)")
+    ap.add_argument("--config", default="c2", choices=sorted(BENCH_CONFIGS),
+                    help="BASELINE.json workload: c2 = configs[1] (default, the metric's config), c3 = configs[2] (6-channel input, "
+                         "motion head, 256 crops per GPU), c4 = configs[3] (fs normalisation, motion head, 512 crops per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-apply", action="store_true", help="skip the inference-twin block")
     ap.add_argument("--arch", default=ARCH, help="student architecture (default: the BASELINE config, resnet34)")
     ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
     args = ap.parse_args()
 
+    cfg = BENCH_CONFIGS[args.config]
+    if args.batch is None:
+        args.batch = cfg["batch"]
+    c_in, motion = cfg["c_in"], cfg["motion"]
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,12 +359,17 @@ def main():
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
     from vpd_amd.trainer import ModelTrainer
 
+    from vpd_amd.data import RGB_MEAN_STD
     torch.manual_seed(0)
-    enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device)
+    enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device, in_channels=c_in)
     enc.reset_parameters(seed=0)                 # reference init semantics, same weights on every rank
-    trainer = ModelTrainer(enc, motion=False)
+    trainer = ModelTrainer(enc, motion=motion)
+    if world > 1 and motion:                     # the motion head is initialised in the trainer: rank 0's on every rank
+        torch.distributed.broadcast(enc.engine.params, 0)
+        enc.engine.mark_weights_changed()
     optimizer, scaler = trainer.get_optimizer(5e-4)
-    img, emb = synthetic_batch(args.batch, device, seed=1 + rank)
+    img, emb = synthetic_batch(args.batch, device, seed=1 + rank, c_in=c_in, mean_std=RGB_MEAN_STD[cfg["norm"]],
+                               target_dim=(2 if motion else 1) * EMB_DIM)
     eng = enc.engine
     enc.train()
 
@@ -330,7 +387,7 @@ def main():
         torch.cuda.synchronize(device)
 
     # one-time setup that is not a "step": build the plan / workspace, and bring the RCCL communicator up
-    eng.plan(HW, HW, args.batch, True, False)
+    eng.plan(HW, HW, args.batch, True, motion)
     if world > 1:
         t = torch.zeros(1, device=device)
         torch.distributed.all_reduce(t)
@@ -356,7 +413,7 @@ def main():
 
     # ---- instrumented steps for the roofline: EVERY rank runs them (they contain the gradient all-reduce; a rank that
     # ran them alone would wait for its peers forever), rank 0 arms the per-kernel dispatch events and reads them ----
-    pl = eng.plan(HW, HW, args.batch, True, False)
+    pl = eng.plan(HW, HW, args.batch, True, motion)
     if rank == 0:
         eng.set_timing(pl, True)
     for _ in range(args.profile_steps):
@@ -367,6 +424,26 @@ def main():
         cls = eng.read_timing(pl) if args.profile_steps > 0 else {}
         eng.set_timing(pl, False)
 
+    # multi-GPU self-validation (every rank takes part): the same K steps with the all-reduces NOT overlapped with backward
+    # (VPD_DDP_OVERLAP=0: reduced in line after it), and the communicator's own numbers
+    multi = None
+    if world > 1:
+        os.environ["VPD_DDP_OVERLAP"] = "0"
+        for _ in range(3):
+            one_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        sync()
+        t_off = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t_off, op=torch.distributed.ReduceOp.MAX)
+        os.environ.pop("VPD_DDP_OVERLAP", None)
+        multi = rccl_probe(eng, pl, world, device)
+        multi["ms_per_step_overlap_on"] = 1e3 * dt / args.steps
+        multi["ms_per_step_overlap_off"] = 1e3 * float(t_off.item()) / args.steps
+        multi["lazy_gradients"] = os.environ.get("VPD_DDP_LAZY", "1") != "0"
+
     # a grid-barrier time-out (fused BatchNorm backward; vpd_amd/csrc/sync.h) means the timed steps were not valid steps
     nerr = eng.sync_errors()
     if nerr:
@@ -376,8 +453,10 @@ def main():
     if rank == 0:
         crops = args.batch * world * args.steps
         value = crops / dt
-        flop = train_flop_per_crop(args.arch, C_IN, HW, EMB_DIM)
-        assert (args.arch, C_IN) not in TRAIN_FLOP_PER_CROP or flop == TRAIN_FLOP_PER_CROP[(args.arch, C_IN)]
+        flop = train_flop_per_crop(args.arch, c_in, HW, EMB_DIM)
+        assert (args.arch, c_in) not in TRAIN_FLOP_PER_CROP or flop == TRAIN_FLOP_PER_CROP[(args.arch, c_in)]
+        if motion:      # FCNet(D, [128, 128], 2D) (models/module.py:133-156): forward + both gradients of three linear layers
+            flop += 2 * 3 * (EMB_DIM * 128 + 128 * 128 + 128 * 2 * EMB_DIM)
         kernels = {}
         for k, v in cls.items():
             if v["launches"] > 0:
@@ -402,9 +481,12 @@ def main():
             n = sum(r["launches"] for r in rows)
             traffic = sum(r["launches"] * (2 * r["fetch_KB_per_launch"] + r["write_KB_per_launch"]) for r in rows) / n * 1024
             traffic_note = pmc["note"]
-            import socket
+            from vpd_amd.boxid import gpu_unique_id
             traffic_source = dict(pmc.get("source") or {}, file="profiles/pmc_traffic.json")
-            traffic_source["same_host_as_this_run"] = traffic_source.get("host") == socket.gethostname()
+            # the pool's containers share one hostname: the box is named by the GPU's unique_id (KFD topology)
+            here = gpu_unique_id(local_rank)
+            traffic_source["this_run_gpu_unique_id"] = here
+            traffic_source["same_gpu_as_this_run"] = here != "unknown" and traffic_source.get("gpu_unique_id") == here
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"],
@@ -425,14 +507,15 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "repeats": {"n": len(region_s), "pick": "median", "crops_per_s": [args.batch * world * args.steps / t for t in region_s]},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "configs[1]: Diving48-shaped synthetic crops 128x128, %s student (5-ch RGB+flow), " % ("ResNet-34" if args.arch == ARCH else args.arch) +
-                                      "emb_dim 128, sum-MSE + AdamW, batch=%d per GPU" % args.batch,
+               "config": {"workload": cfg["what"] % ("ResNet-34" if args.arch == ARCH else args.arch) + ", batch=%d per GPU" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "flop_per_crop": flop, "loss_last_step": loss_now},
                "roofline": roofline}
-        if world == 1 and not args.no_apply and args.arch == ARCH:
+        if multi is not None:
+            out["multi_gpu"] = multi
+        if world == 1 and not args.no_apply and args.arch == ARCH and args.config == "c2":
             out["apply"] = apply_block(enc, device)
-        if world == 1 and not args.no_cpu_baseline and args.arch == ARCH:
+        if world == 1 and not args.no_cpu_baseline and args.arch == ARCH and args.config == "c2":
             out["cpu_baseline"], apply_cpu = cpu_baseline()
             if "apply" in out:
                 out["apply"]["cpu_baseline"] = apply_cpu

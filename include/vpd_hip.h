@@ -200,6 +200,28 @@ int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, double* 
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);
 int vpd_op_conv_bm(int M, int Co);
+/* The same launch as a DATA GRADIENT that also takes the sums of the BatchNorm backward consuming its output d (epilogue
+ * modes 6 / 7, reference: the reductions inside torch's batch_norm backward for models/module.py:41-43): g = d * mask with
+ * mask = the ReLU bit map [M][Co/8] of that BatchNorm's activation, rows f64 [4][2][Co] (pre-zeroed) receive sum g and
+ * sum g * z per channel (z: the BatchNorm's dense bf16 input [M][Co]).  y must be dense (ypad 0, yC == Co). */
+int vpd_op_conv2d_bnsums(const void* x_bf16, const void* w_bf16, void* y_bf16, const void* bst_z_bf16,
+                         const unsigned char* bst_mask, double* rows, int n, int xHp, int xWp, int xC, int Hs, int Ws,
+                         int Kc, int Co, const int* tapset9, int accumulate, void* stream);
+/* BatchNorm2d in training mode as the plan runs it (one launch: finalize + apply; models/module.py:41-43 + nn.BatchNorm2d):
+ * rows f64 [4][2][C] hold the per-channel sum / sum of squares of z as the producing convolution's epilogue left them;
+ * writes mean, rstd, scale = gamma rstd, shift = beta - mean scale, updates running_mean / running_var (momentum, unbiased
+ * variance) when given, and out = relu?(scale z + shift (+ residual)) into the bf16 NHWC tensor padded by 1
+ * ([n][H+2][W+2][C]; residual: same layout or null), plus the ReLU bit map [n H W][C/8] when mask_bits is given. */
+int vpd_op_bn_forward(const void* z_bf16, const double* rows, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* mean, float* rstd, float* scale, float* shift, const void* res_padded_bf16,
+                      void* out_padded_bf16, unsigned char* mask_bits, int n, int H, int W, int C, int relu, float momentum,
+                      float eps, void* stream);
+/* BatchNorm backward, finalize + apply in one launch (bn_bwd_apply_fused_kernel): rows f64 [4][2][C] hold sum g and sum g * z
+ * with g = dy * mask (what vpd_op_conv2d_bnsums leaves there); writes dz = gamma rstd (g - mean(g) - xhat mean(g xhat)) into
+ * the bf16 NHWC tensor padded by 1, dgamma = sum g xhat, dbeta = sum g. */
+int vpd_op_bn_backward_apply(const void* dy_bf16, const void* z_bf16, const unsigned char* mask_bits, const double* rows,
+                             const float* gamma, const float* mean, const float* rstd, void* dz_padded_bf16, float* dgamma,
+                             float* dbeta, int n, int H, int W, int C, void* stream);
 /* dw[slice][Co][Kc] (fp32) += sum over output pixels of dz[m][co] * x[gather(m, tap)][kc].
  * slab: optional fp32 scratch of vpd_op_wgrad_slab_bytes() bytes; when given, eligible 3x3 stride-1 shapes use
  * the halo kernel (split partials in the slab + reduce), otherwise the generic kernel (fp32 atomics). */

@@ -211,6 +211,54 @@ def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
     assert abs(ep0 - loss_sum / 10) <= 1e-4 * abs(ep0)
 
 
+def _rank_main_bottleneck(rank, world, port, q):
+    """ResNet-50 student, reducer attached: every BatchNorm backward of a Bottleneck student is a grid-barrier launch (42 per
+    step), the bucket all-reduces run on the comm stream beside them."""
+    import torch.distributed as dist
+    from vpd_amd.ddp import shard_slice
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        sd = O.procedural_state_dict(O.encoder_schema("resnet50", 5, 32), 12)
+        img, tgt = O.synthetic_crops(12, 5, 64, 13), O.synthetic_targets(12, 32, False, 14)
+        sl = shard_slice(12, rank, world)
+        enc = RGBF_EmbeddingModel("resnet50", 32, True, "cuda")
+        enc.load_state_dict(sd)
+        tr = ModelTrainer(enc, False, process_group=dist.group.WORLD)
+        assert tr._reducer is not None
+        opt, sc = tr.get_optimizer(5e-4)
+        eps = [tr.epoch([{"img": img[sl], "emb": tgt[sl]}], optimizer=opt, scaler=sc) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert enc.engine.sync_errors() == 0
+        q.put((rank, eps, enc.engine.params.clone().cpu().numpy(), bool(tr._reducer.overlap)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_a_bottleneck_student_with_the_reducer_attached():
+    """the grid-barrier BatchNorm launches of a Bottleneck student and the comm stream's bucket all-reduces
+    together, two ranks sharing this GPU: no barrier time-out, replicas bit-identical after three steps, finite losses that
+    both ranks agree on and that go down."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main_bottleneck, args=(r, 2, 29653, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, e0, w0, ov0), (_, e1, w1, ov1) = res
+    assert ov0 and ov1                                     # overlapped path (the default)
+    assert e0 == e1 and np.isfinite(e0).all() and e0[2] < e0[0]
+    assert np.array_equal(w0, w1)
+
+
 def test_train_cli_two_ranks_keep_identical_replicas(tmp_path):
     """train_vpd_model.py under two ranks (both on this GPU, gloo) with the motion head: the CLI broadcasts rank 0's
     initial weights (encoder AND motion head), all-reduces the gradients, and at the end compares a parameter checksum
@@ -249,6 +297,21 @@ def test_bench_self_launches_two_ranks_from_a_bare_shell():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak"
     assert out["steps"] == 3 and out["repeats"]["n"] == 2 and out["value"] > 0 and np.isfinite(out["config"]["loss_last_step"])
+    # the multi-GPU leg validates itself: communicator as it reports itself, bus bandwidth of an all-reduce of
+    # every gradient bucket's size, and the same steps with the all-reduces not overlapped with backward
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["world_size"] == 2 and mg["lazy_gradients"] is True
+    assert len(mg["allreduce_per_bucket"]) == 4 and all(b["busbw_GBps"] > 0 and b["ms"] > 0 for b in mg["allreduce_per_bucket"])
+    assert abs(sum(b["MB"] for b in mg["allreduce_per_bucket"]) - 21.36 * 4) < 1.0      # the ResNet-34 student's 21.4 M parameters
+    assert mg["ms_per_step_overlap_on"] > 0 and mg["ms_per_step_overlap_off"] > 0
+    # configs[2] under its own name: 6-channel input + motion head, 2 ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c3", "--steps", "2", "--warmup", "1",
+                        "--repeats", "1", "--batch", "8", "--profile-steps", "0", "--no-cpu-baseline", "--no-apply"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out3 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out3["config"]["workload"].startswith("configs[2]") and out3["config"]["global_batch"] == 16
+    assert np.isfinite(out3["config"]["loss_last_step"]) and out3["config"]["flop_per_crop"] > out["config"]["flop_per_crop"]
     # a failing rank fails the launcher
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--arch", "no_such_arch", "--no-cpu-baseline", "--no-apply"], cwd=root, env=env,

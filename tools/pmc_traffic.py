@@ -53,7 +53,10 @@ def main():
     # traffic figure comes from the box it ran on)
     import socket
     import time
-    source = {"tag": os.environ.get("VPD_PROFILE_TAG", ""), "host": socket.gethostname(),
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vpd_amd.boxid import gpu_unique_id
+    # (every container of the pool is called the same: the GPU's unique_id from the KFD topology names the box)
+    source = {"tag": os.environ.get("VPD_PROFILE_TAG", ""), "host": socket.gethostname(), "gpu_unique_id": gpu_unique_id(0),
               "collected_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
               "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"}
     json.dump({"note": note, "source": source, "kernels": kernels}, open(out, "w"), indent=1)

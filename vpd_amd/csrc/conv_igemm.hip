@@ -1808,15 +1808,9 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
             if (pws_enabled(p)) {
                 if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 4, true, true>(p, g, stream);
                 if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 3, 4, true, true>(p, g, stream);
-                // 16 x 16 images (layer2): a 256-pixel tile's halo is 18 x 18 = 324 pixels, not the 400 of layer3's four 8 x 8
-                // images -- the 22 KB the two smaller halo buffers leave go to a deeper weight ring.  The K loop is bound by the
-                // loaders' bytes in flight (~42 KB per CU at ~1 us of L2 latency = the measured 39 GB/s), not by their issue rate.
-                static const int l2ns = getenv("VPD_PWS_L2NS") ? atoi(getenv("VPD_PWS_L2NS")) : 7;
-                HaloGeom g3;
-                if (l2ns > 5 && halo_geom(p, 256, 328, &g3)) {
-                    if (l2ns >= 9) return launch_pws<256, 64, 328, 9, 4, true>(p, g3, stream);
-                    return launch_pws<256, 64, 328, 7, 4, true>(p, g3, stream);
-                }
+                // (round 4: layer2's 18 x 18 halo needs 328 rows, not 416, and the 22 KB that frees were given to a deeper weight ring,
+                //  NS 7 and 9 -- same-box 72.02 / 72.02 / 71.86 k crops/s for NS 7 / 9 / 5, profiles/r04_ab_layer2_ring_depth.txt: the K
+                //  loop is not bound by the loaders' bytes in flight; instantiations removed)
                 return launch_pws<256, 64, 416, PWS_NS_C6, 4, true>(p, g, stream);
             }
             return launch_ws<256, 64, 416, 2, 2, 4>(p, g, stream);       // 104 + 32 KiB

@@ -734,6 +734,24 @@ bool vpd_wgrad_overwrites(const WgradParams& p0) {
 
 size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float); }   // ksplit * tiles <= 256
 
+// deferred slab sums of single halo launches (vpd_launch_wgrad with defer_reduce) join a grouped launch's reduce
+static void wg_reduce_take_extra(WgReduceGroup& red, long& max_n4, int& max_ks, std::vector<WgradParams>* extra) {
+    if (!extra) return;
+    while (!extra->empty() && red.nprob < WG_GROUP_MAX) {
+        const WgradParams& q = extra->front();
+        const int ks = vpd_wgrad_split(q.M, q.Co, q.Kc, nullptr);
+        const long n4 = (long)(q.taps.nr == 1 ? 1 : 9) * q.Co * q.Kc / 4;
+        red.slab[red.nprob] = reinterpret_cast<const float4*>(q.slab);
+        red.dw[red.nprob] = reinterpret_cast<float4*>(q.dw);
+        red.n4[red.nprob] = n4;
+        red.ksplit[red.nprob] = ks;
+        max_n4 = n4 > max_n4 ? n4 : max_n4;
+        max_ks = ks > max_ks ? ks : max_ks;
+        ++red.nprob;
+        extra->erase(extra->begin());
+    }
+}
+
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
     const int ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, nullptr);
     const long n4 = (long)(p.taps.nr == 1 ? 1 : 9) * p.Co * p.Kc / 4;
@@ -810,7 +828,7 @@ bool vpd_wgrad_group_eligible(const WgradParams& p) {
     return vpd_wgrad_overwrites(q) && wg_halo_geom(q, &g);
 }
 // ps[i].slab must point to vpd_wgrad_group_slab_floats() floats of its own (ignored when that is 0)
-hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream) {
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream, std::vector<WgradParams>* extra) {
     if (n < 1 || n > WG_GROUP_MAX) return hipErrorInvalidValue;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     WgGroup grp = {};
@@ -855,6 +873,7 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
     if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<3>, dim3(grid), dim3(768), lds, stream, grp);
     else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<4>, dim3(grid), dim3(768), lds, stream, grp);
     else VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<5>, dim3(grid), dim3(768), lds, stream, grp);
+    wg_reduce_take_extra(red, max_n4, max_ks, extra);
     if (red.nprob > 0 && !(ablate & 16)) {
         const int groups = max_ks < 16 ? max_ks : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),
@@ -1532,7 +1551,8 @@ struct Wg2Cache {
 void* vpd_wgrad128_cache_new() { return new Wg2Cache(); }
 void vpd_wgrad128_cache_free(void* c) { delete static_cast<Wg2Cache*>(c); }
 
-hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream) {
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream,
+                                     std::vector<WgradParams>* extra) {
     if (n < 1 || n > WG2_MAX || !dev_table) return hipErrorInvalidValue;
     static int ncu = 0;
     if (!ncu) {
@@ -1622,6 +1642,7 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     static const int pipe = getenv("VPD_WG2_PIPE") ? atoi(getenv("VPD_WG2_PIPE")) : 0;
     if (pipe) VPD_LAUNCH(conv_wgrad128_persistent_kernel<true>, dim3(sch.grid), dim3(512), lds, stream, grp);
     else VPD_LAUNCH(conv_wgrad128_persistent_kernel<false>, dim3(sch.grid), dim3(512), lds, stream, grp);
+    wg_reduce_take_extra(red, max_n4, max_ks, extra);
     if (red.nprob > 0) {
         const int groups = max_ks < 16 ? max_ks : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),

@@ -1,5 +1,7 @@
 // Host-side launcher declarations for the HIP kernels (internal to libvpdhip).
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 struct BnApplyParams {
@@ -73,14 +75,17 @@ size_t vpd_wgrad_slab_bytes();
 // grouped (per-stage, deferred) weight gradients: see WgGroup in conv_wgrad.hip
 bool vpd_wgrad_group_eligible(const WgradParams& p);
 size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc, int ntaps = 9);
-hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
+// `extra` (both grouped launchers): single halo launches whose split partials still sit in their slabs (WgradParams::defer_reduce)
+// -- their sums ride in this launch's slab-reduce launch (one launch instead of one per conv); the ones taken are erased
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream, std::vector<WgradParams>* extra = nullptr);
 bool vpd_wgrad_overwrites(const WgradParams& p);
 // 128 x 64 tiles, persistent blocks, host-built schedule (conv_wgrad128_persistent_kernel in conv_wgrad.hip)
 bool vpd_wgrad128_eligible(const WgradParams& p);
 size_t vpd_wgrad128_table_bytes();
 void* vpd_wgrad128_cache_new();
 void vpd_wgrad128_cache_free(void* cache);
-hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache, void* dev_table, hipStream_t stream);
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache, void* dev_table, hipStream_t stream,
+                                     std::vector<WgradParams>* extra = nullptr);
 bool vpd_wgrad_halo_shape_ok(int Hout, int Wout, int stride = 1, int Hin = 0, int Win = 0);
 
 hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,

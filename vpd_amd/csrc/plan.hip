@@ -192,13 +192,16 @@ void add_conv(vpd_plan* p, ConvInfo& c, int Ci, int Co, int k, int stride, int p
     }
     c.wg_off = p->wg_elems;
     p->wg_elems += (long long)c.ntaps * Co * c.Kc;
-    if (stem && p->train && p->slab_elems == 0)      // the stem wgrad's split slab (shared region, summed at once)
-        p->slab_elems += (long long)(vpd_wgrad_slab_bytes() / 4);
+    // split slabs of the single (not grouped) halo launches: TWO regions of the maximum size -- region 0 for the stem and the
+    // 3x3 convs, region 1 for the 1x1 convs, so that a down-sampling block's two weight gradients can both wait for their
+    // stage's slab-reduce launch (round 4); a region is summed before it is written again
+    if (stem && p->train && p->slab_elems == 0)
+        p->slab_elems += 2 * (long long)(vpd_wgrad_slab_bytes() / 4);
     if (!stem && ((k == 3 && pad == 1) || (k == 1 && pad == 0)) && (stride == 1 || stride == 2) && p->train &&
         vpd_wgrad_halo_shape_ok(c.Hout, c.Wout, stride, Hin, Win)) {
         // halo wgrad conv: ONE shared slab, summed right after each wgrad launch while it is still in the Infinity
         // Cache (per-conv slabs summed once per bucket were measured 4 % slower: 490 MB fall out of the cache)
-        c.slab_off = 0;
+        c.slab_off = k == 1 ? (long long)(vpd_wgrad_slab_bytes() / 4) : 0;
     }
 }
 
@@ -869,7 +872,8 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
 }
 
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
-                          hipStream_t st, ZeroRanges* collect_zero = nullptr, bool prezeroed = false) {
+                          hipStream_t st, ZeroRanges* collect_zero = nullptr, bool prezeroed = false,
+                          std::vector<WgradParams>* defer_to = nullptr) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -898,6 +902,15 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     }
     if (vpd_wgrad_overwrites(q) && !q.defer_reduce && !cv.stem) {      // time the MFMA kernel alone, then sum its slab
         hipError_t e;
+        if (defer_to) {      // a slab region is summed before it is written again
+            for (size_t i = 0; i < defer_to->size();) {
+                if ((*defer_to)[i].slab == q.slab) {
+                    e = vpd_launch_wgrad_reduce((*defer_to)[i], st);
+                    if (e != hipSuccess) return e;
+                    defer_to->erase(defer_to->begin() + i);
+                } else ++i;
+            }
+        }
         {
             // class 5 = the grouped per-stage launches (and single stride-1 halo launches); a stride-2 conv's own halo
             // launch (two output tiles, 128 splits) is a different regime: class 6 with the other per-conv launches
@@ -906,6 +919,10 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
             e = vpd_launch_wgrad(q, st);
         }
         if (e != hipSuccess) return e;
+        if (defer_to) {      // the slab sum rides in the stage's grouped slab-reduce launch (or is launched by whoever flushes the list)
+            defer_to->push_back(q);
+            return hipSuccess;
+        }
         return vpd_launch_wgrad_reduce(q, st);
     }
     TimeScope ts(c.p, st, cv.stem ? 7 : (vpd_wgrad_overwrites(q) ? 5 : 6), conv_flops(cv, c.n));      // 7: stem kernels
@@ -1321,6 +1338,22 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     const bool grouped = p->wg_group;
     struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
     std::vector<Pending> pending;
+    // VPD_WG_REDUCE_MERGE=1 (round 4, MEASURED NEGATIVE, default off): single halo launches (the stride-2 3x3 and 1x1 convs of
+    // a down-sampling block) leave their split partials in their slab regions for the stage's grouped slab-reduce launch -- 6
+    // launches of ~5-8 us per ResNet-34 step become extra rows of 3.  Same box: 72.5 k vs 73.4 k crops/s
+    // (profiles/r04_ab_reduce_merge_negative.txt): behind the 120-250 us grouped weight-gradient launch the ~40 MB of
+    // partials per boundary have left the caches, which costs more than the launches saved (the same lesson as round 1's
+    // per-bucket sums).
+    std::vector<WgradParams> reduce_later;
+    static const int merge_reduce = getenv("VPD_WG_REDUCE_MERGE") ? atoi(getenv("VPD_WG_REDUCE_MERGE")) : 0;
+    auto flush_reduce_later = [&]() -> hipError_t {
+        for (const WgradParams& q : reduce_later) {
+            const hipError_t e = vpd_launch_wgrad_reduce(q, s);
+            if (e != hipSuccess) return e;
+        }
+        reduce_later.clear();
+        return hipSuccess;
+    };
     auto make_q = [&](const Pending& pd) {
         const ConvInfo& cv = *pd.cv;
         WgradParams q;
@@ -1336,7 +1369,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     };
     // `slot`: the stage whose table / schedule cache the 128 x 64 launch uses
     auto flush_group = [&](int slot) -> hipError_t {
-        if (pending.empty()) return hipSuccess;
+        if (pending.empty()) return flush_reduce_later();
         hipError_t r = hipSuccess;
         // persistent 128-wide tiles (conv_wgrad128_persistent_kernel) for every conv it takes: one launch per 18 problems
         // (a ResNet-50 stage has up to 19: two balanced launches)
@@ -1362,7 +1395,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 }
                 if (!p->wg2_cache[sl]) p->wg2_cache[sl] = vpd_wgrad128_cache_new();
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad128_group(elig.data() + at, cnt, p->wg2_cache[sl], ws + p->wg2_tbl_off[sl], s);
+                r = vpd_launch_wgrad128_group(elig.data() + at, cnt, p->wg2_cache[sl], ws + p->wg2_tbl_off[sl], s, &reduce_later);
                 at += cnt;
             }
         }
@@ -1380,11 +1413,12 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             }
             {
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad_group(qs, take, s);
+                r = vpd_launch_wgrad_group(qs, take, s, &reduce_later);
             }
             done += take;
         }
         pending.clear();
+        if (r == hipSuccess) r = flush_reduce_later();      // (whatever no grouped reduce launch had room for)
         return r;
     };
     // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
@@ -1393,7 +1427,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             pending.push_back({&cv, dz, x});
             return hipSuccess;
         }
-        return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed);
+        // (a bucket is handed over -- unpacked, its event recorded -- only behind its stage's flush_group, i.e. behind these sums)
+        return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed, grouped && merge_reduce ? &reduce_later : nullptr);
     };
     // lazy: the caller asked for it (vpd_plan_set_lazy_grads).  With bucket events the reducer then sums the scratch ranges
     // (vpd_plan_bucket_scratch_range) and the non-conv tensors of the flat buffer instead of the whole flat buffer
@@ -1401,6 +1436,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     p->lazy_next = false;
     p->grads_in_scratch = lazy;
     auto unpack_bucket = [&](int b) -> int {
+        LCHECK(flush_reduce_later());      // (nothing left in the normal order of events)
         int nb = (int)p->bmap_unpack[b].size() / 2;
         if (lazy) nb = b == 3 ? p->nstem_unpack_blocks : 0;      // the stem's row-tap packing is undone here either way
         if (nb > 0)
@@ -1833,6 +1869,59 @@ extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, double* stat
     q.taps = tapset_from(tapset9);
     if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
     LCHECK(vpd_launch_conv(q, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_op_conv2d_bnsums(const void* x, const void* w, void* y, const void* bst_z, const unsigned char* bst_mask,
+                                    double* rows, int n, int xHp, int xWp, int xC, int Hs, int Ws, int Kc, int Co,
+                                    const int* tapset9, int accumulate, void* stream) {
+    if (!bst_z || !bst_mask || !rows) return fail("null argument");
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.w = (const bf16_t*)w;
+    q.y = (bf16_t*)y; q.yHp = Hs; q.yWp = Ws; q.yC = Co; q.ypad = 0;
+    q.N = n; q.Hs = Hs; q.Ws = Ws; q.osub = 1; q.istr = 1;
+    q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws; q.accumulate = accumulate;
+    q.bst_z = (const bf16_t*)bst_z; q.bst_mask = bst_mask; q.stats = rows; q.stat_rows = VPD_FUSED_ROWS;
+    q.taps = tapset_from(tapset9);
+    if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
+    if (!vpd_conv_takes_bn_sums(q)) return fail("no kernel takes the BatchNorm sums for this shape");
+    LCHECK(vpd_launch_conv(q, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_op_bn_forward(const void* z, const double* rows, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float* mean, float* rstd, float* scale, float* shift, const void* res,
+                                 void* out, unsigned char* mask_bits, int n, int H, int W, int C, int relu, float momentum,
+                                 float eps, void* stream) {
+    if (!z || !rows || !gamma || !beta || !mean || !rstd || !scale || !shift || !out) return fail("null argument");
+    BnApplyParams a;
+    memset(&a, 0, sizeof a);
+    a.z = (const bf16_t*)z;
+    a.res_kind = res ? 1 : 0; a.res = (const bf16_t*)res; a.rHp = H + 2; a.rWp = W + 2; a.rpad = 1;
+    a.out = (bf16_t*)out; a.oHp = H + 2; a.oWp = W + 2; a.opad = 1;
+    a.M = n * H * W; a.H = H; a.W = W; a.C = C; a.relu = relu; a.mask_out = mask_bits;
+    BnFusedFwd f;
+    memset(&f, 0, sizeof f);
+    f.rows = const_cast<double*>(rows); f.count = (float)a.M; f.gamma = gamma; f.beta = beta; f.rm = running_mean; f.rv = running_var;
+    f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift; f.momentum = momentum; f.eps = eps;
+    LCHECK(vpd_launch_bn_fwd_fused(a, f, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int vpd_op_bn_backward_apply(const void* dy, const void* z, const unsigned char* mask_bits, const double* rows,
+                                        const float* gamma, const float* mean, const float* rstd, void* dz, float* dgamma,
+                                        float* dbeta, int n, int H, int W, int C, void* stream) {
+    if (!dy || !z || !mask_bits || !rows || !gamma || !mean || !rstd || !dz || !dgamma || !dbeta) return fail("null argument");
+    BnBwdParams b;
+    memset(&b, 0, sizeof b);
+    b.dy = (const bf16_t*)dy; b.z = (const bf16_t*)z; b.mean = mean; b.rstd = rstd;
+    b.dz = (bf16_t*)dz; b.dzHp = H + 2; b.dzWp = W + 2; b.dzpad = 1;
+    b.M = n * H * W; b.H = H; b.W = W; b.C = C; b.mask_bits = mask_bits;
+    BnFusedBwd f;
+    memset(&f, 0, sizeof f);
+    f.rows = const_cast<double*>(rows); f.gamma = gamma; f.dgamma = dgamma; f.dbeta = dbeta; f.count = (float)b.M;
+    LCHECK(vpd_launch_bn_bwd_apply_fused(b, f, (hipStream_t)stream));
     return 0;
 }
 
