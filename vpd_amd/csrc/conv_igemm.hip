@@ -1313,14 +1313,22 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, dstamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost);
         const char* names[16] = {"entry", "setup done", "first READY", "K loop done", "epilogue issued", "tiles done", "stats flushed",
-                                 "stores drained", "L entry", "L halo issued", "L first landed", "L done", "L origin known", "L weights issued", "all epilogues", ""};
+                                 "stores drained", "L entry", "L halo issued", "L first landed", "L done", "L origin known", "(realtime)", "all epilogues", "(realtime)"};
         fprintf(stderr, "[pws stamps %s, %d blocks] cycles from the consumer's entry (median / max over blocks)\n", tag, nb);
         for (int k = 1; k < 15; ++k) {
+            if (k == 13) continue;
             std::vector<long long> d;
             for (int b = 0; b < nb; ++b) if (h[b * 16 + k] && h[b * 16]) d.push_back((long long)(h[b * 16 + k] - h[b * 16]));
             if (d.empty()) continue;
             std::sort(d.begin(), d.end());
             fprintf(stderr, "  %-16s %8lld %8lld\n", names[k], d[d.size() / 2], d.back());
+        }
+        {      // the clock the shader held between "halo issued" (slot 9 ~ slot 13's time) and "loader done" (slots 11 / 15)
+            std::vector<double> ghz;
+            for (int b = 0; b < nb; ++b)
+                if (h[b * 16 + 15] > h[b * 16 + 13] && h[b * 16 + 11] > h[b * 16 + 9])
+                    ghz.push_back((double)(h[b * 16 + 11] - h[b * 16 + 9]) / (double)(h[b * 16 + 15] - h[b * 16 + 13]) * 0.1);
+            if (!ghz.empty()) { std::sort(ghz.begin(), ghz.end()); fprintf(stderr, "  s_memtime ticks per ns over the K loops (median over blocks): %.3f  (min %.3f max %.3f)\n", ghz[ghz.size() / 2], ghz.front(), ghz.back()); }
         }
         unsigned long long lo = ~0ull, hi = 0;
         for (int b = 0; b < nb; ++b) { if (h[b * 16] && h[b * 16] < lo) lo = h[b * 16]; if (h[b * 16 + 7] > hi) hi = h[b * 16 + 7]; }
@@ -1746,6 +1754,7 @@ bool vpd_conv_takes_bn_sums(const ConvParams& p) {
         return s2 && !p.accumulate && p.osub == 2;
     }
     if (p.x2 || p.osub != 1) return false;
+    if (p.yWp != p.Ws || p.yHp != p.Hs) return false;      // (the 3x3 kernels index z / the bit map by dense pixel number)
     if (p.bst_z2) return p.accumulate && p.stats2 && (kc == 1 || kc == 2 || kc == 3 || kc == 6);      // mode 8: conv3x3_ws_kernel only
     if (kc == 0) {      // layer1's persistent kernel (not its two-group variant)
         static const int l1 = getenv("VPD_DGRAD_SUMS_L1") ? atoi(getenv("VPD_DGRAD_SUMS_L1")) : 1;

@@ -50,8 +50,12 @@ struct PwsGrid {
 #ifdef PWS_STAMPS
 #define PWS_STAMP(slot) do { if (p.err && lane == 0 && (wave == 0 || wave == NMW)) \
     reinterpret_cast<unsigned long long*>(p.err)[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// the constant 100 MHz counter beside a stamp: (delta s_memtime) / (delta s_memrealtime) x 100 MHz = the clock the shader held
+#define PWS_STAMP_RT(slot) do { if (p.err && lane == 0 && (wave == 0 || wave == NMW)) \
+    reinterpret_cast<unsigned long long*>(p.err)[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PWS_STAMP(slot) do { } while (0)
+#define PWS_STAMP_RT(slot) do { } while (0)
 #endif
 
 template <int N>
@@ -104,6 +108,9 @@ static __device__ __forceinline__ void pws_lgkm0() {
                              // fit, 248 / 250 VGPRs, since the statistics partials are tile-local).  MEASURED NEGATIVE, same box, kernel trace:
                              // mode 6 26.3 vs 25.4 us, mode 7 28.5 vs 28.1 (profiles/r04_early_z_negative.txt) -- 32 KB of HBM-cold z per
                              // block requested inside the K loop sit in the CU's memory queue in front of the loaders' L2-hit transfers
+#endif
+#ifndef PWS_BST_ROWS4
+#define PWS_BST_ROWS4 3      // ... how many tap rows (3 K-steps each) before the tile's end (1, 2, 3: all measured, none gains)
 #endif
 #ifndef PWS_ACC_PRE
 #define PWS_ACC_PRE 1        // accumulate modes: the old values of y of a whole tile requested before its epilogue
@@ -292,7 +299,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
             if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
             if (++w_st == NS) w_st = 0;
         }
-        PWS_STAMP(13);                                               // first weight bundles issued
+        PWS_STAMP_RT(13);                                            // (100 MHz counter at the loader's start of streaming)
         const int total_chunks = njobs * nchunks;
         int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0; // the chunk whose halo is issued during this chunk
         for (int c = 0; c < total_chunks; ++c) {
@@ -333,6 +340,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         }
         pws_vmwait<0>();
         PWS_STAMP(11);                                               // loader done
+        PWS_STAMP_RT(15);                                            // (100 MHz counter at the loader's end)
         __builtin_amdgcn_s_barrier();                                // END
         return;
     }
@@ -478,7 +486,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
         const bool res_pre = RES_EARLY && p.res != nullptr;
 #pragma nounroll
         for (int row = 0; row < nrows; ++row) {
-            if (BST_EARLY && row == nrows - 3) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+            if (BST_EARLY && row == nrows - (MI <= 2 ? 3 : PWS_BST_ROWS4)) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
             if (RES_EARLY && res_pre && row == nrows - 3) conv_res_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, resf);
             if (PWS_TOUCH && row == nrows - 3) pws_epilogue_touch<BM, BN, WM, WN, EPM, !BST_EARLY>(p, mtile, n0, geo, lds0 + OFF_DUMP);
             // the next tap row: the same chunk's, or the first one of the next chunk (other halo buffer)
