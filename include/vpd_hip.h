@@ -229,6 +229,11 @@ int vpd_op_wgrad(const void* dz_bf16, const void* x_bf16, float* dw, int n, int 
                  int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
                  float* slab, void* stream);
 size_t vpd_op_wgrad_slab_bytes(void);
+/* The weight gradients of a down-sampling BasicBlock's first conv (3x3, stride 2, pad 1) and of its 1x1 stride-2 branch in ONE
+ * launch (models/module.py:88-110: both read the block input x): dz / dz2 padded bf16 [n][Ho+2][Wo+2][Co], x padded bf16
+ * [n][2Ho+2][2Wo+2][Ci], dw fp32 [9][Co][Ci], dw2 fp32 [Co][Ci], slab / slab2: vpd_op_wgrad_slab_bytes() each. */
+int vpd_op_wgrad_pair(const void* dz_bf16, const void* dz2_bf16, const void* x_bf16, float* dw, float* dw2, int n, int Ho, int Wo,
+                      int Ci, int Co, float* slab, float* slab2, void* stream);
 /* dumps the ds_read_b64_tr_b16 fragments of one [128][64] bf16 tile: out [4][4][64][8] bf16 */
 int vpd_op_tr_read_probe(const void* tile_bf16, void* out_bf16, void* stream);
 /* Grouped weight gradients of `nprob` 3x3 pad-1 / 1x1 pad-0 convolutions (stride 1 or 2) on 128-channel-wide tiles in ONE persistent launch (the

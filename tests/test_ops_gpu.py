@@ -425,3 +425,32 @@ def test_conv_epilogue_batchnorm_sums(case, accumulate):
     want1, want2 = gm.sum(0), (gm * z.double()).sum(0)
     assert float((s[0] - want1).abs().max()) <= 2e-5 * float(gm.abs().sum(0).max())
     assert float((s[1] - want2).abs().max()) <= 2e-5 * float((gm * z.double()).abs().sum(0).max())
+
+
+PAIR_CASES = [("l2_32to16", 2, 64, 128, 16), ("l3_16to8", 3, 128, 256, 8), ("l4_8to4_ragged", 5, 256, 512, 4)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_wgrad_pair_downsampling_block(case):
+    """The 1x1 stride-2 branch's weight gradient as a tenth tap of its 3x3 stride-2 sibling's launch (round 4; in the plan behind
+    VPD_WG_PAIR=1, measured slower than the two launches): both against torch's conv2d gradients in fp32 on the same bf16 operands."""
+    name, n, ci, co, ho = case
+    L = _lib()
+    g = torch.Generator().manual_seed(len(name) + n)
+    x = bf16_round(torch.randn(n, ci, 2 * ho, 2 * ho, generator=g))
+    dz = bf16_round(torch.randn(n, co, ho, ho, generator=g))
+    dz2 = bf16_round(torch.randn(n, co, ho, ho, generator=g))
+    w3 = torch.zeros(co, ci, 3, 3, requires_grad=True)
+    w1 = torch.zeros(co, ci, 1, 1, requires_grad=True)
+    (F.conv2d(x, w3, None, stride=2, padding=1) * dz).sum().backward()
+    (F.conv2d(x, w1, None, stride=2, padding=0) * dz2).sum().backward()
+    xp, dzp, dz2p = to_padded_nhwc(x, 1, 1, 1, 1, slack=4096), to_padded_nhwc(dz, 1, 1, 1, 1), to_padded_nhwc(dz2, 1, 1, 1, 1)
+    dw = torch.full((9 * co * ci,), float("nan"), device="cuda")
+    dw2 = torch.full((co * ci,), float("nan"), device="cuda")
+    nsl = L.vpd_op_wgrad_slab_bytes() // 4
+    slab, slab2 = torch.empty(nsl, device="cuda"), torch.empty(nsl, device="cuda")
+    _check(L.vpd_op_wgrad_pair(ptr(dzp), ptr(dz2p), ptr(xp), ptr(dw), ptr(dw2), n, ho, ho, ci, co, ptr(slab), ptr(slab2), stream()))
+    torch.cuda.synchronize()
+    got3 = dw.view(3, 3, co, ci).permute(2, 3, 0, 1).cpu()
+    got1 = dw2.view(co, ci, 1, 1).cpu()
+    assert rel_l2(got3, w3.grad) < 1e-3 and rel_l2(got1, w1.grad) < 1e-3, (rel_l2(got3, w3.grad), rel_l2(got1, w1.grad))

@@ -207,6 +207,11 @@ struct WgradParams {
     // holds the 3x3 geometry, only tap 4 is accumulated and dw / the slab have ONE slice
     int one_by_one;
     int prefer_halo_1x1;                        // caller's wish for a 1x1 conv: the halo kernel (no atomics) instead of conv_wgrad_kernel
+    // halo kernel, PAIR mode (dz2 != null; round 4): the 1x1 stride-2 down-sampling branch of the same BasicBlock as a TENTH tap of
+    // its 3x3 stride-2 sibling's launch -- same input x (whose halo, the launch's dominant stream, is staged once for both), same
+    // output geometry and channel count, its own dz2 (same padded layout as dz):
+    //   dw2[co][kc] = sum_m dz2[m][co] * x[2 y + 1, 2 x + 1][kc]   (the 3x3's centre tap position), partials in slab2 like slab
+    const bf16_t* dz2; float* dw2; float* slab2;
 };
 
 // ---------------------------------------------------------------------------

@@ -1581,8 +1581,9 @@ static bool conv1x1_ws_eligible(const ConvParams& p) {
     // the merged parity classes of a stride-2 3x3 data gradient (+ the 1x1 branch's as extra K-steps of class 0) at the layer3
     // and layer4 boundaries (layer2's has 2,048 blocks of 2-8 K-steps: gather kernel)
     static const int dgon = getenv("VPD_CONV_S2_DGRAD_WS") ? atoi(getenv("VPD_CONV_S2_DGRAD_WS")) : 1;
+    static const int dgk = getenv("VPD_CONV_S2_DGRAD_KMIN") ? atoi(getenv("VPD_CONV_S2_DGRAD_KMIN")) : 256;
     if (p.ncls > 1 || p.x2 || p.osub != 1)
-        return dgon && p.ncls == 4 && p.osub == 2 && p.istr == 1 && !p.alt_w && !p.accumulate && !p.ep_scale && p.Kc >= 256 &&
+        return dgon && p.ncls == 4 && p.osub == 2 && p.istr == 1 && !p.alt_w && !p.accumulate && !p.ep_scale && p.Kc >= dgk &&
                p.Co % 128 == 0 && (!p.x2 || p.Kc2 == p.Kc) && (!p.bst_z || (p.yC == p.Co && p.ypad == 0));
     if (p.bst_z || p.oph != 0 || p.opw != 0) return false;
     // the stride-2 convs at the ResNet stage boundaries (3x3 forward, with the BasicBlock's 1x1 branch as second convolution):

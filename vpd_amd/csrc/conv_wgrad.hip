@@ -204,10 +204,13 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
 }
 
 // MFMA-wave body of conv_wgrad_halo_kernel for taps [T0, T1): ci columns 16*ctile .. +15, all 64 co.
-template <int T0, int T1, int NS>
+// PAIR2 (the 4-tap half only): a second dz tile at element offset `dz2_off` of every stage and the 1x1 branch's single tap
+// (the centre one) on top -- eight more MFMAs per chunk, behind the wave's own 32, with the fragment registers re-used
+template <int T0, int T1, int NS, bool PAIR2 = false>
 static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, const WgHaloGeom& g, const bf16_t* ring,
-                                                       int STAGE, int nch, int ctile, int lane, int bx, int by) {
+                                                       int STAGE, int nch, int ctile, int lane, int bx, int by, int dz2_off = 0) {
     constexpr int NT = T1 - T0;
+    static_assert(!PAIR2 || NT == 4, "the pair's extra tap rides in the 4-tap half");
     // W, H: OUTPUT dims; the x halo is rows of the padded INPUT (stride S = 1 or 2: input pixel S*y + r, S*x + t)
     const int W = p.Ws, H = p.Hs, Wp = p.xWp, S = p.istr;
     f32x4 acc[NT][4];
@@ -216,10 +219,13 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    f32x4 acc2[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
     // chunk-invariant LDS element offsets (within a stage) of every transposed read of this lane.
     // dz rows are 32*ks + 8*gq + 4*h + q: the swizzle only looks at row bits 1 and 3, so k-step 1 is +32 rows.
-    int offA[4][2], offB[2][NT][2];
+    int offA[4][2], offB[2][NT][2], offC[2][2];
     {
         const int ra = 8 * gq + q;
 #pragma unroll
@@ -245,6 +251,11 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
                     const int r = hmv + (p.taps.dy0 + (tt / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tt % 3) * p.taps.dxs);
                     const int col = ctile * 16 + 4 * pp;
                     offB[ks][t][h] = 64 * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
+                }
+                {      // the centre tap (tap 4): the input pixel of the 1x1 stride-2 branch
+                    const int r = hmv + (p.taps.dy0 + p.taps.dys) * Wp + (p.taps.dx0 + p.taps.dxs);
+                    const int col = ctile * 16 + 4 * pp;
+                    offC[ks][h] = 64 * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
                 }
             }
     }
@@ -282,6 +293,21 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
                         acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][t], acc[t][a], 0, 0, 0);
+            if constexpr (PAIR2) {
+                // the 1x1 branch: dz2 tile x the centre tap's pixels (the 5-tap wave of this SIMD is still in its 40 MFMAs)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) az[ks][a] = frag(st + dz2_off + ks * 32 * 64, offA[a][0], offA[a][1]);
+                    bx[ks][0] = frag(st, offC[ks][0], offC[ks][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc2[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][0], acc2[a], 0, 0, 0);
+            }
             continue;
         }
 #pragma unroll
@@ -316,17 +342,25 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
     }
+    if constexpr (PAIR2) {      // the 1x1 branch's single slice
+        float* o = p.slab2 + (size_t)by * p.Co * p.Kc + (size_t)co0 * p.Kc + ci0 + 16 * ctile + i16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc2[a][j];
+    }
 }
 
 #define WG_CH 64           // pixels per chunk = two MFMA K-steps (vpd_wgrad_split assumes 64)
 #define WG_NS 3            // ring stages
 
 // NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS).  (bx, by) = (output tile, pixel split) of this block.
-template <int NPASS, int NS = WG_NS>
+template <int NPASS, int NS = WG_NS, bool PAIR = false>
 static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, const WgHaloGeom& g, int bx, int by) {
     constexpr int HROWS = 32 * NPASS;
-    constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile then halo
-    constexpr int PER_CHUNK = 2 + NPASS;                          // LDS-DMA instructions per loader wave per chunk
+    constexpr int STAGE = (WG_CH + HROWS + (PAIR ? WG_CH : 0)) * 64;      // bf16 elements per stage: dz tile, halo (, dz2 tile)
+    constexpr int PER_CHUNK = 2 + NPASS + (PAIR ? 2 : 0);         // LDS-DMA instructions per loader wave per chunk
+    constexpr int DZ2_OFF = (WG_CH + HROWS) * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);               // [WG_NS][dz 64x64 | halo HROWSx64]
 
@@ -384,6 +418,23 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
                 const bf16_t* src = p.x + (size_t)gp * p.xC + ci0 + cpc * 8;
                 __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + WG_CH * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
+            if constexpr (PAIR) {      // the 1x1 branch's dz tile: same pixels, same padded layout, its own tensor
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (lw + 4 * i) * 8 + lrow;
+                    const int m = ch * WG_CH + row;
+                    const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
+                    const bf16_t* src = p.dz2 + cpc * 8;
+                    if (m < p.M) {
+                        const int b = m / (H * W);
+                        const int r = m - b * H * W;
+                        const int yy = r / W;
+                        const int xx = r - yy * W;
+                        src = p.dz2 + ((size_t)(b * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cpc * 8;
+                    }
+                    __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + DZ2_OFF + (lw + 4 * i) * 8 * 64), 16, 0, 0);
+                }
+            }
         };
         if (VPD_ABL(p, 1)) {
             for (int c = 0; c < nch; ++c) __builtin_amdgcn_s_barrier();
@@ -412,12 +463,12 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
         return;
     }
     if (wave < 4) wgrad_mfma_half<0, 5, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
-    else wgrad_mfma_half<5, 9, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
+    else wgrad_mfma_half<5, 9, NS, PAIR>(p, g, ring, STAGE, nch, ctile, lane, bx, by, DZ2_OFF);
 }
 
-template <int NPASS, int NS = WG_NS>
+template <int NPASS, int NS = WG_NS, bool PAIR = false>
 __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
-    wgrad_halo_body<NPASS, NS>(p, g, blockIdx.x, blockIdx.y);
+    wgrad_halo_body<NPASS, NS, PAIR>(p, g, blockIdx.x, blockIdx.y);
 }
 
 // Grouped launch: the weight gradients of SEVERAL convolutions of one ResNet stage in one grid.  A weight gradient
@@ -916,6 +967,26 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 5) VPD_LAUNCH(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
+        else if (p.dz2) {
+            // PAIR: a stride-2 3x3 with its block's 1x1 stride-2 branch as a tenth tap (+ one 8-KB dz2 tile per stage: two ring
+            // stages for both halo sizes -- three stages of the 10-pass halo plus the tiles would be 168 KB)
+            if (p.istr != 2 || p.one_by_one || !p.dw2 || !p.slab2 || npass > 13) return hipErrorInvalidValue;
+            const size_t lds2 = (size_t)2 * (2 * WG_CH + 32 * (npass <= 10 ? 10 : 13)) * 64 * sizeof(bf16_t);
+            if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 2, true>), dim3(tiles, g.ksplit), dim3(768), lds2, stream, p, g);
+            else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2, true>), dim3(tiles, g.ksplit), dim3(768), lds2, stream, p, g);
+            if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
+            // both slab sums in ONE launch
+            WgReduceGroup red = {};
+            red.nprob = 2;
+            red.slab[0] = reinterpret_cast<const float4*>(p.slab); red.dw[0] = reinterpret_cast<float4*>(p.dw);
+            red.n4[0] = (long)9 * p.Co * p.Kc / 4; red.ksplit[0] = g.ksplit;
+            red.slab[1] = reinterpret_cast<const float4*>(p.slab2); red.dw[1] = reinterpret_cast<float4*>(p.dw2);
+            red.n4[1] = (long)p.Co * p.Kc / 4; red.ksplit[1] = g.ksplit;
+            const int groups = g.ksplit < 16 ? g.ksplit : 16;
+            hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((red.n4[0] + 63) / 64), 2), dim3(64 * groups), 0, stream,
+                               red, groups);
+            return hipGetLastError();
+        }
         else if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 3>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
