@@ -22,6 +22,8 @@ python3 $R/tools/pmc_mfma_util.py $OUT/${TAG}_pmc_mfma $OUT/${TAG}_mfma_util.jso
 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/${TAG}_bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o p -- python3 $R/bench.py $ARGS > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 cp $OUT/${TAG}_prof/p_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
+python3 $R/tools/launch_gaps.py $OUT/${TAG}_prof/p_kernel_trace.csv > $OUT/${TAG}_launch_gaps.txt 2>&1
+python3 $R/tools/step_timeline.py $OUT/${TAG}_prof/p_kernel_trace.csv > $OUT/${TAG}_step_timeline.txt 2>&1
 python3 $R/tools/prof_summary.py $OUT/${TAG}_kernel_stats.csv 25 60 > $OUT/${TAG}_summary.txt
 python3 $R/tools/bandwidth_table.py $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_kernel_stats.csv > $OUT/${TAG}_bandwidth.txt 2>/dev/null
 rm -rf $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma $OUT/${TAG}_prof
