@@ -207,6 +207,16 @@ int vpd_op_conv_bm(int M, int Co);
 int vpd_op_conv2d_bnsums(const void* x_bf16, const void* w_bf16, void* y_bf16, const void* bst_z_bf16,
                          const unsigned char* bst_mask, double* rows, int n, int xHp, int xWp, int xC, int Hs, int Ws,
                          int Kc, int Co, const int* tapset9, int accumulate, void* stream);
+/* conv2(relu(bn1(z))) of a torchvision BasicBlock in training mode as ONE launch (conv3x3_pws_xf_kernel: the convolution's
+ * loader waves finalize bn1 from rows_in, apply scale z + shift and the ReLU on the way into LDS, and write the activation
+ * (bf16 NHWC padded by 1, border pre-zeroed) and its ReLU bit map [n H W][Kc/8] out for backward; reference:
+ * BasicBlock.forward conv1 -> bn1 -> relu -> conv2 under model.train()).  z dense bf16 [n][H][W][Kc]; w bf16 [9][Co][Kc];
+ * y dense bf16 [n][H][W][Co]; rows_out f64 [4][2][Co] (pre-zeroed) receive sum y / sum y^2.  Fails when the shape is not
+ * one the transforming loaders take (whole padded images per pixel tile). */
+int vpd_op_conv2d_bn_in(const void* z_bf16, const double* rows_in, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* mean, float* rstd, float* scale, float* shift, void* act_out_padded_bf16,
+                        unsigned char* mask_bits, const void* w_bf16, void* y_bf16, double* rows_out, int n, int H, int W,
+                        int Kc, int Co, float momentum, float eps, void* stream);
 /* BatchNorm2d in training mode as the plan runs it (one launch: finalize + apply; models/module.py:41-43 + nn.BatchNorm2d):
  * rows f64 [4][2][C] hold the per-channel sum / sum of squares of z as the producing convolution's epilogue left them;
  * writes mean, rstd, scale = gamma rstd, shift = beta - mean scale, updates running_mean / running_var (momentum, unbiased

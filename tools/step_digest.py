@@ -1,0 +1,47 @@
+"""A few train steps of the BASELINE student on a fixed synthetic batch -> losses + a digest of every parameter and BatchNorm
+buffer.  Used to compare two builds / switch settings of the library on the same GPU: `VPD_CONV_XF=0 python tools/step_digest.py`
+against the default must print the same line (the transforming loaders produce the bits of the launch they replace)."""
+import argparse
+import hashlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--arch", default="resnet34")
+    args = ap.parse_args()
+    from vpd_amd.data import RGB_MEAN_STD
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.models.util import step
+    from vpd_amd.trainer import ModelTrainer
+    device = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    enc = RGBF_EmbeddingModel(args.arch, bench.EMB_DIM, True, device, in_channels=5)
+    enc.reset_parameters(seed=0)
+    trainer = ModelTrainer(enc, motion=False)
+    optimizer, scaler = trainer.get_optimizer(5e-4)
+    img, emb = bench.synthetic_batch(args.batch, device, seed=1, c_in=5, mean_std=RGB_MEAN_STD["diving48"], target_dim=bench.EMB_DIM)
+    enc.train()
+    eng = enc.engine
+    losses = []
+    for _ in range(args.steps):
+        loss = trainer._forward_loss(img, emb, train=True)
+        step(optimizer, scaler, loss)
+        losses.append(float(eng.loss_step.item()))
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    h.update(eng.params.detach().cpu().numpy().tobytes())
+    h.update(eng.bn_running.detach().cpu().numpy().tobytes())
+    print("losses %s  params+bn sha256 %s" % (" ".join("%.9g" % v for v in losses), h.hexdigest()[:20]))
+
+
+if __name__ == "__main__":
+    main()

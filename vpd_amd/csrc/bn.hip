@@ -717,23 +717,6 @@ struct BnFusedFwdArgs {
     float momentum, eps;
 };
 
-static __device__ __forceinline__ void bn_finalize_channel(const double* rows, int C, int ch, float count, float eps,
-                                                           float gamma, float beta, float* mu_o, float* r_o, float* sc_o,
-                                                           float* sh_o, double* var_o) {
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
-        s1 += rows[((size_t)t * 2) * C + ch];
-        s2 += rows[((size_t)t * 2 + 1) * C + ch];
-    }
-    const double mu = s1 / (double)count;
-    double var = s2 / (double)count - mu * mu;
-    var = var > 0.0 ? var : 0.0;
-    const float r = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma * r;
-    *mu_o = (float)mu; *r_o = r; *sc_o = sc; *sh_o = beta - (float)mu * sc; *var_o = var;
-}
-
 __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams p, const BnFusedFwdArgs f) {
     extern __shared__ float sm[];                      // scale[C] shift[C] (rscale[C] rshift[C])
     const int C = p.C;

@@ -177,6 +177,47 @@ struct ConvParams {
     bf16_t* pool_y;
 };
 
+// One channel of a train-mode BatchNorm from its fp64 accumulator rows [VPD_FUSED_ROWS][2][C] (sum z, sum z^2): mean, 1 / std,
+// scale = gamma / std, shift = beta - mean * scale (bn_fwd_fused_kernel; the transforming loaders of conv3x3_pws_xf_kernel)
+static __device__ __forceinline__ void bn_finalize_channel(const double* rows, int C, int ch, float count, float eps,
+                                                           float gamma, float beta, float* mu_o, float* r_o, float* sc_o,
+                                                           float* sh_o, double* var_o) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
+        s1 += rows[((size_t)t * 2) * C + ch];
+        s2 += rows[((size_t)t * 2 + 1) * C + ch];
+    }
+    // (one fp64 division per thread, not two per channel plus an fp64 square root: every block of the fused BatchNorm launch and
+    //  every loader wave of conv3x3_pws_xf_kernel runs this in front of its first byte of real work; the cancellation-prone part,
+    //  E[z^2] - mean^2, stays in fp64, 1 / sqrt is v_rsq_f32 -- 1 ulp)
+    const double inv = 1.0 / (double)count;
+    const double mu = s1 * inv;
+    double var = s2 * inv - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    const float r = __builtin_amdgcn_rsqf((float)(var + (double)eps));
+    const float sc = gamma * r;
+    *mu_o = (float)mu; *r_o = r; *sc_o = sc; *sh_o = beta - (float)mu * sc; *var_o = var;
+}
+
+// conv3x3_pws_xf_kernel (train forward, round 4): BatchNorm + ReLU of the PRODUCING convolution applied by this launch's
+// loader waves on the way into LDS -- the launch that used to sit between the two convolutions of a BasicBlock
+// (bn_fwd_fused_kernel: ~5 us of fixed cost around 2-5 us of data movement on layer3 / layer4) is gone.  The loaders read the
+// dense z of the producer instead of the padded activation, finalize the statistics themselves (every block, as the fused
+// BatchNorm launch did), and write the activation and its ReLU bit map out for backward (ConvParams::x is that OUTPUT).
+struct ConvXf {
+    const bf16_t* z;                            // [N*H*W][Kc] dense output of the producing convolution
+    const double* rows;                         // its BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][Kc], complete
+    const float* gamma; const float* beta;
+    float* rm; float* rv;                       // running statistics (block 0 updates them) or null
+    float* mean; float* rstd; float* scale; float* shift;      // stored by block 0 for backward
+    unsigned char* mask;                        // ReLU bit map [N*H*W][Kc/8] or null
+    float count, momentum, eps;
+    float rHp;                                  // 1 / (H + 2), correctly rounded (vpd_fdiv)
+    int ablate;                                 // diagnostics (VPD_XF_ABLATE): 1 no activation / bit-map stores, 4 no finalize
+};
+struct PwsNoXf {};
+
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the
 // bucket-level reduce so both agree on the number of slabs without a host->device hand-off.
 static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, int Kc, int* cpb_out) {

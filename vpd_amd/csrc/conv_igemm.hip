@@ -189,20 +189,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p0)
 // tile [BN][64] streams (double-buffered LDS-DMA, prefetched one tap ahead).  No register staging, one
 // barrier per 64-deep K-step.
 // ---------------------------------------------------------------------------
-struct HaloGeom {
-    int TR;        // output rows per tile (BM / W)
-    int multi;     // tile spans TR/H whole images (TR > H)
-    int HR;        // padded rows in the halo
-    int NHP;       // halo pixels = HR * (W + 2)
-    int total_pix; // N * (H+2) * (W+2): clamp for the last (ragged) tile
-    // conv3x3_pws_kernel only: swizzle key of halo pixel (row hr, column xp of the padded tile) = (xp & kmask) ^ ((hr & rowmask) << kshift)
-    int kmask, kshift, rowmask;
-    float rH, rW, rWp;   // correctly rounded 1 / H, 1 / W, 1 / (W + 2) from the host (vpd_fdiv)
-};
-
-typedef const void __attribute__((address_space(1)))* gptr_t;
-typedef void __attribute__((address_space(3)))* lptr_t;
-
 #include "conv_pws.h"
 
 template <int BM, int BN, int HROWS, bool HALO2>
@@ -1262,7 +1248,7 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 #ifndef PWS_NS_C6
 #define PWS_NS_C6 5
 #endif
-static int pws_cu_count() {
+int pws_cu_count() {
     static int ncu = 0;
     if (!ncu) {
         int dev = 0;

@@ -67,6 +67,9 @@ struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
 bool vpd_conv_takes_bn_sums(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
+// conv_xf.hip: a train-forward 3x3 whose loaders apply the producing convolution's BatchNorm + ReLU (ConvXf)
+bool vpd_conv_xf_ok(const ConvParams& p);
+hipError_t vpd_launch_conv_xf(const ConvParams& p, const ConvXf& xf, hipStream_t stream);
 bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu);     // fused dgrad + BatchNorm-backward epilogue (ConvBnBwd) possible
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);

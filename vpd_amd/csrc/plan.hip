@@ -697,7 +697,8 @@ bool conv_pair_ok(const Ctx& c, const ConvInfo& c1, const ConvInfo& cd, bool tra
 // kernel takes the shape; *pooled tells the caller whether it did (false: plain conv into y, the pooling launch follows)
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
                         const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
-                        const AltConv* alt = nullptr, bf16_t* pool_y = nullptr, bool* pooled = nullptr) {
+                        const AltConv* alt = nullptr, bf16_t* pool_y = nullptr, bool* pooled = nullptr,
+                        const ConvXf* xf = nullptr, bool* xf_query = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -727,9 +728,12 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         if (!ok) { q.pool_y = nullptr; q.ep_scale = nullptr; q.ep_shift = nullptr; q.ep_relu = 0; }
         if (pooled) *pooled = ok;
     }
+    if (xf_query) { *xf_query = vpd_conv_xf_ok(q); return hipSuccess; }      // (would conv_xf.hip take this launch?)
     const int kc = vpd_conv_kernel_class(q);
     // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2 -- except layer1's 64 -> 64 convs, which stay in slot 0
     TimeScope ts(c.p, c.s, kc == 5 ? 7 : (kc == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kc), flops);
+    // xf: the producing convolution's BatchNorm + ReLU applied by this launch's loaders; `x` is then the activation it WRITES
+    if (xf) return vpd_launch_conv_xf(q, *xf, c.s);
     return vpd_launch_conv(q, c.s);
 }
 
@@ -1242,8 +1246,14 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         } else {
             LCHECK(run_conv_train(c, B.c1, cur, bn_running));
         }
-        LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1,
-                          B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr));
+        // BasicBlock: bn1 + ReLU applied by conv2's loader waves (conv_xf.hip) -- no launch between the two convolutions
+        bool xf2 = false;
+        if (!p->bottleneck && c.fused(B.c1) && c.fused(B.c2))
+            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                                nullptr, &xf2));
+        if (!xf2)
+            LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1,
+                              B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
@@ -1260,7 +1270,20 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             cur = outp;
             continue;
         }
-        LCHECK(run_conv_train(c, B.c2, a1, bn_running));
+        if (xf2) {
+            ConvXf xf;
+            memset(&xf, 0, sizeof xf);
+            const BnInfo& b1 = B.c1.bn;
+            xf.z = c.b16(B.c1.z_off); xf.rows = c.bn_rows(b1);
+            xf.gamma = params + b1.w_off; xf.beta = params + b1.b_off;
+            xf.rm = bn_running ? bn_running + b1.rm_off : nullptr; xf.rv = bn_running ? bn_running + b1.rv_off : nullptr;
+            xf.mean = c.bn_mean(b1); xf.rstd = c.bn_rstd(b1); xf.scale = c.bn_scale(b1); xf.shift = c.bn_shift(b1);
+            xf.mask = B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr;
+            xf.count = (float)(n * B.c1.Hout * B.c1.Wout); xf.momentum = kBnMomentum; xf.eps = kBnEps;
+            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &xf));
+        } else {
+            LCHECK(run_conv_train(c, B.c2, a1, bn_running));
+        }
         unsigned char* mbits = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
         if (B.ds) {
             if (!pair) LCHECK(run_conv_train(c, B.cd, cur, bn_running));
@@ -1915,6 +1938,32 @@ extern "C" int vpd_op_conv2d_bnsums(const void* x, const void* w, void* y, const
     if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
     if (!vpd_conv_takes_bn_sums(q)) return fail("no kernel takes the BatchNorm sums for this shape");
     LCHECK(vpd_launch_conv(q, (hipStream_t)stream));
+    return 0;
+}
+
+// A train-forward 3x3 whose loaders apply the producing convolution's BatchNorm + ReLU (conv_xf.hip): z dense [n][H][W][Kc],
+// act_out padded [n][H+2][W+2][Kc] (zero border, interior written here), y dense [n][H][W][Co], rows_out [VPD_FUSED_ROWS][2][Co]
+extern "C" int vpd_op_conv2d_bn_in(const void* z, const double* rows_in, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                                   void* act_out, unsigned char* mask_bits, const void* w, void* y, double* rows_out, int n, int H,
+                                   int W, int Kc, int Co, float momentum, float eps, void* stream) {
+    if (!z || !rows_in || !gamma || !beta || !mean || !rstd || !scale || !shift || !act_out || !w || !y || !rows_out)
+        return fail("null argument");
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)act_out; q.xHp = H + 2; q.xWp = W + 2; q.xC = Kc; q.w = (const bf16_t*)w;
+    q.y = (bf16_t*)y; q.yHp = H; q.yWp = W; q.yC = Co; q.ypad = 0;
+    q.stats = rows_out; q.stat_rows = VPD_FUSED_ROWS;
+    q.N = n; q.Hs = H; q.Ws = W; q.osub = 1; q.istr = 1; q.Kc = Kc; q.Co = Co; q.M = n * H * W;
+    q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
+    q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
+    if (!vpd_conv_xf_ok(q)) return fail("conv_xf.hip does not take this shape");
+    ConvXf xf;
+    memset(&xf, 0, sizeof xf);
+    xf.z = (const bf16_t*)z; xf.rows = rows_in; xf.gamma = gamma; xf.beta = beta; xf.rm = running_mean; xf.rv = running_var;
+    xf.mean = mean; xf.rstd = rstd; xf.scale = scale; xf.shift = shift; xf.mask = mask_bits;
+    xf.count = (float)q.M; xf.momentum = momentum; xf.eps = eps;
+    LCHECK(vpd_launch_conv_xf(q, xf, (hipStream_t)stream));
     return 0;
 }
 
