@@ -185,7 +185,8 @@ int vpd_plan_sync_errors(vpd_plan_t* plan, void* workspace, void* stream, unsign
  * 1 conv3x3_ws_kernel<256,128,352>, 2 conv3x3_ws_kernel<128,128,288>, 3 conv3x3_ws_kernel<128,64,288>,
  * 4 conv_igemm_kernel (gather), 5 conv_wgrad_halo_grouped_kernel (stride-1 3x3, per stage, without its slab reduce),
  * 6 per-conv weight-gradient launches (stride-2 3x3 on conv_wgrad_halo_kernel, 1x1 on conv_wgrad_kernel),
- * 7 conv_stem_persistent_kernel.  vpd_plan_read_timing (nclasses >= 8) waits for the
+ * 7 conv_stem_persistent_kernel, 8 conv3x3_pws_xf_kernel (a BasicBlock's second 3x3 with bn1 + ReLU applied by its loader
+ * waves; counted under its plain twin's class when nclasses == 8).  vpd_plan_read_timing (nclasses >= 8) waits for the
  * events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
 int vpd_plan_set_timing(vpd_plan_t* plan, int enable);
 int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);

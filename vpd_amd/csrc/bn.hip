@@ -884,7 +884,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
     for (int m = mbeg + pl; m < mend; m += ppi, ++it) {
         float g[8], z[8];
         const uint4 zr = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + c);
-        uint4 gr = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c);
+        uint4 gr;
+        if (MASK == 3 && !WRITE_G && p.dy_pooled) {         // dy = gradient of the global average pool, produced here
+            const float* d = p.dy_pooled + (size_t)(m / HW) * C + c;
+            const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + 4);
+            const float dv[8] = {d0.x * p.dy_pool_scale, d0.y * p.dy_pool_scale, d0.z * p.dy_pool_scale, d0.w * p.dy_pool_scale,
+                                 d1.x * p.dy_pool_scale, d1.y * p.dy_pool_scale, d1.z * p.dy_pool_scale, d1.w * p.dy_pool_scale};
+            gr = pack8(dv);
+            *reinterpret_cast<uint4*>(p.dy_rw + (size_t)m * C + c) = gr;
+        } else {
+            gr = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + c);
+        }
         unpack8(gr, g);
         unpack8(zr, z);
         if (MASK == 1) {

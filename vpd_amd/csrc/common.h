@@ -214,7 +214,7 @@ struct ConvXf {
     unsigned char* mask;                        // ReLU bit map [N*H*W][Kc/8] or null
     float count, momentum, eps;
     float rHp;                                  // 1 / (H + 2), correctly rounded (vpd_fdiv)
-    int ablate;                                 // diagnostics (VPD_XF_ABLATE): 1 no activation / bit-map stores, 4 no finalize
+    int ablate;                                 // diagnostics (VPD_XF_ABLATE; results are then wrong): 1 no activation / bit-map stores, 4 no finalize, 8 no prologue priority
 };
 struct PwsNoXf {};
 

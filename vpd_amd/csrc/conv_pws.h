@@ -314,7 +314,8 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             constexpr unsigned OFF_XF = OFF_RED + 3u * WM * BN * 4u;     // scale[Ci], shift[Ci]
             // The prologue below is ~800 vector ALU instructions per loader wave (slice constants, the first chunk's transform) in
             // front of the block's first MFMA, while the SIMD's OTHER wave -- older, so the winner of every issue arbitration -- runs
-            // its own set-up with slack to spare: priority to the loaders until the first READY (stamps: first READY 10,800 -> ...)
+            // its own set-up with slack to spare: priority to the loaders until the first chunk is written (stamps: first READY at
+            // 9,950 instead of 10,800 cycles; same-box 72.52 vs 72.27 k crops/s, profiles/r04_xf_ab.txt)
             if (!(xf.ablate & 8)) __builtin_amdgcn_s_setprio(3);
             constexpr int HTX = 8 - A;
             using SX = PwsSched<W_PER, HPASS, HTX, A>;
@@ -441,7 +442,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                 for (int k = 0; k < HPASS; ++k) put(t00, 0, k, sc, sh);
             }
             PWS_STAMP(13);                                               // first chunk written
-            if (!(xf.ablate & 16)) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             const int total_chunks = njobs * nchunks;
             int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0;
 #ifdef PWS_STAMPS
@@ -489,8 +490,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                                 for (int u = 0; u < SX::cnt(t - A); ++u) tie(SX::first(t - A) + u);
 #pragma unroll
                                 for (int u = 0; u < SX::cnt(t - A); ++u)
-                                    if (!((xf.ablate & 32) && u > 0) && !(xf.ablate & 64))      // (diagnostics: one slice per step / none)
-                                        put(ht, h_buf, SX::first(t - A) + u, sc, sh);
+                                    put(ht, h_buf, SX::first(t - A) + u, sc, sh);
                             }
                         }
                     }

@@ -38,6 +38,10 @@ struct BnBwdParams {
     // the stored activation; g is then neither read back from nor written to dy (the consumer of the identity path masks
     // dy itself: ConvParams::acc_mask)
     const unsigned char* mask_bits;
+    // fused backward with mask_bits only: dy does not exist yet -- it is the gradient of the global average pool, dy[b][y][x][c] =
+    // bf16(dy_pooled[b][c] * dy_pool_scale) (avgpool_bwd_kernel's value).  The kernel computes it, uses it, and writes it to dy_rw
+    // (unmasked: the identity path of the block adds onto it later) -- the avgpool_bwd launch in front of it is gone
+    const float* dy_pooled; float dy_pool_scale;
 };
 
 struct StemPoolBwdParams {

@@ -359,7 +359,10 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         // block map of vpd_plan_adamw_step: every conv tile as in the pack map (not the stem), then the ranges
         // of [0, nparam_padded) that are not conv weights, in 2048-float chunks (ADAM_PLAIN_CHUNK of optim.hip)
         const int nconv = (int)p->descs.size();
-        for (size_t i = 0; i + 1 < p->bmap_pack.size(); i += 2) {             // descs[0] is the stem: a plain range here
+        // (descs[0] is the stem: a plain range here, packed by a 28-block pack_weights_kernel launch afterwards.  Round 4 tried ONE
+        //  block of this launch for it -- update, then the row-tap packing, which gathers across the whole tensor: its ~30 dependent
+        //  round trips under the launch's 5 TB/s of traffic made it the launch's pole, 155 vs 131 us, profiles/r04_small_folds.txt)
+        for (size_t i = 0; i + 1 < p->bmap_pack.size(); i += 2) {
             if (p->bmap_pack[i] == 0) { p->nstem_pack_blocks++; continue; }
             p->bmap_adam.push_back(p->bmap_pack[i]); p->bmap_adam.push_back(p->bmap_pack[i + 1]);
         }
@@ -731,7 +734,10 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
     if (xf_query) { *xf_query = vpd_conv_xf_ok(q); return hipSuccess; }      // (would conv_xf.hip take this launch?)
     const int kc = vpd_conv_kernel_class(q);
     // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2 -- except layer1's 64 -> 64 convs, which stay in slot 0
-    TimeScope ts(c.p, c.s, kc == 5 ? 7 : (kc == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kc), flops);
+    const int tcls = kc == 5 ? 7 : (kc == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kc);
+    // (class 8: conv3x3_pws_xf_kernel -- a convolution that also does a BatchNorm launch's work is not the same kernel; readers
+    //  that ask for fewer than nine classes get it under the class of its plain twin)
+    TimeScope ts(c.p, c.s, xf ? (8 | (tcls << 8)) : tcls, flops);
     // xf: the producing convolution's BatchNorm + ReLU applied by this launch's loaders; `x` is then the activation it WRITES
     if (xf) return vpd_launch_conv_xf(q, *xf, c.s);
     return vpd_launch_conv(q, c.s);
@@ -993,9 +999,11 @@ hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int r
 bool relu_bits_ok(const Ctx& c, const ConvInfo& cv) {
     return c.p->relu_bits && c.fused(cv) && vpd_bn_bwd_fused_ok(c.n * cv.Hout * cv.Wout, cv.Co, false, false);
 }
+// dy_pooled: dy has not been produced yet -- it is the gradient of the global average pool over cv's output (the last block of
+// the network); the fused launch with a ReLU bit map produces it itself, every other path gets the avgpool_bwd launch first
 hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t* act, bf16_t* dz, int dzpad,
                       int write_g, float* grads, bool relu_from_z = false, bool reduce_done = false,
-                      const unsigned char* mask_bits = nullptr) {
+                      const unsigned char* mask_bits = nullptr, const float* dy_pooled = nullptr) {
     BnBwdParams b;
     memset(&b, 0, sizeof b);
     b.dy = dy; b.dy_rw = dy; b.z = c.b16(cv.z_off);
@@ -1007,7 +1015,16 @@ hipError_t run_bn_bwd(const Ctx& c, const ConvInfo& cv, bf16_t* dy, const bf16_t
     if (mask_bits) { b.mask_bits = mask_bits; b.act = nullptr; b.write_g = 0; write_g = 0; }
     if (relu_from_z && !reduce_done) { b.act = nullptr; b.mscale = c.bn_scale(cv.bn); b.mshift = c.bn_shift(cv.bn); }
     if (reduce_done) b.act = nullptr;        // dy already holds g (masked by the producing dgrad kernel)
-    if (c.fused(cv) && !reduce_done && vpd_bn_bwd_fused_ok(b.M, b.C, b.act != nullptr, write_g != 0)) {
+    const bool fused = c.fused(cv) && !reduce_done && vpd_bn_bwd_fused_ok(b.M, b.C, b.act != nullptr, write_g != 0);
+    if (dy_pooled) {
+        static const bool fold = !(getenv("VPD_POOLBWD_FOLD") && !atoi(getenv("VPD_POOLBWD_FOLD")));
+        if (fused && mask_bits && fold) { b.dy_pooled = dy_pooled; b.dy_pool_scale = 1.f / (float)(cv.Hout * cv.Wout); }
+        else {
+            hipError_t e = vpd_launch_avgpool_bwd(dy_pooled, cv.Hout, cv.Wout, cv.Co, c.n, dy, c.s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    if (fused) {
         BnFusedBwd f;
         f.rows = c.bn_rows(cv.bn); f.sync = c.ws + cv.bn.sync_off;
         f.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
@@ -1352,6 +1369,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     }
     int gi = 0;      // index of the G buffer holding d(out) of the current block
     bf16_t* G[3] = {c.b16(p->G_off[0]), c.b16(p->G_off[1]), c.b16(p->G_off[2])};
+    bool pool_pending = false;      // d(out) of the last block has not been written yet: d(pooled) is what there is
     if (!p->motion && p->fused_head && p->feat % 2 == 0) {
         const StageInfo& S = p->stages[3];
         LCHECK(vpd_launch_head_bwd_fused(demb, params + p->fc.w_off, c.f32(p->pooled_off), grads + p->fc.w_off,
@@ -1361,7 +1379,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
         LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, p->feat, p->D, 0, 0, 0, s));
         const StageInfo& S = p->stages[3];
-        LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
+        // BasicBlock students: the last block's BatchNorm backward produces d(out) from d(pooled) itself (run_bn_bwd)
+        if (!p->bottleneck && !p->blocks.back().ds) pool_pending = true;
+        else LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
     }
     // grouped mode: eligible convs are queued and launched together when the stage's backward is done
     // (running weight gradients or their slab sums on a second stream was measured 6 % slower: DESIGN.md)
@@ -1550,6 +1570,10 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         bf16_t* dnew = G[(gi + 2) % 3];
         bf16_t* dz2 = c.b16(grouped && B.c2.dz_own_off ? B.c2.dz_own_off : S.dz2_off[par]);
         bf16_t* dz1 = c.b16(grouped && B.c1.dz_own_off ? B.c1.dz_own_off : S.dz1_off[par]);
+        if (pool_pending && (p->bottleneck || B.ds || bn2_sums_for[bi] || bn2_fused_for[bi])) {      // (not the path that produces d(out) itself)
+            LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, dout, s));
+            pool_pending = false;
+        }
         if (p->bottleneck) {
             bf16_t* dz3 = c.b16(grouped && B.c3.dz_own_off ? B.c3.dz_own_off : S.dz3_off);
             bf16_t* da2 = c.b16(p->T_off[0]);
@@ -1629,8 +1653,11 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         if (bn2_sums_for[bi] && !B.ds)      // (the next block's conv1 data gradient took the sums: mbits is set, dout is left alone)
             LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mbits));
         else if (bn2_sums_for[bi]) { /* down-sampling block: applied above */ }
-        else if (!bn2_fused_for[bi] && !bn_pair)
-            LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits));
+        else if (!bn2_fused_for[bi] && !bn_pair) {
+            LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits,
+                              pool_pending ? c.f32(p->dpooled_off) : nullptr));
+            pool_pending = false;
+        }
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
         if (dgrad_takes_bn(c, B.c2)) {
             // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
@@ -1855,7 +1882,9 @@ extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
         HCHECK(hipEventSynchronize(t.b));
         float ms = 0.f;
         HCHECK(hipEventElapsedTime(&ms, t.a, t.b));
-        out[3 * t.cls + 0] += 1.0; out[3 * t.cls + 1] += ms; out[3 * t.cls + 2] += t.flops;
+        int cls = t.cls & 0xff;
+        if (cls >= nclasses) cls = t.cls >> 8;
+        out[3 * cls + 0] += 1.0; out[3 * cls + 1] += ms; out[3 * cls + 2] += t.flops;
         p->ev_pool.push_back(t.a); p->ev_pool.push_back(t.b);
     }
     p->timed.clear();
