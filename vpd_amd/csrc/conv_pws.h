@@ -663,6 +663,9 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             }
     }
 
+#ifdef PWS_STAMPS
+    unsigned long long xs_store = 0;                                 // cycles this wave spent issuing the activation / bit-map stores
+#endif
     unsigned stage = 0;                                              // ring stage of the step being consumed
     int gch = 0;                                                     // global chunk index: halo buffer gch & 1
     for (int job = 0; job < njobs; ++job) {
@@ -811,7 +814,16 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                         interleave();
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (XF) {
-                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) { xf_store(bf0, 0); __builtin_amdgcn_sched_barrier(0); }
+                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) {
+#ifdef PWS_STAMPS
+                                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+                                xf_store(bf0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+#ifdef PWS_STAMPS
+                                xs_store += __builtin_amdgcn_s_memtime() - t0;
+#endif
+                            }
                         }
                         // region 2: K-half 0 of the NEXT step (landed: READY_s covers it; behind a tile's last step these are the
                         // next tile's first fragments or stale bytes, never used) while K-half 1 multiplies
@@ -822,7 +834,16 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                         interleave();
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (XF) {
-                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) { xf_store(bf1, 1); __builtin_amdgcn_sched_barrier(0); }
+                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) {
+#ifdef PWS_STAMPS
+                                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+                                xf_store(bf1, 1);
+                                __builtin_amdgcn_sched_barrier(0);
+#ifdef PWS_STAMPS
+                                xs_store += __builtin_amdgcn_s_memtime() - t0;
+#endif
+                            }
                         }
                     }
                 } else {
@@ -908,6 +929,10 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
 #ifdef PWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PWS_STAMP(7);                                                    // stores drained (diagnostic wait)
+    if (XF && p.err && lane == 0 && wave == 0) {                     // (XF: slot 7 re-used -- cycles spent in the centre-tap stores)
+        unsigned long long* e = reinterpret_cast<unsigned long long*>(p.err) + blockIdx.x * 16;
+        e[7] = e[0] + xs_store;
+    }
 #endif
 }
 

@@ -47,7 +47,7 @@ hipError_t launch_xf(const ConvParams& p, const HaloGeom& g, const ConvXf& xf, h
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, dstamps, (size_t)nb * 16 * 8, hipMemcpyDeviceToHost);
         const char* names[16] = {"entry", "setup done", "first READY", "K loop done", "epilogue issued", "tiles done", "stats flushed",
-                                 "stores drained", "L entry", "L sum issuing", "L first chunk landed", "L done", "L sum counted wait",
+                                 "sum centre-tap stores", "L entry", "L sum issuing", "L first chunk landed", "L done", "L sum counted wait",
                                  "L sum at barrier", "all epilogues", "table written"};
         fprintf(stderr, "[pws xf stamps <%d,%d> NS %d, %d blocks] cycles from the consumer's entry (median / max over blocks)\n", BM, BN, NS, nb);
         for (int k = 1; k < 16; ++k) {
