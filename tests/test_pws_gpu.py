@@ -87,3 +87,15 @@ def test_pws_conv_matches_reference_and_old_kernel(case, blocks):
     assert old["fwd"] < 4e-3 and old["dgrad"] < 4e-3
     # same products, same order of additions: identical bf16 outputs
     assert new["y_crc"] == old["y_crc"] and new["dx_crc"] == old["dx_crc"], (new, old)
+
+
+def test_transforming_loaders_with_many_tiles_per_block():
+    """conv3x3_pws_xf_kernel (conv2 of a BasicBlock with bn1 + ReLU applied by its loader waves) with 24 blocks instead of one per CU:
+    a block then walks ~11 pixel tiles (layer3) / ~5 (layer4), so the next tile's slices are requested and transformed inside the K
+    loop again and again, across halo buffers and ring wrap-arounds; the operator test's own gates apply (bit for bit the two launches
+    it replaces, torch in float64).  One child process: VPD_PWS_BLOCKS is read once per process."""
+    env = dict(os.environ, VPD_PWS_BLOCKS="24")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_ops_gpu.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "loaders and (l3 or l4)"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "5 passed" in r.stdout, r.stdout[-1000:]
