@@ -224,10 +224,12 @@ __global__ __launch_bounds__(256) void stem_pool_pair_kernel(const StemPoolParam
             }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            float best[8];
-            int bi[8];
+            // running maximum as ONE unsigned word per channel: the candidate's bf16 bits (post-ReLU, so non-negative: unsigned order
+            // = value order) above 15 - tap index -- v_max_u32 then keeps the larger value and, on a tie, the EARLIER tap, exactly
+            // what `if (a > best) { best = a; bi = idx; }` over the bf16-rounded activation did with a compare and two selects
+            unsigned key[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+            for (int j = 0; j < 8; ++j) key[j] = 0u;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -235,21 +237,30 @@ __global__ __launch_bounds__(256) void stem_pool_pair_kernel(const StemPoolParam
                     if (!ok[r][2 * o + tt]) continue;
                     float v[8];
                     unpack8(zr[r][2 * o + tt], v);
+                    const unsigned low = 15u - (unsigned)(r * 3 + tt);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float a = v[j] * sc[j] + sh[j];
-                        a = a > 0.f ? a : 0.f;
-                        a = bf2f(f2bf(a));
-                        if (a > best[j]) { best[j] = a; bi[j] = r * 3 + tt; }
+                    for (int j = 0; j < 8; j += 2) {
+                        float a0 = v[j] * sc[j] + sh[j], a1 = v[j + 1] * sc[j + 1] + sh[j + 1];
+                        a0 = a0 > 0.f ? a0 : 0.f; a1 = a1 > 0.f ? a1 : 0.f;
+                        const unsigned w = pack2bf(a0, a1);              // (the bf16-rounded activation, what a materialised tensor would hold)
+                        const unsigned k0 = (w << 16) | low, k1 = (w & 0xffff0000u) | low;
+                        key[j] = k0 > key[j] ? k0 : key[j];
+                        key[j + 1] = k1 > key[j + 1] ? k1 : key[j + 1];
                     }
                 }
             const int ox = 2 * kx + o;
             const size_t oo = ((size_t)(b * (Ho + 2 * p.opad) + oy + p.opad) * (Wo + 2 * p.opad) + ox + p.opad) * p.C + c;
-            *reinterpret_cast<uint4*>(p.out + oo) = pack8(best);
+            uint4 ov;
+            ov.x = (key[0] >> 16) | (key[1] & 0xffff0000u); ov.y = (key[2] >> 16) | (key[3] & 0xffff0000u);
+            ov.z = (key[4] >> 16) | (key[5] & 0xffff0000u); ov.w = (key[6] >> 16) | (key[7] & 0xffff0000u);
+            *reinterpret_cast<uint4*>(p.out + oo) = ov;
             if (p.idx) {
+                unsigned bi[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bi[j] = 15u - (key[j] & 15u);
                 uint2 iv;
-                iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
-                iv.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+                iv.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+                iv.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
                 *reinterpret_cast<uint2*>(p.idx + ((size_t)(b * Ho + oy) * Wo + ox) * p.C + c) = iv;
             }
         }
