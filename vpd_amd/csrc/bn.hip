@@ -206,11 +206,25 @@ __global__ __launch_bounds__(256) void stem_pool_pair_kernel(const StemPoolParam
     *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(p.scale + c + 4);
     *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(p.shift + c);
     *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(p.shift + c + 4);
+    // (item -> (image, row, output pair): 64-bit divisions cost more than the pooling itself; below 2^21 items the float
+    //  reciprocal splits exactly, and cv is a power of two for every ResNet stem)
+    const bool fast = total < VPD_FDIV_MAX && (cv & (cv - 1)) == 0;
+    const int cvs = 31 - __builtin_clz(cv);
+    const float rWk = 1.0f / (float)Wk, rHo = 1.0f / (float)Ho;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        long t = it / cv;
-        const int kx = (int)(t % Wk); t /= Wk;
-        const int oy = (int)(t % Ho);
-        const int b = (int)(t / Ho);
+        int kx, oy, b;
+        if (fast) {
+            const int t = (int)it >> cvs;
+            const int q = vpd_fdiv(t, rWk);
+            kx = t - q * Wk;
+            b = vpd_fdiv(q, rHo);
+            oy = q - b * Ho;
+        } else {
+            long t = it / cv;
+            kx = (int)(t % Wk); t /= Wk;
+            oy = (int)(t % Ho);
+            b = (int)(t / Ho);
+        }
         uint4 zr[3][5];
         bool ok[3][5];
 #pragma unroll
@@ -548,11 +562,23 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_quad_kernel(const StemPoolB
     LD8(mu, p.mean + c) LD8(rs, p.rstd + c) LD8(sc, p.scale + c) LD8(shf, p.shift + c)
     LD8(c1, p.coef + c) LD8(c2, p.coef + p.C + c) LD8(c3, p.coef + 2 * p.C + c)
 #undef LD8
+    // item -> (image, quad row, quad column): two 64-bit divisions + two remainders were ~480 of an item's ~1,100 vector instructions
+    // (the launch is ALU-bound: 60 us for 318 MB); item counts below 2^21 split exactly with the float reciprocal (vpd_fdiv)
+    const bool fast = items < VPD_FDIV_MAX;
+    const float rWk = 1.0f / (float)Wk, rHk = 1.0f / (float)Hk;
     for (long it = (long)blockIdx.x * per + threadIdx.x / cv; it < items; it += (long)gridDim.x * per) {
-        const int kx = (int)(it % Wk);
-        const long q = it / Wk;
-        const int ky = (int)(q % Hk);
-        const int b = (int)(q / Hk);
+        int kx, ky, b;
+        if (fast) {
+            const int q = vpd_fdiv((int)it, rWk);
+            kx = (int)it - q * Wk;
+            b = vpd_fdiv(q, rHk);
+            ky = q - b * Hk;
+        } else {
+            kx = (int)(it % Wk);
+            const long q = it / Wk;
+            ky = (int)(q % Hk);
+            b = (int)(q / Hk);
+        }
         // windows w[wy][wx] = (ky + wy, kx + wx); the far ones may fall off the pooled map
         uint4 dw[2][2];
         uint2 iw[2][2];
