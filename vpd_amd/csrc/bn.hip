@@ -663,11 +663,13 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_sums_kernel(const StemPoolB
     const int mbeg = blockIdx.x * p.ppb;
     int mend = mbeg + p.ppb;
     mend = mend < Mo ? mend : Mo;
+    const bool fast = Mo < VPD_FDIV_MAX;               // (two integer divisions per item were ~90 of its ~130 vector instructions)
+    const float rHWo = 1.0f / (float)HWo, rWo = 1.0f / (float)p.Wo;
     if (pl < ppi)
         for (int m = mbeg + pl; m < mend; m += ppi) {
-            const int b = m / HWo;
+            const int b = fast ? vpd_fdiv(m, rHWo) : m / HWo;
             const int r = m - b * HWo;
-            const int oy = r / p.Wo;
+            const int oy = fast ? vpd_fdiv(r, rWo) : r / p.Wo;
             const int ox = r - oy * p.Wo;
             float d[8], a[8];
             unpack8(*reinterpret_cast<const uint4*>(p.dpool + (size_t)m * p.C + c), d);
