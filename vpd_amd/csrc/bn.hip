@@ -826,6 +826,13 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
         }
     }
     __syncthreads();
+    // fast path: the stride (grid x 1024) is a multiple of C / 8, so a thread keeps its channel slice for every item it takes -- its
+    // sixteen coefficients are read from the LDS once, not per item
+    float ksc[8], ksh[8];
+    if (fast && have) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ksc[j] = s_sc[c + j]; ksh[j] = s_sh[c + j]; }
+    }
     while (have) {
         // the next item's operands are requested before this one is computed (two items in flight per thread)
         const long nx = it + stride;
@@ -834,8 +841,13 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
         if (hn) load_item(nx, zn, rn, on, cn);
         float v[8];
         unpack8(zc, v);
+        if (fast) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] * s_sc[c + j] + s_sh[c + j];
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * ksc[j] + ksh[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * s_sc[c + j] + s_sh[c + j];
+        }
         if (p.res_kind == 1) {
             float rr[8];
             unpack8(rc, rr);
@@ -1124,6 +1136,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
                               sD + 3 * C, f.dgamma2, f.dbeta2, blockIdx.x == 0);
     }
     __syncthreads();
+    // fast path: the stride (grid x 1024) is a multiple of C / 8 -- a thread's channel slice, and with it its 24 (48) coefficients, is
+    // the same for every item it takes: read from the LDS once
+    float kA[8], kB[8], kD[8], kA2[8], kB2[8], kD2[8];
+    if (fast && have) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kA[j] = sA[c + j]; kB[j] = sB[c + j]; kD[j] = sD[c + j];
+            if (PAIR) { kA2[j] = sA[3 * C + c + j]; kB2[j] = sB[3 * C + c + j]; kD2[j] = sD[3 * C + c + j]; }
+        }
+    }
     while (have) {
         const long nx = it + stride;
         const bool hn = nx < total;
@@ -1133,15 +1155,27 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
         unpack8(gc, g);
         unpack8(zc, z);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            g[j] = ((bc >> j) & 1u) ? g[j] : 0.f;
-            o[j] = sA[c + j] * g[j] + sB[c + j] * z[j] + sD[c + j];
+        for (int j = 0; j < 8; ++j) g[j] = ((bc >> j) & 1u) ? g[j] : 0.f;
+        // (explicit fma nesting in both branches: left to the compiler, the contraction of A g + B z + D depended on where the
+        //  operands came from, and every bit of dz with it)
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(kA[j], g[j], __builtin_fmaf(kB[j], z[j], kD[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(sA[c + j], g[j], __builtin_fmaf(sB[c + j], z[j], sD[c + j]));
         }
         *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
         if (PAIR) {      // same g, the branch's own z and coefficients, same padded geometry
             unpack8(z2c, z);
+            if (fast) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = sA[3 * C + c + j] * g[j] + sB[3 * C + c + j] * z[j] + sD[3 * C + c + j];
+                for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(kA2[j], g[j], __builtin_fmaf(kB2[j], z[j], kD2[j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = __builtin_fmaf(sA[3 * C + c + j], g[j], __builtin_fmaf(sB[3 * C + c + j], z[j], sD[3 * C + c + j]));
+            }
             *reinterpret_cast<uint4*>(f.dz2 + oo) = pack8(o);
         }
         it = nx; have = hn; gc = gn; zc = zn; z2c = z2n; bc = bn_; oo = on; c = cn;
