@@ -64,11 +64,10 @@ hipError_t launch_xf(const ConvParams& p, const HaloGeom& g, const ConvXf& xf, h
     return hipGetLastError();
 }
 
-// 6: 256 x 64 tiles (layer2 / layer3 at 256 crops), 3: 128 x 64 tiles (layer4); 0: not taken
+// 6: 256 x 64 tiles (layer2 / layer3 at 256 crops), 3: 128 x 64 tiles (layer4); 0: the kernel does not take the shape
 int xf_class(const ConvParams& p, HaloGeom* g) {
-    static const int on = getenv("VPD_CONV_XF") ? atoi(getenv("VPD_CONV_XF")) : 1;
     static const int pws = getenv("VPD_PWS") ? atoi(getenv("VPD_PWS")) : 1;
-    if (!on || !pws) return 0;
+    if (!pws) return 0;
     if (conv_ep_mode(p) != 1 || p.Kc % 64 != 0 || p.Co % 64 != 0 || p.M <= 0) return 0;
     if ((long)p.N * p.Hs >= VPD_FDIV_MAX) return 0;
     const int kc = vpd_conv_kernel_class(p, g);
@@ -85,7 +84,21 @@ int xf_class(const ConvParams& p, HaloGeom* g) {
 
 }  // namespace
 
+// The plan's question: take the XF kernel for this launch?  OFF by default since the BatchNorm launches read their coefficients once
+// per thread (same day, +1.6 % on the step): they now cost 7.0-7.7 us on layer3 and 6.2-7.0 on layer4 instead of 9.4 / 7.0, an XF
+// launch still costs ~8.5 us more than its plain twin, and what had been +0.3..0.55 % became -0.1 % at 256 crops and -0.45 % at 512
+// (profiles/r04_xf_ab.txt, last table).  Every one of the Co / 64 channel tiles of a pixel tile transforms the same input pixels on
+// SIMDs whose issue slots an MFMA wave owns; the launch it replaces shrinks with the tensor.  VPD_CONV_XF=1 takes it wherever it
+// fits, VPD_CONV_XF_NT bounds the channel tiles (2 = layer2 only: +-0 there).
 bool vpd_conv_xf_ok(const ConvParams& p) {
+    static const int on = getenv("VPD_CONV_XF") ? atoi(getenv("VPD_CONV_XF")) : 0;
+    static const int max_nt = getenv("VPD_CONV_XF_NT") ? atoi(getenv("VPD_CONV_XF_NT")) : 99;
+    if (!on || p.Co / 64 > max_nt) return false;
+    HaloGeom g;
+    return xf_class(p, &g) != 0;
+}
+// ... and the operator-level entry point's: does the kernel take this shape at all?
+bool vpd_conv_xf_fits(const ConvParams& p) {
     HaloGeom g;
     return xf_class(p, &g) != 0;
 }

@@ -72,7 +72,8 @@ hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
 bool vpd_conv_takes_bn_sums(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
 // conv_xf.hip: a train-forward 3x3 whose loaders apply the producing convolution's BatchNorm + ReLU (ConvXf)
-bool vpd_conv_xf_ok(const ConvParams& p);
+bool vpd_conv_xf_ok(const ConvParams& p);        // the plan's switch (VPD_CONV_XF, default off) AND the shape
+bool vpd_conv_xf_fits(const ConvParams& p);      // the shape alone (operator-level entry point)
 hipError_t vpd_launch_conv_xf(const ConvParams& p, const ConvXf& xf, hipStream_t stream);
 bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu);     // fused dgrad + BatchNorm-backward epilogue (ConvBnBwd) possible
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad

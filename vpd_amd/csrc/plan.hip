@@ -1986,7 +1986,7 @@ extern "C" int vpd_op_conv2d_bn_in(const void* z, const double* rows_in, const f
     q.N = n; q.Hs = H; q.Ws = W; q.osub = 1; q.istr = 1; q.Kc = Kc; q.Co = Co; q.M = n * H * W;
     q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
     q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
-    if (!vpd_conv_xf_ok(q)) return fail("conv_xf.hip does not take this shape");
+    if (!vpd_conv_xf_fits(q)) return fail("conv_xf.hip does not take this shape");
     ConvXf xf;
     memset(&xf, 0, sizeof xf);
     xf.z = (const bf16_t*)z; xf.rows = rows_in; xf.gamma = gamma; xf.beta = beta; xf.rm = running_mean; xf.rv = running_var;
