@@ -868,10 +868,24 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
         if (p.mask_out) {      // bit j = the STORED bf16 value is > 0 (values are >= 0 after the ReLU: non-zero bits)
             const unsigned w[4] = {ov.x, ov.y, ov.z, ov.w};
             unsigned bits = 0;
+            if (p.relu) {
+                // after the ReLU a stored value is +0 or positive: [half != 0] = min(half, 1) as unsigned 16-bit lanes (one instruction
+                // per word instead of two compares and two selects per element); the four words' flags side by side -- low halves at
+                // bits 0, 2, 4, 6, high halves at 16, 18, 20, 22 -- then the high halves folded one bit above the low ones
+                unsigned acc = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bits |= ((w[j] & 0x7fffu) != 0u && !(w[j] & 0x8000u)) ? (1u << (2 * j)) : 0u;
-                bits |= ((w[j] & 0x7fff0000u) != 0u && !(w[j] & 0x80000000u)) ? (2u << (2 * j)) : 0u;
+                for (int j = 0; j < 4; ++j) {
+                    unsigned f1;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f1) : "v"(w[j]), "v"(0x00010001u));
+                    acc |= f1 << (2 * j);
+                }
+                bits = (acc | (acc >> 15)) & 0xffu;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bits |= ((w[j] & 0x7fffu) != 0u && !(w[j] & 0x8000u)) ? (1u << (2 * j)) : 0u;
+                    bits |= ((w[j] & 0x7fff0000u) != 0u && !(w[j] & 0x80000000u)) ? (2u << (2 * j)) : 0u;
+                }
             }
             p.mask_out[it] = (unsigned char)bits;      // it = m * (C / 8) + c / 8
         }
