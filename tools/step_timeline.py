@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One training step as a timeline: every kernel launch of the LAST profiled step in order, with its duration and the gap
+"""One training step as a timeline: every kernel launch of one profiled step (the quietest of the last ten) in order, with its duration and the gap
 to its predecessor, from a rocprofv3 --kernel-trace csv.   tools/step_timeline.py <kernel_trace.csv> [launches_per_step]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -8,8 +8,16 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("pack_input") or "pack_input_kernel" in r["Kernel_Name"]]
 if len(starts) < 2:
     sys.exit("need at least two steps in the trace")
-a, b = starts[-2] - 1, starts[-1] - 1
-step = rows[a:b]
+# the step with the smallest sum of inter-dispatch gaps among the last ten complete ones (one host hiccup under the profiler
+# puts 40-120 us gaps into a single step; the per-step statistics over all steps are in tools/launch_gaps.py's output)
+best = None
+for k in range(max(1, len(starts) - 10), len(starts)):
+    a, b = starts[k - 1] - 1, starts[k] - 1
+    cand = rows[a:b]
+    gaps = sum(max(0, int(cand[i]["Start_Timestamp"]) - int(cand[i - 1]["End_Timestamp"])) for i in range(1, len(cand)))
+    if best is None or gaps < best[0]:
+        best = (gaps, cand)
+step = best[1]
 t0 = int(step[0]["Start_Timestamp"])
 prev_end = t0
 tot = 0.0
