@@ -101,15 +101,16 @@ def test_transforming_loaders_with_many_tiles_per_block():
     assert "5 passed" in r.stdout, r.stdout[-1000:]
 
 
-def test_train_steps_are_bit_identical_with_the_transforming_loaders_on():
+def test_train_steps_are_bit_identical_under_the_round4_switches():
     """VPD_CONV_XF=1 (conv2 of every BasicBlock of layer2-4 applies bn1 + ReLU in its loader waves; off by default since the
-    BatchNorm launches got cheaper than what the XF kernel costs) must not change a bit of the train step: losses of three steps at
-    256 crops and a SHA-256 over all parameters and BatchNorm buffers, from two child processes (the switch is read once)."""
-    outs = []
-    for v in ("1", "0"):
-        env = dict(os.environ, VPD_CONV_XF=v)
+    BatchNorm launches got cheaper than what the XF kernel costs) and VPD_POOLBWD_FOLD=0 (the avgpool_bwd launch instead of the last
+    BatchNorm backward producing d(out) itself) must not change a bit of the train step: losses of three steps at 256 crops and a
+    SHA-256 over all parameters and BatchNorm buffers, one child process per setting (the switches are read once)."""
+    outs = {}
+    for name, extra in (("default", {}), ("xf", {"VPD_CONV_XF": "1"}), ("pool_launch", {"VPD_POOLBWD_FOLD": "0"})):
+        env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "step_digest.py"), "--steps", "3"], env=env,
                            capture_output=True, text=True, timeout=900, cwd=REPO)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("losses ")][-1])
-    assert outs[0] == outs[1], outs
+        outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("losses ")][-1]
+    assert outs["xf"] == outs["default"] and outs["pool_launch"] == outs["default"], outs
