@@ -252,6 +252,10 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
 
     if (wave >= NMW) {
         // ------------------------------ loader waves ------------------------------
+#ifdef PWS_LOADER_PRIO      // (-DPWS_LOADER_PRIO=1|3, measured neutral: the loaders are the younger half of each SIMD's two waves and lose
+                            //  every issue arbitration, but they issue so little that it does not matter -- 72.1 / 72.3 vs 72.1 k crops/s)
+        __builtin_amdgcn_s_setprio(PWS_LOADER_PRIO);
+#endif
         const int lw = wave - NMW;
         const int piece = lane & 7;
         const int lrow = lane >> 3;
