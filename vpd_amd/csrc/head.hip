@@ -13,13 +13,27 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const bf16_t* act, int Hp,
         const int b = (int)(it / cv);
         const int c = (int)(it - (long)b * cv) << 3;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int y = 0; y < H; ++y)
-            for (int x = 0; x < W; ++x) {
+        if (H == 4 && W == 4) {      // (128 x 128 crops: all sixteen pixels requested before the first is added -- one round trip, not 16)
+            uint4 px[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                px[q] = *reinterpret_cast<const uint4*>(act + ((size_t)(b * Hp + (q >> 2) + pad) * Wp + (q & 3) + pad) * C + c);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {      // same order of additions as the general loop
                 float v[8];
-                unpack8(*reinterpret_cast<const uint4*>(act + ((size_t)(b * Hp + y + pad) * Wp + x + pad) * C + c), v);
+                unpack8(px[q], v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             }
+        } else {
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(act + ((size_t)(b * Hp + y + pad) * Wp + x + pad) * C + c), v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[j];
+                }
+        }
         float* o = pooled + (size_t)b * C + c;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = acc[j] * inv;
@@ -206,12 +220,24 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float* e, const float* 
     float a = 0.f;
     // four elements per thread and trip, loads of a trip issued together (the batch's 32 k values are 8 trips)
     const long n4 = n >> 2;
-    for (long i = threadIdx.x; i < n4; i += 1024) {
-        const float4 ev = reinterpret_cast<const float4*>(e)[i];
-        const float4 tv = reinterpret_cast<const float4*>(t)[i];
-        const float4 d = {ev.x - tv.x, ev.y - tv.y, ev.z - tv.z, ev.w - tv.w};
-        a += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
-        if (de) reinterpret_cast<float4*>(de)[i] = float4{2.f * d.x, 2.f * d.y, 2.f * d.z, 2.f * d.w};
+    for (long i0 = threadIdx.x; i0 < n4; i0 += 8 * 1024) {      // eight trips' loads in flight (one block: nothing else hides them)
+        float4 ev[8], tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long i = i0 + u * 1024;
+            const long ic = i < n4 ? i : i0;
+            ev[u] = reinterpret_cast<const float4*>(e)[ic];
+            tv[u] = reinterpret_cast<const float4*>(t)[ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                            // (same order of additions per thread as one trip at a time)
+            const long i = i0 + u * 1024;
+            if (i < n4) {
+                const float4 d = {ev[u].x - tv[u].x, ev[u].y - tv[u].y, ev[u].z - tv[u].z, ev[u].w - tv[u].w};
+                a += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+                if (de) reinterpret_cast<float4*>(de)[i] = float4{2.f * d.x, 2.f * d.y, 2.f * d.z, 2.f * d.w};
+            }
+        }
     }
     for (long i = (n4 << 2) + threadIdx.x; i < n; i += 1024) {
         const float d = e[i] - t[i];
