@@ -132,6 +132,9 @@ static __device__ __forceinline__ void pws_lgkm0() {
 #ifndef PWS_ACC_PRE
 #define PWS_ACC_PRE 1        // accumulate modes: the old values of y of a whole tile requested before its epilogue
 #endif
+#ifndef PWS_EVAL_COEF_LDS
+#define PWS_EVAL_COEF_LDS 1      // eval: the block's BN scale / shift in LDS for all its tiles (0: 2 * NI global loads per tile epilogue)
+#endif
 #ifndef PWS_TOUCH
 #define PWS_TOUCH 0      // measured: -1.2 % (256 crops), -1.5 % (512), -1.6 % (apply) same-box -- profiles/r03_epilogue_touch_negative.txt
 #endif
@@ -657,6 +660,13 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     auto red_word = [&](int which, int a, int j) __attribute__((always_inline)) {
         return (wm * 3 + which) * BN + wn * 64 + a * 16 + 4 * fq + j;
     };
+    // eval (mode 3): the block's 2 * BN scale / shift values into the statistics scratch (unused in this mode), once -- every tile's
+    // epilogue then starts with LDS reads instead of a global round trip (conv_epilogue_impl, lds_coef)
+    const float* const eval_coef = (EPM == 3 && PWS_EVAL_COEF_LDS) ? redf : nullptr;
+    if (EPM == 3 && PWS_EVAL_COEF_LDS) {
+        if (tid < 2 * BN) redf[tid] = tid < BN ? p.ep_scale[n0 + tid] : p.ep_shift[n0 + tid - BN];
+        pws_lgkm0();                                                 // (written before this wave's first READY)
+    }
     if (STATS && fr == 0) {
 #pragma unroll
         for (int a = 0; a < NI; ++a)
@@ -886,8 +896,8 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
         else if constexpr (ACC_PRE && EPM == 2) conv_epilogue_acc_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, accf);
         else if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
         else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
-        else if (RES_EARLY && res_pre) conv_epilogue_res_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, resf);
-        else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+        else if (RES_EARLY && res_pre) conv_epilogue_res_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, resf, 0, eval_coef);
+        else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, 0, eval_coef);
         if constexpr (STATS) {
 #pragma unroll
             for (int a = 0; a < NI; ++a)
