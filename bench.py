@@ -345,6 +345,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if os.environ.get("VPD_BENCH_STREAM") == "created":      # A/B: the step on a created stream instead of the null stream
+        torch.cuda.set_stream(torch.cuda.Stream(device))
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("VPD_DIST_BACKEND", "nccl")      # "nccl" is RCCL; gloo only for single-GPU dry runs of this path

@@ -352,3 +352,28 @@ def test_no_test_video_holds_the_reference_test_split_out(tmp_path, monkeypatch,
     monkeypatch.setenv("VPD_DIVING48_TEST_FILE", str(tmp_path / "absent.json"))
     with pytest.raises(FileNotFoundError):
         get_test_prefixes("diving48")
+
+
+def test_pretrained_checkpoint_lookup_prefers_the_v1_file_and_refuses_to_guess(tmp_path, monkeypatch):
+    """`--pretrained` (reference models/rgb.py:57-58) reads the file torchvision would download: with several checkpoints of one
+    architecture in a directory the ImageNet-V1 file is taken, and a set without it is an error, not a lexicographic pick."""
+    import torch
+    from vpd_amd.models.rgb import IMAGENET_V1_FILES, find_imagenet_weights
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(tmp_path / "hub"))
+    monkeypatch.setenv("VPD_PRETRAINED_WEIGHTS", str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        find_imagenet_weights("resnet50")
+    (tmp_path / "resnet50-11ad3fa6.pth").write_bytes(b"v2")
+    assert find_imagenet_weights("resnet50").endswith("resnet50-11ad3fa6.pth")       # a single candidate is taken as it is
+    (tmp_path / "resnet50-00000000.pth").write_bytes(b"other")
+    with pytest.raises(FileNotFoundError, match="none is the ImageNet-V1 file"):
+        find_imagenet_weights("resnet50")
+    (tmp_path / IMAGENET_V1_FILES["resnet50"]).write_bytes(b"v1")
+    assert find_imagenet_weights("resnet50").endswith(IMAGENET_V1_FILES["resnet50"])
+    assert not find_imagenet_weights("resnet50").endswith("wide_resnet50_2-95faca4d.pth")
+    monkeypatch.setenv("VPD_PRETRAINED_WEIGHTS", str(tmp_path / "resnet50-11ad3fa6.pth"))   # an explicit file always wins
+    assert find_imagenet_weights("resnet50").endswith("resnet50-11ad3fa6.pth")
+    (tmp_path / "hub" / "checkpoints").mkdir(parents=True)
+    (tmp_path / "hub" / "checkpoints" / "resnet18-f37072fd.pth").write_bytes(b"v1")
+    monkeypatch.delenv("VPD_PRETRAINED_WEIGHTS")
+    assert find_imagenet_weights("resnet18").endswith("resnet18-f37072fd.pth")

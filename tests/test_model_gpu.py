@@ -795,6 +795,15 @@ def test_pretrained_backbone_from_a_local_checkpoint(tmp_path, monkeypatch):
     assert (np.linalg.norm(got - want, axis=1) / np.linalg.norm(want, axis=1)).max() <= 2e-2
     enc3 = RGBF_EmbeddingModel("resnet18", 32, False, "cuda", pretrained=True)      # 3 channels: the stem as it is
     assert torch.equal(enc3.state_dict()["resnet.conv1.weight"].cpu(), tv["conv1.weight"])
+    # torchvision's ImageNet-V1 files were saved before BatchNorm had num_batches_tracked: they load like nn.BatchNorm loads them
+    legacy = {k: v for k, v in tv.items() if not k.endswith("num_batches_tracked")}
+    assert len(legacy) < len(tv)
+    torch.save(legacy, str(tmp_path / "resnet18-deadbeef.pth"))
+    enc4 = RGBF_EmbeddingModel("resnet18", 32, True, "cuda", pretrained=True)
+    sd4 = enc4.state_dict()
+    assert torch.equal(sd4["resnet.layer2.0.bn1.running_var"].cpu(), tv["layer2.0.bn1.running_var"])
+    assert int(sd4["resnet.bn1.num_batches_tracked"]) == 0
+    assert np.array_equal(enc4.embed(x)[:, :4].shape, (3, 4))
 
 
 def test_ragged_batches_and_graph():

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyParams p) {
             for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
         }
         const size_t oo = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * p.C + c;
-        *reinterpret_cast<uint4*>(p.out + oo) = pack8(v);
+        vpd_store16<VPD_CP_BNF>(p.out + oo, pack8(v));
     }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const StemPoolParams p) 
             }
         }
         const size_t oo = ((size_t)(b * (Ho + 2 * p.opad) + oy + p.opad) * (Wo + 2 * p.opad) + ox + p.opad) * p.C + c;
-        *reinterpret_cast<uint4*>(p.out + oo) = pack8(best);
+        vpd_store16<VPD_CP_STEM>(p.out + oo, pack8(best));
         if (p.idx) {
             uint2 iv;
             iv.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void stem_pool_pair_kernel(const StemPoolParam
             uint4 ov;
             ov.x = (key[0] >> 16) | (key[1] & 0xffff0000u); ov.y = (key[2] >> 16) | (key[3] & 0xffff0000u);
             ov.z = (key[4] >> 16) | (key[5] & 0xffff0000u); ov.w = (key[6] >> 16) | (key[7] & 0xffff0000u);
-            *reinterpret_cast<uint4*>(p.out + oo) = ov;
+            vpd_store16<VPD_CP_STEM>(p.out + oo, ov);
             if (p.idx) {
                 unsigned bi[8];
 #pragma unroll
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = c1[j] * (g[j] - c2[j] - (z[j] - mu[j]) * rs[j] * c3[j]);
         const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * p.C + c;
-        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+        vpd_store16<VPD_CP_BNB>(p.dz + oo, pack8(o));
     }
 }
 
@@ -626,12 +626,14 @@ __global__ __launch_bounds__(256) void stem_pool_bwd_quad_kernel(const StemPoolB
                             const unsigned sel = (word >> (8 * (j & 3))) & 0xffu;
                             g += sel == want ? d[wy][wx][j] : 0.f;
                         }
-                    const float a = z[j] * sc[j] + shf[j];
+                    // (explicit fma nesting, as in bn_bwd_apply_fused_kernel: left to the compiler the contraction of these lines -- and
+                    //  with it the stem's dz in the last bit -- changed when the STORE below became a non-temporal one)
+                    const float a = __builtin_fmaf(z[j], sc[j], shf[j]);
                     g = a > 0.f ? g : 0.f;
                     const float xh = (z[j] - mu[j]) * rs[j];
-                    o[j] = c1[j] * (g - c2[j] - xh * c3[j]);
+                    o[j] = c1[j] * __builtin_fmaf(-xh, c3[j], g - c2[j]);
                 }
-                *reinterpret_cast<uint4*>(p.dz + ((size_t)(b * p.Hz + 2 * ky + dy) * p.Wz + 2 * kx + dx) * p.C + c) = pack8(o);
+                vpd_store16<VPD_CP_STEM>(p.dz + ((size_t)(b * p.Hz + 2 * ky + dy) * p.Wz + 2 * kx + dx) * p.C + c, pack8(o));
             }
     }
 }
@@ -745,6 +747,10 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
 // ===========================================================================
 #include "sync.h"
 
+#ifdef VPD_CALIB
+__global__ void vpd_calib_empty_kernel(float* p) { if (p == nullptr) __builtin_trap(); }
+#endif
+
 struct BnFusedFwdArgs {
     double* rows; float count;                 // this BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][C]
     const float* gamma; const float* beta; float* rm; float* rv;
@@ -791,9 +797,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
             y = r / p.W;
             x = r - y * p.W;
         }
-        zv = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + cc);
-        if (p.res_kind == 1) rv = *reinterpret_cast<const uint4*>(p.res + ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * C + cc);
-        else if (p.res_kind == 2) rv = *reinterpret_cast<const uint4*>(p.res + (size_t)m * C + cc);
+        zv = vpd_load16<VPD_CL_BN>(p.z + (size_t)m * C + cc);
+        if (p.res_kind == 1) rv = vpd_load16<VPD_CL_BN>(p.res + ((size_t)(b * p.rHp + y + p.rpad) * p.rWp + x + p.rpad) * C + cc);
+        else if (p.res_kind == 2) rv = vpd_load16<VPD_CL_BN>(p.res + (size_t)m * C + cc);
         o = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + cc;
     };
     long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -864,7 +870,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
             for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
         }
         const uint4 ov = pack8(v);
-        *reinterpret_cast<uint4*>(p.out + oo) = ov;
+        if (C > 64) vpd_store16<VPD_CP_BNF>(p.out + oo, ov); else vpd_store16<VPD_CP_BNF64>(p.out + oo, ov);
         if (p.mask_out) {      // bit j = the STORED bf16 value is > 0 (values are >= 0 after the ReLU: non-zero bits)
             const unsigned w[4] = {ov.x, ov.y, ov.z, ov.w};
             unsigned bits = 0;
@@ -907,6 +913,10 @@ hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f0,
     if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)4 * p.C * sizeof(float), s, p, f);
+#ifdef VPD_CALIB      // tools/build_variant_lib.sh calib -DVPD_CALIB: what ONE more launch costs inside the real step (profiles/r05_floor_probe.txt)
+    static const int n_extra = getenv("VPD_CALIB_EMPTY") ? atoi(getenv("VPD_CALIB_EMPTY")) : 0;
+    for (int i = 0; i < n_extra; ++i) hipLaunchKernelGGL(vpd_calib_empty_kernel, dim3(256), dim3(256), 0, s, f.mean);
+#endif
     return hipGetLastError();
 }
 
@@ -1067,7 +1077,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = c1[j] * (g[j] - c2[j] - (z[j] - mu[j]) * rs[j] * c3[j]);
         const size_t oo = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + c;
-        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+        vpd_store16<VPD_CP_BNB>(p.dz + oo, pack8(o));
     }
 #undef LD8
 }
@@ -1132,9 +1142,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
             y = r / p.W;
             x = r - y * p.W;
         }
-        gv = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * C + cc);
-        zv = *reinterpret_cast<const uint4*>(p.z + (size_t)m * C + cc);
-        if (PAIR) z2v = *reinterpret_cast<const uint4*>(f.z2 + (size_t)m * C + cc);
+        gv = vpd_load16<VPD_CL_BN>(p.dy + (size_t)m * C + cc);
+        zv = vpd_load16<VPD_CL_BN>(p.z + (size_t)m * C + cc);
+        if (PAIR) z2v = vpd_load16<VPD_CL_BN>(f.z2 + (size_t)m * C + cc);
         bits = p.mask_bits[i];                                     // i = m * (C / 8) + c / 8
         o = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + cc;
     };
@@ -1179,7 +1189,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(sA[c + j], g[j], __builtin_fmaf(sB[c + j], z[j], sD[c + j]));
         }
-        *reinterpret_cast<uint4*>(p.dz + oo) = pack8(o);
+        if (C > 64) vpd_store16<VPD_CP_BNB>(p.dz + oo, pack8(o)); else vpd_store16<VPD_CP_BNB64>(p.dz + oo, pack8(o));
         if (PAIR) {      // same g, the branch's own z and coefficients, same padded geometry
             unpack8(z2c, z);
             if (fast) {
@@ -1190,7 +1200,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
                 for (int j = 0; j < 8; ++j)
                     o[j] = __builtin_fmaf(sA[3 * C + c + j], g[j], __builtin_fmaf(sB[3 * C + c + j], z[j], sD[3 * C + c + j]));
             }
-            *reinterpret_cast<uint4*>(f.dz2 + oo) = pack8(o);
+            vpd_store16<VPD_CP_BNB>(f.dz2 + oo, pack8(o));
         }
         it = nx; have = hn; gc = gn; zc = zn; z2c = z2n; bc = bn_; oo = on; c = cn;
     }

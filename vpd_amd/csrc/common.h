@@ -231,6 +231,56 @@ static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, in
     return (nchunks + cpb - 1) / cpb;
 }
 
+// ---------------------------------------------------------------------------
+// Cache policy of the step's big streams (round 5; profiles/r05_cache_policy_ab.txt).  Purely a hint: every flavour stores /
+// loads the same bytes, so all variants are bit-identical.  Store flavours: 0 plain (write-back: the line stays in the writing
+// XCD's L2 until the kernel-end release), 1 `sc1` (write-through, line dropped), 2 `sc0 sc1`, 3 `nt` (kept, marked streaming).
+// Load flavours: 0 plain, 3 `nt`.  The consumers of these tensors are chip-wide (the next launch maps blocks to pixels
+// differently), so a plain store's L2 line is dead weight that evicts halos and weights other kernels DO re-read.
+// Per-site macros (override with -DVPD_CP_xxx=n through tools/build_variant_lib.sh for an A/B):
+//   VPD_CP_EPI  conv epilogue outputs      VPD_CP_BNF  BatchNorm-forward outputs      VPD_CP_BNB  BatchNorm-backward dz
+//   VPD_CP_STEM stem pooling outputs       VPD_CL_BN   BatchNorm kernels' once-read operand loads
+// ---------------------------------------------------------------------------
+#ifndef VPD_CP_ALL
+#define VPD_CP_ALL 1
+#endif
+#ifndef VPD_CP_EPI
+#define VPD_CP_EPI VPD_CP_ALL
+#endif
+#ifndef VPD_CP_BNF
+#define VPD_CP_BNF VPD_CP_ALL
+#endif
+#ifndef VPD_CP_BNB
+#define VPD_CP_BNB VPD_CP_ALL
+#endif
+#ifndef VPD_CP_BNF64          // the same two for 64-channel tensors (layer1): their consumer, the resident-weights 3x3 kernel, walks
+#define VPD_CP_BNF64 3               // consecutive tiles and DOES find a third of its halo rows in its own XCD's L2
+#endif
+#ifndef VPD_CP_BNB64
+#define VPD_CP_BNB64 3
+#endif
+#ifndef VPD_CP_STEM
+#define VPD_CP_STEM 3
+#endif
+#ifndef VPD_CL_BN
+#define VPD_CL_BN 3
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned int vpd_u32x4_cp;
+template <int CP> static __device__ __forceinline__ void vpd_store16(void* p, const uint4& v) {
+    if (CP == 0) { *reinterpret_cast<uint4*>(p) = v; return; }
+    const vpd_u32x4_cp w = {v.x, v.y, v.z, v.w};
+    // (s_nop 1: a store of more than 8 bytes followed by a vector-ALU write of its data registers needs wait states that hipcc's
+    //  hazard recognizer inserts for its own instructions but not behind inline assembly -- without it the stored bits are wrong)
+    if (CP == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+    if (CP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
+    if (CP == 3) __builtin_nontemporal_store(w, reinterpret_cast<vpd_u32x4_cp*>(p));
+}
+template <int CP> static __device__ __forceinline__ uint4 vpd_load16(const void* p) {
+    if (CP == 0) return *reinterpret_cast<const uint4*>(p);
+    const vpd_u32x4_cp w = __builtin_nontemporal_load(reinterpret_cast<const vpd_u32x4_cp*>(p));
+    return uint4{w.x, w.y, w.z, w.w};
+}
+
 // One weight-gradient launch: dw[tap][co][kc] += sum_m dz[m][co] * x[gather(m,tap)][kc]
 struct WgradParams {
     const bf16_t* dz; int dzHp, dzWp, dzC, dzpad;

@@ -95,7 +95,7 @@ static __device__ __forceinline__ void frag_row_store(bf16_t* base, uint2 (&v)[N
 #pragma unroll
     for (int a = 0; a + 1 < NI; a += 2) {
         frag_pair_swap(v[a], v[a + 1]);
-        if (valid) *reinterpret_cast<uint4*>(base + frag_pair_chan(a, fq)) = uint4{v[a].x, v[a].y, v[a + 1].x, v[a + 1].y};
+        if (valid) vpd_store16<VPD_CP_EPI>(base + frag_pair_chan(a, fq), uint4{v[a].x, v[a].y, v[a + 1].x, v[a + 1].y});
     }
     if constexpr ((NI & 1) != 0) {
         if (valid) *reinterpret_cast<uint2*>(base + (NI - 1) * 16 + 4 * fq) = v[NI - 1];
@@ -405,7 +405,7 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
             // the pair leaves 16 bytes wide (64 contiguous bytes per pixel and instruction); a trailing odd group 8 bytes wide
             if (pair) {
                 frag_pair_swap(ovs[0], ovs[1]);
-                if (valid) *reinterpret_cast<uint4*>(dpix + frag_pair_chan(a0, fq)) = uint4{ovs[0].x, ovs[0].y, ovs[1].x, ovs[1].y};
+                if (valid) vpd_store16<VPD_CP_EPI>(dpix + frag_pair_chan(a0, fq), uint4{ovs[0].x, ovs[0].y, ovs[1].x, ovs[1].y});
             } else if (valid) {
                 *reinterpret_cast<uint2*>(dpix + a0 * 16 + 4 * fq) = ovs[0];
             }

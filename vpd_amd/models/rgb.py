@@ -11,20 +11,40 @@ from ..engine import StudentEngine
 from .module import ENCODER_ARCH, attach_views
 
 
+# The ImageNet-V1 files `pretrained=True` downloads (torchvision's model_urls; models/rgb.py:57-58 reaches them through
+# ENCODER_ARCH[...].pretrained_init): preferred when a directory holds several checkpoints of one architecture.
+IMAGENET_V1_FILES = {
+    "resnet18": "resnet18-f37072fd.pth", "resnet34": "resnet34-b627a593.pth", "resnet50": "resnet50-0676ba61.pth",
+    "resnet101": "resnet101-63fe2227.pth", "resnet152": "resnet152-394f9c45.pth",
+    "wide_resnet50_2": "wide_resnet50_2-95faca4d.pth", "wide_resnet101_2": "wide_resnet101_2-32ee1156.pth",
+}
+
+
 def find_imagenet_weights(model_arch):
     """The checkpoint torchvision would download for `model_arch`: $VPD_PRETRAINED_WEIGHTS (a file, or a directory holding
-    <arch>*.pth), else torch hub's cache (~/.cache/torch/hub/checkpoints/<arch>-<hash>.pth).  There is no download here."""
+    <arch>*.pth), else torch hub's cache (~/.cache/torch/hub/checkpoints/<arch>-<hash>.pth).  There is no download here.
+    With several candidates in one place the ImageNet-V1 file (what the reference's pretrained=True means) is taken; if
+    none of them is that file the choice would be a guess, so it is an error."""
     import glob
     import os
-    cand = []
     env = os.environ.get("VPD_PRETRAINED_WEIGHTS")
-    if env:
-        cand += [env] if os.path.isfile(env) else sorted(glob.glob(os.path.join(env, model_arch + "*.pth")))
-    cand += sorted(glob.glob(os.path.join(torch.hub.get_dir(), "checkpoints", model_arch + "-*.pth")))
-    if not cand:
-        raise FileNotFoundError("--pretrained: no ImageNet state_dict for %s; set VPD_PRETRAINED_WEIGHTS to the torchvision "
-                                "checkpoint (or to a directory holding %s*.pth)" % (model_arch, model_arch))
-    return cand[0]
+    if env and os.path.isfile(env):
+        return env
+    places = ([env] if env else []) + [os.path.join(torch.hub.get_dir(), "checkpoints")]
+    for place in places:
+        cand = sorted(glob.glob(os.path.join(place, model_arch + "-*.pth")) + glob.glob(os.path.join(place, model_arch + ".pth")))
+        if not cand:
+            continue
+        v1 = [c for c in cand if os.path.basename(c) == IMAGENET_V1_FILES.get(model_arch)]
+        if len(cand) > 1 and not v1:
+            raise FileNotFoundError("--pretrained: %d checkpoints for %s in %s and none is the ImageNet-V1 file %s; point "
+                                    "VPD_PRETRAINED_WEIGHTS at the file to use" % (len(cand), model_arch, place,
+                                                                                   IMAGENET_V1_FILES.get(model_arch)))
+        path = (v1 or cand)[0]
+        print("--pretrained: ImageNet weights from", path)
+        return path
+    raise FileNotFoundError("--pretrained: no ImageNet state_dict for %s; set VPD_PRETRAINED_WEIGHTS to the torchvision "
+                            "checkpoint (or to a directory holding %s-*.pth)" % (model_arch, model_arch))
 
 
 class RGBF_EmbeddingModel(nn.Module):
@@ -67,14 +87,15 @@ class RGBF_EmbeddingModel(nn.Module):
             mod.register_buffer("num_batches_tracked", eng.num_batches_tracked[i])
         self.reset_parameters()
         if weights is not None:
-            self.load_imagenet_backbone(torch.load(weights, map_location="cpu"))
+            self.load_imagenet_backbone(torch.load(weights, map_location="cpu", weights_only=True))
 
     def load_imagenet_backbone(self, sd):
         """What `pretrained=True` does in the reference (models/rgb.py:57-61), from a torchvision-format state_dict
         (`conv1.weight`, `layer1.0.bn1.running_mean`, ..., `fc.weight [1000, F]`): every backbone tensor is taken as it
         is, the 3-channel stem becomes its channel mean expanded to the input channels when they are not 3
         (add_flow_to_model, :19-23), and the 1000-way fc is dropped -- the embedding layer keeps its fresh nn.Linear
-        initialisation (replace_last_layer, :40-43)."""
+        initialisation (replace_last_layer, :40-43).  Checkpoints without `num_batches_tracked` (saved before torch 0.4.1,
+        as the V1 files are) load like they do in nn.BatchNorm: the counters keep their value."""
         own = super().state_dict()
         new = {}
         for k, v in sd.items():
@@ -88,6 +109,11 @@ class RGBF_EmbeddingModel(nn.Module):
             if tuple(v.shape) != tuple(own[key].shape):
                 raise ValueError("shape of %s: %s, expected %s" % (k, tuple(v.shape), tuple(own[key].shape)))
             new[key] = v
+        # torchvision's ImageNet-V1 files predate BatchNorm's num_batches_tracked buffer; nn.BatchNorm's own loader
+        # tolerates its absence (the counter keeps its value), and so does this one
+        for k in own:
+            if k.endswith(".num_batches_tracked") and k not in new:
+                new[k] = own[k]
         missing = [k for k in own if k not in new and not k.startswith("resnet.fc.")]
         if missing:
             raise KeyError("the ImageNet state_dict lacks " + ", ".join(missing[:4]))
