@@ -232,17 +232,16 @@ static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, in
 }
 
 // ---------------------------------------------------------------------------
-// Cache policy of the step's big streams (round 5; profiles/r05_cache_policy_ab.txt).  Purely a hint: every flavour stores /
-// loads the same bytes, so all variants are bit-identical.  Store flavours: 0 plain (write-back: the line stays in the writing
-// XCD's L2 until the kernel-end release), 1 `sc1` (write-through, line dropped), 2 `sc0 sc1`, 3 `nt` (kept, marked streaming).
-// Load flavours: 0 plain, 3 `nt`.  The consumers of these tensors are chip-wide (the next launch maps blocks to pixels
-// differently), so a plain store's L2 line is dead weight that evicts halos and weights other kernels DO re-read.
-// Per-site macros (override with -DVPD_CP_xxx=n through tools/build_variant_lib.sh for an A/B):
-//   VPD_CP_EPI  conv epilogue outputs      VPD_CP_BNF  BatchNorm-forward outputs      VPD_CP_BNB  BatchNorm-backward dz
-//   VPD_CP_STEM stem pooling outputs       VPD_CL_BN   BatchNorm kernels' once-read operand loads
+// Cache policy of the step's big streams (round 5; profiles/r05_floor_probe.txt).  Purely a hint: every flavour stores / loads the
+// same bytes.  Store flavours: 0 plain, 1 `sc1` (write-through, line dropped from the XCD's L2), 2 `sc0 sc1`, 3 `nt`; load
+// flavours 0 plain, 3 `nt`.  MEASURED NEUTRAL (sc1 epilogue / BatchNorm stores + nt layer1 stores + nt BatchNorm loads: +0.6 % on a
+// box where round 4's library runs 75.9 k crops/s, -0.1 % on one where it runs 73.3 k; all-nt: -0.3 ... -1 %), so every site
+// defaults to plain; the per-site macros stay as the A/B hook (-DVPD_CP_xxx=n through tools/build_variant_lib.sh):
+//   VPD_CP_EPI  conv epilogue outputs      VPD_CP_BNF / _BNF64  BatchNorm-forward outputs (C > 64 / C = 64)
+//   VPD_CP_BNB / _BNB64  BatchNorm-backward dz      VPD_CP_STEM stem pooling outputs      VPD_CL_BN  BatchNorm operand loads
 // ---------------------------------------------------------------------------
 #ifndef VPD_CP_ALL
-#define VPD_CP_ALL 1
+#define VPD_CP_ALL 0
 #endif
 #ifndef VPD_CP_EPI
 #define VPD_CP_EPI VPD_CP_ALL
@@ -253,24 +252,25 @@ static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, in
 #ifndef VPD_CP_BNB
 #define VPD_CP_BNB VPD_CP_ALL
 #endif
-#ifndef VPD_CP_BNF64          // the same two for 64-channel tensors (layer1): their consumer, the resident-weights 3x3 kernel, walks
-#define VPD_CP_BNF64 3               // consecutive tiles and DOES find a third of its halo rows in its own XCD's L2
+#ifndef VPD_CP_BNF64
+#define VPD_CP_BNF64 VPD_CP_BNF
 #endif
 #ifndef VPD_CP_BNB64
-#define VPD_CP_BNB64 3
+#define VPD_CP_BNB64 VPD_CP_BNB
 #endif
 #ifndef VPD_CP_STEM
-#define VPD_CP_STEM 3
+#define VPD_CP_STEM VPD_CP_ALL
 #endif
 #ifndef VPD_CL_BN
-#define VPD_CL_BN 3
+#define VPD_CL_BN 0
 #endif
 typedef __attribute__((ext_vector_type(4))) unsigned int vpd_u32x4_cp;
 template <int CP> static __device__ __forceinline__ void vpd_store16(void* p, const uint4& v) {
     if (CP == 0) { *reinterpret_cast<uint4*>(p) = v; return; }
     const vpd_u32x4_cp w = {v.x, v.y, v.z, v.w};
     // (s_nop 1: a store of more than 8 bytes followed by a vector-ALU write of its data registers needs wait states that hipcc's
-    //  hazard recognizer inserts for its own instructions but not behind inline assembly -- without it the stored bits are wrong)
+    //  hazard recognizer inserts for its own instructions but not behind inline assembly -- without it the stored bits are wrong,
+    //  and a step with wrong bits ran 5 % FASTER on power-limited boxes, which first read as a win of the write-through stores)
     if (CP == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
     if (CP == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");
     if (CP == 3) __builtin_nontemporal_store(w, reinterpret_cast<vpd_u32x4_cp*>(p));
