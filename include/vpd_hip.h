@@ -185,9 +185,7 @@ int vpd_plan_sync_errors(vpd_plan_t* plan, void* workspace, void* stream, unsign
  * 1 conv3x3_ws_kernel<256,128,352>, 2 conv3x3_ws_kernel<128,128,288>, 3 conv3x3_ws_kernel<128,64,288>,
  * 4 conv_igemm_kernel (gather), 5 conv_wgrad_halo_grouped_kernel (stride-1 3x3, per stage, without its slab reduce),
  * 6 per-conv weight-gradient launches (stride-2 3x3 on conv_wgrad_halo_kernel, 1x1 on conv_wgrad_kernel),
- * 7 conv_stem_persistent_kernel, 8 conv3x3_pws_xf_kernel (a BasicBlock's second 3x3 with bn1 + ReLU applied by its loader
- * waves; counted under its plain twin's class when nclasses == 8).  vpd_plan_read_timing (nclasses >= 8) waits for the
- * events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
+ * 7 conv_stem_persistent_kernel.  vpd_plan_read_timing (nclasses >= 8) waits for the events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
 int vpd_plan_set_timing(vpd_plan_t* plan, int enable);
 int vpd_plan_read_timing(vpd_plan_t* plan, double* out, int nclasses);
 
@@ -208,16 +206,6 @@ int vpd_op_conv_bm(int M, int Co);
 int vpd_op_conv2d_bnsums(const void* x_bf16, const void* w_bf16, void* y_bf16, const void* bst_z_bf16,
                          const unsigned char* bst_mask, double* rows, int n, int xHp, int xWp, int xC, int Hs, int Ws,
                          int Kc, int Co, const int* tapset9, int accumulate, void* stream);
-/* conv2(relu(bn1(z))) of a torchvision BasicBlock in training mode as ONE launch (conv3x3_pws_xf_kernel: the convolution's
- * loader waves finalize bn1 from rows_in, apply scale z + shift and the ReLU on the way into LDS, and write the activation
- * (bf16 NHWC padded by 1, border pre-zeroed) and its ReLU bit map [n H W][Kc/8] out for backward; reference:
- * BasicBlock.forward conv1 -> bn1 -> relu -> conv2 under model.train()).  z dense bf16 [n][H][W][Kc]; w bf16 [9][Co][Kc];
- * y dense bf16 [n][H][W][Co]; rows_out f64 [4][2][Co] (pre-zeroed) receive sum y / sum y^2.  Fails when the shape is not
- * one the transforming loaders take (whole padded images per pixel tile). */
-int vpd_op_conv2d_bn_in(const void* z_bf16, const double* rows_in, const float* gamma, const float* beta, float* running_mean,
-                        float* running_var, float* mean, float* rstd, float* scale, float* shift, void* act_out_padded_bf16,
-                        unsigned char* mask_bits, const void* w_bf16, void* y_bf16, double* rows_out, int n, int H, int W,
-                        int Kc, int Co, float momentum, float eps, void* stream);
 /* BatchNorm2d in training mode as the plan runs it (one launch: finalize + apply; models/module.py:41-43 + nn.BatchNorm2d):
  * rows f64 [4][2][C] hold the per-channel sum / sum of squares of z as the producing convolution's epilogue left them;
  * writes mean, rstd, scale = gamma rstd, shift = beta - mean scale, updates running_mean / running_var (momentum, unbiased
@@ -240,11 +228,6 @@ int vpd_op_wgrad(const void* dz_bf16, const void* x_bf16, float* dw, int n, int 
                  int xHp, int xWp, int xC, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
                  float* slab, void* stream);
 size_t vpd_op_wgrad_slab_bytes(void);
-/* The weight gradients of a down-sampling BasicBlock's first conv (3x3, stride 2, pad 1) and of its 1x1 stride-2 branch in ONE
- * launch (models/module.py:88-110: both read the block input x): dz / dz2 padded bf16 [n][Ho+2][Wo+2][Co], x padded bf16
- * [n][2Ho+2][2Wo+2][Ci], dw fp32 [9][Co][Ci], dw2 fp32 [Co][Ci], slab / slab2: vpd_op_wgrad_slab_bytes() each. */
-int vpd_op_wgrad_pair(const void* dz_bf16, const void* dz2_bf16, const void* x_bf16, float* dw, float* dw2, int n, int Ho, int Wo,
-                      int Ci, int Co, float* slab, float* slab2, void* stream);
 /* dumps the ds_read_b64_tr_b16 fragments of one [128][64] bf16 tile: out [4][4][64][8] bf16 */
 int vpd_op_tr_read_probe(const void* tile_bf16, void* out_bf16, void* stream);
 /* Grouped weight gradients of `nprob` 3x3 pad-1 / 1x1 pad-0 convolutions (stride 1 or 2) on 128-channel-wide tiles in ONE persistent launch (the

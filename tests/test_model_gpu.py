@@ -315,30 +315,6 @@ print("LOSS", loss.item())
 """
 
 
-def test_dgrad_with_batchnorm_backward_in_its_epilogue(tmp_path):
-    """VPD_DGRAD_BN=1: the data-gradient launches of layers 3 / 4 carry the BatchNorm backward of their output in the
-    epilogue behind the in-launch grid barrier (ConvBnBwd; needs the full 256-crop batch: one block per CU).  Same
-    rounding points and formulas as the separate bn_bwd_fused_kernel, so the gradients of a whole ResNet-34 step must
-    agree with the default path to the level of summation order in the fp32 block sums (measured ~1e-6)."""
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("0", "1"):
-        out = str(tmp_path / ("g%s.npy" % flag))
-        env = dict(os.environ, VPD_DGRAD_BN=flag)
-        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
-    (g0, l0), (g1, l1) = outs
-    assert l0 == l1
-    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
-    # the untrained network amplifies last-bit differences (DESIGN.md, "Run-to-run reproducibility"): a direction + norm gate
-    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
-    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
-
-
 def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
     """Default path: the stride-1 3x3 data gradients of layers 2-4 add sum g and sum g*z of the BatchNorm that consumes
     their output to its rows (conv_epilogue.h, EPM 6 / 7) and the BatchNorm launch only finalizes and applies
@@ -352,53 +328,6 @@ def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
         out = str(tmp_path / ("g%s.npy" % flag))
         env = dict(os.environ, VPD_DGRAD_SUMS=flag)
         r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
-    (g0, l0), (g1, l1) = outs
-    assert l0 == l1
-    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
-    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
-    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
-
-
-def test_fused_head_matches_the_separate_launches(tmp_path):
-    """VPD_FUSED_HEAD=1 (off by default: measured slower): pool + fc + loss in one launch, d(pooled) + dW + db in one launch
-    (head.hip, head_*_fused_kernel) instead of avgpool / sgemm / mse / colsum / avgpool_bwd.  fp32
-    arithmetic on both sides, different summation order: the loss agrees to 1e-6, the gradients as in the tests above."""
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("0", "1"):
-        out = str(tmp_path / ("g%s.npy" % flag))
-        env = dict(os.environ, VPD_FUSED_HEAD=flag)
-        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
-                           text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-        outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
-    (g0, l0), (g1, l1) = outs
-    assert abs(l1 / l0 - 1) < 1e-6, (l0, l1)
-    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
-    cos = float(np.dot(g0.astype(np.float64), g1.astype(np.float64)) / (np.linalg.norm(g0) * np.linalg.norm(g1)))
-    assert cos > 0.999 and abs(np.linalg.norm(g1) / np.linalg.norm(g0) - 1) < 1e-2, (cos, rel_l2(g1, g0))
-
-
-_STEP_SCRIPT_R50 = _STEP_SCRIPT.replace('"resnet34"', '"resnet50"').replace("(256, 5, 128, 128)", "(32, 5, 128, 128)") \
-    .replace("(256, 32)", "(32, 32)")
-
-
-def test_batchnorm_backward_sums_on_a_bottleneck_student(tmp_path):
-    """VPD_DGRAD_SUMS_BNECK=1 (off by default: measured neutral on ResNet-50): bn2 / bn3 sums in the 1x1 data gradients on
-    the gather kernel (epilogue modes 6 / 7), bn1's in conv2's (stride 1 halo kernel or the merged stride-2 launch)."""
-    import subprocess
-    import sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("0", "1"):
-        out = str(tmp_path / ("g%s.npy" % flag))
-        env = dict(os.environ, VPD_DGRAD_SUMS_BNECK=flag)
-        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT_R50.format(repo=repo, out=out)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))

@@ -425,108 +425,3 @@ def test_conv_epilogue_batchnorm_sums(case, accumulate):
     want1, want2 = gm.sum(0), (gm * z.double()).sum(0)
     assert float((s[0] - want1).abs().max()) <= 2e-5 * float(gm.abs().sum(0).max())
     assert float((s[1] - want2).abs().max()) <= 2e-5 * float((gm * z.double()).abs().sum(0).max())
-
-
-PAIR_CASES = [("l2_32to16", 2, 64, 128, 16), ("l3_16to8", 3, 128, 256, 8), ("l4_8to4_ragged", 5, 256, 512, 4)]
-
-
-@pytest.mark.parametrize("case", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
-def test_wgrad_pair_downsampling_block(case):
-    """The 1x1 stride-2 branch's weight gradient as a tenth tap of its 3x3 stride-2 sibling's launch (round 4; in the plan behind
-    VPD_WG_PAIR=1, measured slower than the two launches): both against torch's conv2d gradients in fp32 on the same bf16 operands."""
-    name, n, ci, co, ho = case
-    L = _lib()
-    g = torch.Generator().manual_seed(len(name) + n)
-    x = bf16_round(torch.randn(n, ci, 2 * ho, 2 * ho, generator=g))
-    dz = bf16_round(torch.randn(n, co, ho, ho, generator=g))
-    dz2 = bf16_round(torch.randn(n, co, ho, ho, generator=g))
-    w3 = torch.zeros(co, ci, 3, 3, requires_grad=True)
-    w1 = torch.zeros(co, ci, 1, 1, requires_grad=True)
-    (F.conv2d(x, w3, None, stride=2, padding=1) * dz).sum().backward()
-    (F.conv2d(x, w1, None, stride=2, padding=0) * dz2).sum().backward()
-    xp, dzp, dz2p = to_padded_nhwc(x, 1, 1, 1, 1, slack=4096), to_padded_nhwc(dz, 1, 1, 1, 1), to_padded_nhwc(dz2, 1, 1, 1, 1)
-    dw = torch.full((9 * co * ci,), float("nan"), device="cuda")
-    dw2 = torch.full((co * ci,), float("nan"), device="cuda")
-    nsl = L.vpd_op_wgrad_slab_bytes() // 4
-    slab, slab2 = torch.empty(nsl, device="cuda"), torch.empty(nsl, device="cuda")
-    _check(L.vpd_op_wgrad_pair(ptr(dzp), ptr(dz2p), ptr(xp), ptr(dw), ptr(dw2), n, ho, ho, ci, co, ptr(slab), ptr(slab2), stream()))
-    torch.cuda.synchronize()
-    got3 = dw.view(3, 3, co, ci).permute(2, 3, 0, 1).cpu()
-    got1 = dw2.view(co, ci, 1, 1).cpu()
-    assert rel_l2(got3, w3.grad) < 1e-3 and rel_l2(got1, w1.grad) < 1e-3, (rel_l2(got3, w3.grad), rel_l2(got1, w1.grad))
-
-
-# conv2(relu(bn1(z))) with bn1 applied by conv2's loader waves (conv_xf.hip, round 4).  Shapes: the three stride-1 stages the
-# transforming loaders take, each also with a ragged last pixel tile (images beyond the batch inside the tile), and layer2 with
-# one or two pixel tiles per block (the next tile's slices requested and processed inside the K loop).
-XF_CASES = [("l3_256", 256, 8, 256, 256), ("l3_ragged", 250, 8, 256, 256), ("l2_256", 256, 16, 128, 128),
-            ("l2_uneven", 203, 16, 128, 128), ("l4_256", 256, 4, 512, 512), ("l4_ragged", 77, 4, 512, 512),
-            ("l3_small", 70, 8, 256, 256)]
-
-
-@pytest.mark.parametrize("case", XF_CASES, ids=[c[0] for c in XF_CASES])
-def test_conv_with_batchnorm_applied_by_its_loaders(case):
-    name, n, hw, ci, co = case
-    h = w = hw
-    L = _lib()
-    g = torch.Generator().manual_seed(len(name) * 31 + n)
-    z = bf16_round(torch.randn(n, ci, h, w, generator=g) * 1.7 + 0.3)
-    wt = bf16_round(torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5)
-    gamma, beta = torch.rand(ci, generator=g) + 0.5, torch.randn(ci, generator=g) * 0.2
-    rm0, rv0 = torch.randn(ci, generator=g) * 0.1, torch.rand(ci, generator=g) + 0.5
-    M = n * h * w
-    zd = z.double()
-    parts = torch.rand(4, generator=g).double()
-    parts = parts / parts.sum()
-    s1, s2 = zd.sum(dim=(0, 2, 3)), (zd * zd).sum(dim=(0, 2, 3))
-    rows_in = torch.stack([torch.stack([s1 * f, s2 * f]) for f in parts]).contiguous().cuda()
-    zdev = z.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda()
-    wp = pack_fwd(wt)
-    dev = lambda t: t.clone().float().cuda()
-    gd, bd = dev(gamma), dev(beta)
-
-    def run(fused):
-        act = torch.zeros(n * (h + 2) * (w + 2) * ci, dtype=torch.bfloat16, device="cuda")
-        mask = torch.zeros(M * ci // 8, dtype=torch.uint8, device="cuda")
-        rm, rv = dev(rm0), dev(rv0)
-        coef = [torch.zeros(ci, device="cuda") for _ in range(4)]
-        y = torch.full((M * co,), float("nan"), dtype=torch.bfloat16, device="cuda")
-        rows_out = torch.zeros(4, 2, co, dtype=torch.float64, device="cuda")
-        if fused:
-            _check(L.vpd_op_conv2d_bn_in(ptr(zdev), ptr(rows_in), ptr(gd), ptr(bd), ptr(rm), ptr(rv), *[ptr(t) for t in coef],
-                                         ptr(act), ptr(mask), ptr(wp), ptr(y), ptr(rows_out), n, h, w, ci, co, C.c_float(0.1),
-                                         C.c_float(1e-5), stream()))
-        else:      # the two launches it replaces
-            _check(L.vpd_op_bn_forward(ptr(zdev), ptr(rows_in), ptr(gd), ptr(bd), ptr(rm), ptr(rv), *[ptr(t) for t in coef], None,
-                                       ptr(act), ptr(mask), n, h, w, ci, 1, C.c_float(0.1), C.c_float(1e-5), stream()))
-            rows16 = torch.zeros(16, 2, co, dtype=torch.float64, device="cuda")
-            _check(L.vpd_op_conv2d(ptr(act), ptr(wp), ptr(y), ptr(rows16), n, h + 2, w + 2, ci, h, w, co, 0, h, w, 1, 0, 0, 1, ci, co,
-                                   tapset(3, 3, 0, 1, 0, 1, 0, 3, 1), 0, stream()))
-            rows_out = rows16
-        torch.cuda.synchronize()
-        return act, mask, rm, rv, coef, y, rows_out.sum(dim=0).cpu()
-
-    act, mask, rm, rv, coef, y, sums = run(True)
-    # 1) the launches it replaces, same operands: activation, bit map, statistics and convolution output bit for bit
-    act2, mask2, rm2, rv2, coef2, y2, sums2 = run(False)
-    assert torch.equal(act.view(torch.int16), act2.view(torch.int16))
-    assert torch.equal(mask, mask2)
-    assert torch.equal(rm, rm2) and torch.equal(rv, rv2) and all(torch.equal(a, b) for a, b in zip(coef, coef2))
-    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
-    assert float((sums - sums2).abs().max()) <= 1e-5 * float(sums2.abs().max())
-    # 2) torch in float64 on the same bf16 operands
-    rm_ref, rv_ref = rm0.double().clone(), rv0.double().clone()
-    a_ref = F.batch_norm(zd, rm_ref, rv_ref, gamma.double(), beta.double(), training=True, momentum=0.1, eps=1e-5).clamp_min(0)
-    got_a = from_nhwc(act, n, h + 2, w + 2, ci, 1).double()
-    assert rel_l2(got_a, a_ref) < 3e-3
-    assert torch.allclose(rm.cpu().double(), rm_ref, rtol=1e-5, atol=1e-6) and torch.allclose(rv.cpu().double(), rv_ref, rtol=1e-5)
-    border = act.view(n, h + 2, w + 2, ci).float()
-    assert float(border[:, 0].abs().max()) == 0.0 and float(border[:, :, 0].abs().max()) == 0.0
-    assert float(border[:, -1].abs().max()) == 0.0 and float(border[:, :, -1].abs().max()) == 0.0
-    y_ref = F.conv2d(got_a.float(), wt, None, padding=1)          # on the activation as stored (bf16)
-    got_y = y.view(n, h, w, co).permute(0, 3, 1, 2).float().cpu()
-    assert torch.isfinite(got_y).all()
-    assert rel_l2(got_y, y_ref) < REL_TOL
-    yd = got_y.double()
-    assert float((sums[0] - yd.sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * float(yd.abs().sum(dim=(0, 2, 3)).max())
-    assert float((sums[1] - (yd * yd).sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * float((yd * yd).sum(dim=(0, 2, 3)).max())

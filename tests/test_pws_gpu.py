@@ -63,7 +63,6 @@ CASES = {
     "c2_128x128_layer4_ragged": (403, 512, 512, 4, 4),     # 128-pixel tiles = 8 images: 50.4 tiles x 4 channel tiles
     "c3_128x64_layer4_small": (37, 512, 512, 4, 4),        # < 200 tiles of 128 x 128: 128 x 64 tiles, 4.6 x 8
     "c3_128x64_one_chunk_pair": (21, 128, 128, 4, 4),      # two 64-channel chunks only: 18 K-steps per tile
-    "c0_256x64_layer1_resident_weights": (21, 64, 64, 32, 32),   # 64 -> 64 channels: RESW variant (VPD_PWS_L1=1), 84 tiles
 }
 
 
@@ -79,7 +78,7 @@ def _run(case, env_extra):
 @pytest.mark.parametrize("case", list(CASES), ids=list(CASES))
 @pytest.mark.parametrize("blocks", ["24", "0"], ids=["few_blocks", "device_blocks"])
 def test_pws_conv_matches_reference_and_old_kernel(case, blocks):
-    new = _run(case, {"VPD_PWS": "1", "VPD_PWS_BLOCKS": blocks, "VPD_PWS_L1": "1"})
+    new = _run(case, {"VPD_PWS": "1", "VPD_PWS_BLOCKS": blocks})
     assert new["fwd"] < 4e-3 and new["dgrad"] < 4e-3 and new["acc"] < 8e-3, new
     assert new["sum"] < 1e-4 and new["sumsq"] < 1e-4, new
     assert new["repeat"], new
@@ -89,28 +88,15 @@ def test_pws_conv_matches_reference_and_old_kernel(case, blocks):
     assert new["y_crc"] == old["y_crc"] and new["dx_crc"] == old["dx_crc"], (new, old)
 
 
-def test_transforming_loaders_with_many_tiles_per_block():
-    """conv3x3_pws_xf_kernel (conv2 of a BasicBlock with bn1 + ReLU applied by its loader waves) with 24 blocks instead of one per CU:
-    a block then walks ~11 pixel tiles (layer3) / ~5 (layer4), so the next tile's slices are requested and transformed inside the K
-    loop again and again, across halo buffers and ring wrap-arounds; the operator test's own gates apply (bit for bit the two launches
-    it replaces, torch in float64).  One child process: VPD_PWS_BLOCKS is read once per process."""
-    env = dict(os.environ, VPD_PWS_BLOCKS="24")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_ops_gpu.py"), "-x", "-q", "-p", "no:cacheprovider",
-                        "-k", "loaders and (l3 or l4)"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "5 passed" in r.stdout, r.stdout[-1000:]
-
-
-def test_train_steps_are_bit_identical_under_the_round4_switches():
-    """VPD_CONV_XF=1 (conv2 of every BasicBlock of layer2-4 applies bn1 + ReLU in its loader waves; off by default since the
-    BatchNorm launches got cheaper than what the XF kernel costs) and VPD_POOLBWD_FOLD=0 (the avgpool_bwd launch instead of the last
-    BatchNorm backward producing d(out) itself) must not change a bit of the train step: losses of three steps at 256 crops and a
-    SHA-256 over all parameters and BatchNorm buffers, one child process per setting (the switches are read once)."""
+def test_train_steps_are_bit_identical_with_the_pool_gradient_folded():
+    """VPD_POOLBWD_FOLD=0 (the avgpool_bwd launch instead of the last BatchNorm backward producing d(out) itself) must not change a
+    bit of the train step: losses of three steps at 256 crops and a SHA-256 over all parameters and BatchNorm buffers, one child
+    process per setting (the switch is read once)."""
     outs = {}
-    for name, extra in (("default", {}), ("xf", {"VPD_CONV_XF": "1"}), ("pool_launch", {"VPD_POOLBWD_FOLD": "0"})):
+    for name, extra in (("default", {}), ("pool_launch", {"VPD_POOLBWD_FOLD": "0"})):
         env = dict(os.environ, **extra)
         r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "step_digest.py"), "--steps", "3"], env=env,
                            capture_output=True, text=True, timeout=900, cwd=REPO)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("losses ")][-1]
-    assert outs["xf"] == outs["default"] and outs["pool_launch"] == outs["default"], outs
+    assert outs["pool_launch"] == outs["default"], outs

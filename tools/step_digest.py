@@ -1,6 +1,6 @@
 """A few train steps of the BASELINE student on a fixed synthetic batch -> losses + a digest of every parameter and BatchNorm
-buffer.  Used to compare two builds / switch settings of the library on the same GPU: `VPD_CONV_XF=0 python tools/step_digest.py`
-against the default must print the same line (the transforming loaders produce the bits of the launch they replace)."""
+buffer.  Used to compare two builds / switch settings of the library on the same GPU: `VPD_LIB_PATH=old.so python tools/step_digest.py`
+against the tree must print the same line when a change claims to compute the same numbers."""
 import argparse
 import hashlib
 import os

@@ -57,12 +57,10 @@ SIGNATURES = {
     "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),
     "vpd_op_conv_bm": (C.c_int, [C.c_int, C.c_int]),
     "vpd_op_conv2d_bnsums": (C.c_int, [vp] * 6 + [C.c_int] * 8 + [c_int_p, C.c_int, vp]),
-    "vpd_op_conv2d_bn_in": (C.c_int, [vp] * 15 + [C.c_int] * 5 + [C.c_float, C.c_float, vp]),
     "vpd_op_bn_forward": (C.c_int, [vp] * 13 + [C.c_int] * 5 + [C.c_float, C.c_float, vp]),
     "vpd_op_bn_backward_apply": (C.c_int, [vp] * 10 + [C.c_int] * 4 + [vp]),
     "vpd_op_wgrad": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp, vp]),
     "vpd_op_wgrad_slab_bytes": (C.c_size_t, []),
-    "vpd_op_wgrad_pair": (C.c_int, [vp] * 5 + [C.c_int] * 5 + [vp, vp, vp]),
     "vpd_op_tr_read_probe": (C.c_int, [vp, vp, vp]),
     "vpd_op_wgrad128_table_bytes": (C.c_size_t, []),
     "vpd_op_wgrad128_slab_floats": (C.c_size_t, [C.c_int, C.c_int]),

@@ -429,8 +429,7 @@ int vpd_bn_bwd_blocks(int M, int C, int* ppb_out) {
     // pixels per block: enough blocks to hide the load latency (the small layers were latency-bound at one block per
     // CU with the earlier 8 iterations / 1024 blocks: +1.5 % end to end), at least four pixel iterations per thread so
     // that the per-block LDS reduce + 2C atomics stay amortised
-    static const int min_iter = getenv("VPD_BN_MINITER") ? atoi(getenv("VPD_BN_MINITER")) : 4;
-    static const int max_blocks = getenv("VPD_BN_MAXBLK") ? atoi(getenv("VPD_BN_MAXBLK")) : 2048;
+    const int min_iter = 4, max_blocks = 2048;
     const int ppi = 256 / (C / 8);
     int ppb = (M + max_blocks - 1) / max_blocks;
     if (ppb < ppi * min_iter) ppb = ppi * min_iter;
@@ -747,10 +746,6 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
 // ===========================================================================
 #include "sync.h"
 
-#ifdef VPD_CALIB
-__global__ void vpd_calib_empty_kernel(float* p) { if (p == nullptr) __builtin_trap(); }
-#endif
-
 struct BnFusedFwdArgs {
     double* rows; float count;                 // this BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][C]
     const float* gamma; const float* beta; float* rm; float* rv;
@@ -913,10 +908,6 @@ hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f0,
     if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)4 * p.C * sizeof(float), s, p, f);
-#ifdef VPD_CALIB      // tools/build_variant_lib.sh calib -DVPD_CALIB: what ONE more launch costs inside the real step (profiles/r05_floor_probe.txt)
-    static const int n_extra = getenv("VPD_CALIB_EMPTY") ? atoi(getenv("VPD_CALIB_EMPTY")) : 0;
-    for (int i = 0; i < n_extra; ++i) hipLaunchKernelGGL(vpd_calib_empty_kernel, dim3(256), dim3(256), 0, s, f.mean);
-#endif
     return hipGetLastError();
 }
 
@@ -1431,13 +1422,6 @@ hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, 
     const int cv = p.C / 8, ppi = 1024 / cv;
     int G = ncu;                                        // one 1024-thread block per CU: the whole grid is resident
     {
-        // small tensors: fewer blocks (fewer barrier arrivals and row atomics) as long as a block keeps >= `min_elems`
-        static const long min_elems = getenv("VPD_BNF_MINELEMS") ? atol(getenv("VPD_BNF_MINELEMS")) : 0;
-        if (min_elems > 0) {
-            long g2 = ((long)p.M * p.C + min_elems - 1) / min_elems;
-            if (g2 < 16) g2 = 16;
-            if (g2 < G) G = (int)g2;
-        }
     }
     int ppb = (p.M + G - 1) / G;
     ppb = ((ppb + ppi - 1) / ppi) * ppi;

@@ -107,26 +107,6 @@ struct ConvClass {
     TapSet taps;
 };
 
-// BatchNorm backward fused into the EPILOGUE of the data-gradient convolution that produces its input gradient
-// (conv3x3_ws_kernel only, grids of at most one block per CU): the accumulators hold d(activation); the epilogue masks
-// it (g), adds the per-channel sums of g and g * xhat to the BatchNorm's accumulator rows, crosses an in-launch grid
-// barrier (sync.h), finalizes its own channels and writes dz = c1 * (g - c2 - xhat * c3) straight into the padded dz
-// buffer -- d(activation) is never stored, and the separate BatchNorm-backward launch (13-24 us) disappears.
-//   mode 1: g = da * [scale * z + shift > 0]           (conv-BN-ReLU: the block's first BatchNorm)
-//   mode 2: da += old (read-modify-write of y, the identity path), g = da * [act > 0], g is written back to y
-//           (the block-output BatchNorm of the PREVIOUS block, whose ReLU follows the residual add)
-struct ConvBnBwd {
-    int mode;
-    const bf16_t* z;                            // dense [M][Co]: forward output of the BatchNorm's convolution
-    const float* mean; const float* rstd; const float* mscale; const float* mshift;
-    const bf16_t* act; int aHp, aWp, apad;      // mode 2: padded post-ReLU activation
-    const float* gamma; float* dgamma; float* dbeta;
-    double* rows;                               // [VPD_FUSED_ROWS][2][Co], zeroed
-    void* sync; unsigned* err;                  // GridSync (zeroed), sticky time-out counter
-    float count;
-    bf16_t* dz; int dzHp, dzWp, dzpad;          // output
-};
-
 // One implicit-GEMM convolution launch (forward conv, or data-gradient conv).
 // Output pixels are enumerated on a sub-grid (Hs x Ws per image); output pixel
 // (y, x) of the sub-grid lands at (y*osub+oph, x*osub+opw) of tensor Y and
@@ -159,7 +139,6 @@ struct ConvParams {
     unsigned* err;                              // -DPWS_STAMPS builds: 16 x u64 s_memtime stamps per block (conv_pws.h); else unused
     int ablate;                                 // diagnostics only (VPD_ABLATE env): 1 skip weight loads, 2 skip MFMAs, 4 skip halo loads
     TapSet taps;
-    ConvBnBwd bnb;                              // conv3x3_ws_kernel only
     // gather kernel only: extra parity classes of a stride-2 data gradient, selected by blockIdx.z (class 0 is
     // described by the fields above); ncls == 0 or 1 means a single class
     int ncls;
@@ -178,7 +157,7 @@ struct ConvParams {
 };
 
 // One channel of a train-mode BatchNorm from its fp64 accumulator rows [VPD_FUSED_ROWS][2][C] (sum z, sum z^2): mean, 1 / std,
-// scale = gamma / std, shift = beta - mean * scale (bn_fwd_fused_kernel; the transforming loaders of conv3x3_pws_xf_kernel)
+// scale = gamma / std, shift = beta - mean * scale (bn_fwd_fused_kernel)
 static __device__ __forceinline__ void bn_finalize_channel(const double* rows, int C, int ch, float count, float eps,
                                                            float gamma, float beta, float* mu_o, float* r_o, float* sc_o,
                                                            float* sh_o, double* var_o) {
@@ -188,9 +167,9 @@ static __device__ __forceinline__ void bn_finalize_channel(const double* rows, i
         s1 += rows[((size_t)t * 2) * C + ch];
         s2 += rows[((size_t)t * 2 + 1) * C + ch];
     }
-    // (one fp64 division per thread, not two per channel plus an fp64 square root: every block of the fused BatchNorm launch and
-    //  every loader wave of conv3x3_pws_xf_kernel runs this in front of its first byte of real work; the cancellation-prone part,
-    //  E[z^2] - mean^2, stays in fp64, 1 / sqrt is v_rsq_f32 -- 1 ulp)
+    // (one fp64 division per thread, not two per channel plus an fp64 square root: every block of the fused BatchNorm launch
+    //  runs this in front of its first byte of real work; the cancellation-prone part, E[z^2] - mean^2, stays in fp64,
+    //  1 / sqrt is v_rsq_f32 -- 1 ulp)
     const double inv = 1.0 / (double)count;
     const double mu = s1 * inv;
     double var = s2 * inv - mu * mu;
@@ -199,24 +178,6 @@ static __device__ __forceinline__ void bn_finalize_channel(const double* rows, i
     const float sc = gamma * r;
     *mu_o = (float)mu; *r_o = r; *sc_o = sc; *sh_o = beta - (float)mu * sc; *var_o = var;
 }
-
-// conv3x3_pws_xf_kernel (train forward, round 4): BatchNorm + ReLU of the PRODUCING convolution applied by this launch's
-// loader waves on the way into LDS -- the launch that used to sit between the two convolutions of a BasicBlock
-// (bn_fwd_fused_kernel: ~5 us of fixed cost around 2-5 us of data movement on layer3 / layer4) is gone.  The loaders read the
-// dense z of the producer instead of the padded activation, finalize the statistics themselves (every block, as the fused
-// BatchNorm launch did), and write the activation and its ReLU bit map out for backward (ConvParams::x is that OUTPUT).
-struct ConvXf {
-    const bf16_t* z;                            // [N*H*W][Kc] dense output of the producing convolution
-    const double* rows;                         // its BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][Kc], complete
-    const float* gamma; const float* beta;
-    float* rm; float* rv;                       // running statistics (block 0 updates them) or null
-    float* mean; float* rstd; float* scale; float* shift;      // stored by block 0 for backward
-    unsigned char* mask;                        // ReLU bit map [N*H*W][Kc/8] or null
-    float count, momentum, eps;
-    float rHp;                                  // 1 / (H + 2), correctly rounded (vpd_fdiv)
-    int ablate;                                 // diagnostics (VPD_XF_ABLATE; results are then wrong): 1 no activation / bit-map stores, 4 no finalize, 8 no prologue priority
-};
-struct PwsNoXf {};
 
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the
 // bucket-level reduce so both agree on the number of slabs without a host->device hand-off.
@@ -298,11 +259,6 @@ struct WgradParams {
     // holds the 3x3 geometry, only tap 4 is accumulated and dw / the slab have ONE slice
     int one_by_one;
     int prefer_halo_1x1;                        // caller's wish for a 1x1 conv: the halo kernel (no atomics) instead of conv_wgrad_kernel
-    // halo kernel, PAIR mode (dz2 != null; round 4): the 1x1 stride-2 down-sampling branch of the same BasicBlock as a TENTH tap of
-    // its 3x3 stride-2 sibling's launch -- same input x (whose halo, the launch's dominant stream, is staged once for both), same
-    // output geometry and channel count, its own dz2 (same padded layout as dz):
-    //   dw2[co][kc] = sum_m dz2[m][co] * x[2 y + 1, 2 x + 1][kc]   (the 3x3's centre tap position), partials in slab2 like slab
-    const bf16_t* dz2; float* dw2; float* slab2;
 };
 
 // ---------------------------------------------------------------------------

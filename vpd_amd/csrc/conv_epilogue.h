@@ -11,10 +11,8 @@
 // EPM: epilogue mode fixed at compile time (dead branches cost registers and issue slots in every conv kernel):
 //   0 plain store, 1 store + per-channel statistics (train forward), 2 accumulate onto y (data gradient on top of
 //   the identity path), 3 eval epilogue (scale/shift, residual, ReLU); -1 decides at run time (legacy kernels).
-//   4 / 5 fused BatchNorm backward (ConvBnBwd mode 1 / 2): conv_epilogue_bnbwd below, conv3x3_ws_kernel only.
 //   6 / 7 = 0 / 2 + the sums of the consuming BatchNorm's backward (ConvParams::bst_z); 8 = 7 + a second BatchNorm (bst_z2).
 static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p) {
-    if (p.bnb.mode) return 3 + p.bnb.mode;
     if (p.bst_z) return p.accumulate ? (p.bst_z2 ? 8 : 7) : 6;
     return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
 }
@@ -516,141 +514,6 @@ static __device__ __forceinline__ void conv_stats_flush(const ConvParams& p, flo
             // rounding of mean / rstd, so the statistics (and with them the whole step) repeat run to run
             const int rmask = (p.stat_rows ? p.stat_rows : VPD_STAT_ROWS) - 1;
             atomicAdd(&rows[((size_t)(row & rmask) * 2 + which) * p.Co + n0 + c], (double)t);
-        }
-    }
-}
-
-
-#include "sync.h"
-
-// Epilogue of a data-gradient convolution with the BatchNorm backward of its output fused in (ConvBnBwd, common.h).
-// Call from the MFMA-layout threads (tid < 64 * WM * WN); contains 4 workgroup barriers (statistics flush, the two of
-// the grid barrier, coefficients) which every other wave of the block has to match.  T2: ConvBnBwd mode 2.
-template <int BM, int BN, int WM, int WN, bool T2>
-static __device__ __forceinline__ void conv_epilogue_bnbwd(const ConvParams& p, f32x4 (&acc)[BN / WN / 16][BM / WM / 16],
-                                                           int mtile, int n0, const ConvGeo& geo, unsigned char* smem) {
-    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
-    const ConvBnBwd& q = p.bnb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int m0 = mtile * BM;
-    const int HW = geo.Hs * geo.Ws;
-    const int C = p.Co;
-    float s1[NI][4], s2[NI][4];
-#pragma unroll
-    for (int a = 0; a < NI; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { s1[a][j] = 0.f; s2[a][j] = 0.f; }
-    uint2 kg[NI][MI], kz[NI][MI];              // masked gradient (bf16 x 4) and z (bf16 x 4) kept across the barrier
-    auto ld4 = [](const float* ptr, float* o) __attribute__((always_inline)) {
-        const float4 v = *reinterpret_cast<const float4*>(ptr);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    };
-    auto up4 = [](const uint2& r, float* o) __attribute__((always_inline)) {
-        o[0] = bf2f((unsigned short)(r.x & 0xffff)); o[1] = bf2f((unsigned short)(r.x >> 16));
-        o[2] = bf2f((unsigned short)(r.y & 0xffff)); o[3] = bf2f((unsigned short)(r.y >> 16));
-    };
-    // ---- phase 1: g, per-lane partial sums ----
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * WTM + b * 16 + fr;
-        const bool valid = m < geo.M;
-        const int mc = valid ? m : geo.M - 1;
-        size_t aoff = 0;
-        if (T2) {
-            const int bi = mc / HW;
-            const int r = mc - bi * HW;
-            const int yy = r / geo.Ws;
-            const int xx = r - yy * geo.Ws;
-            aoff = ((size_t)(bi * q.aHp + yy + q.apad) * q.aWp + xx + q.apad) * C;
-        }
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * WTN + a * 16 + 4 * fq;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            const uint2 zr = *reinterpret_cast<const uint2*>(q.z + (size_t)mc * C + n);
-            float z[4], mu[4], rs[4];
-            up4(zr, z);
-            ld4(q.mean + n, mu); ld4(q.rstd + n, rs);
-            if (T2) {
-                float o[4];
-                up4(*reinterpret_cast<const uint2*>(p.y + (size_t)mc * C + n), o);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += o[j];
-            }
-            uint2 gr;
-            gr.x = pack2bf(v[0], v[1]); gr.y = pack2bf(v[2], v[3]);       // d(activation) as the unfused path stores it
-            float g[4];
-            up4(gr, g);
-            if (T2) {
-                float av[4];
-                up4(*reinterpret_cast<const uint2*>(q.act + aoff + n), av);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = av[j] > 0.f ? g[j] : 0.f;
-            } else {
-                float sc[4], sh[4];
-                ld4(q.mscale + n, sc); ld4(q.mshift + n, sh);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = (z[j] * sc[j] + sh[j]) > 0.f ? g[j] : 0.f;
-            }
-            gr.x = pack2bf(g[0], g[1]); gr.y = pack2bf(g[2], g[3]);       // exact: g is the bf16 value or 0
-            if (T2 && valid) *reinterpret_cast<uint2*>(p.y + (size_t)mc * C + n) = gr;      // identity path of the next block
-            kg[a][b] = gr; kz[a][b] = zr;
-            if (valid) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s1[a][j] += g[j];
-                    s2[a][j] += g[j] * ((z[j] - mu[j]) * rs[j]);
-                }
-            }
-        }
-    }
-    // ---- phase 2: block sums -> the BatchNorm's rows (conv_stats_flush: p.stats / p.stat_rows point at them) ----
-    conv_stats_flush<BM, BN, WM, WN>(p, s1, s2, blockIdx.y * gridDim.x + blockIdx.x, n0, smem);
-    vpd_grid_barrier(reinterpret_cast<GridSync*>(q.sync), false, q.err, blockIdx.y * gridDim.x + blockIdx.x,
-                     gridDim.x * gridDim.y);
-    // ---- phase 3: totals of this block's channels ----
-    float* coef = reinterpret_cast<float*>(smem);                 // [2][BN]
-    if (tid < 2 * BN) {
-        const int which = tid / BN;
-        const int c = tid - which * BN;
-        double s = 0.0;
-#pragma unroll
-        for (int r = 0; r < VPD_FUSED_ROWS; ++r)
-            s += __hip_atomic_load(&q.rows[((size_t)r * 2 + which) * C + n0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        coef[tid] = (float)(s / (double)q.count);
-        if (blockIdx.x == 0) {
-            if (which == 0) q.dbeta[n0 + c] = (float)s;
-            else q.dgamma[n0 + c] = (float)s;
-        }
-    }
-    __syncthreads();
-    // ---- phase 4: dz = c1 * (g - c2 - xhat * c3) -> padded dz ----
-#pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * WTM + b * 16 + fr;
-        const bool valid = m < geo.M;
-        const int mc = valid ? m : geo.M - 1;
-        const int bi = mc / HW;
-        const int r = mc - bi * HW;
-        const int yy = r / geo.Ws;
-        const int xx = r - yy * geo.Ws;
-        const size_t doff = ((size_t)(bi * q.dzHp + yy + q.dzpad) * q.dzWp + xx + q.dzpad) * C;
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int nl = wn * WTN + a * 16 + 4 * fq;
-            const int n = n0 + nl;
-            float g[4], z[4], mu[4], rs[4], gm[4];
-            up4(kg[a][b], g); up4(kz[a][b], z);
-            ld4(q.mean + n, mu); ld4(q.rstd + n, rs); ld4(q.gamma + n, gm);
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                o[j] = gm[j] * rs[j] * (g[j] - coef[nl + j] - (z[j] - mu[j]) * rs[j] * coef[BN + nl + j]);
-            uint2 ov;
-            ov.x = pack2bf(o[0], o[1]); ov.y = pack2bf(o[2], o[3]);
-            if (valid) *reinterpret_cast<uint2*>(q.dz + doff + n) = ov;
         }
     }
 }

@@ -433,11 +433,6 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
         }
-        if (EPM == 4 || EPM == 5) {          // conv_epilogue_bnbwd: grid barrier (2) + coefficients (1)
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-        }
         return;
     }
 
@@ -514,22 +509,18 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
             for (int j = 0; j < 4; ++j) pr.s3[a][j] = 0.f;
     }
     __builtin_amdgcn_s_barrier();                                 // END
-    if constexpr (EPM == 4 || EPM == 5) {
-        conv_epilogue_bnbwd<BM, BN, WM, WN, EPM == 5>(p, acc, mtile, n0, geo, smem);
-    } else {
-        float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
+    float st1[BN / WN / 16][4], st2[BN / WN / 16][4];
 #pragma unroll
-        for (int a = 0; a < BN / WN / 16; ++a)
+    for (int a = 0; a < BN / WN / 16; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
-        if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
-        else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
-        else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
-        if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
-        if constexpr (EPM == 8) {      // the second BatchNorm's rows: (sum g, sum g * z2)
-            __builtin_amdgcn_s_barrier();                         // the first flush has read the scratch
-            conv_stats_flush<BM, BN, WM, WN>(p, st1, pr.s3, mtile, n0, smem, p.stats2);
-        }
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; }
+    if constexpr (EPM == 8) conv_epilogue_pre2<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst, pr);
+    else if constexpr (BST) conv_epilogue_pre<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo, bst);
+    else conv_epilogue<BM, BN, WM, WN, EPM>(p, acc, mtile, n0, st1, st2, geo);
+    if (p.stats) conv_stats_flush<BM, BN, WM, WN>(p, st1, st2, mtile, n0, smem);
+    if constexpr (EPM == 8) {      // the second BatchNorm's rows: (sum g, sum g * z2)
+        __builtin_amdgcn_s_barrier();                             // the first flush has read the scratch
+        conv_stats_flush<BM, BN, WM, WN>(p, st1, pr.s3, mtile, n0, smem, p.stats2);
     }
 }
 
@@ -862,10 +853,7 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
 static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
     static const int off = getenv("VPD_C64X2") ? !atoi(getenv("VPD_C64X2")) : 0;
     const int W = p.Ws, H = p.Hs;
-    // VPD_C64X2_TRAIN: bit mask of the train-mode epilogue modes that also take this kernel (experiment; default none)
-    static const int train_modes = getenv("VPD_C64X2_TRAIN") ? atoi(getenv("VPD_C64X2_TRAIN")) : 0;
-    const int mode = conv_ep_mode(p);
-    if (off || !(mode == 3 || ((train_modes >> mode) & 1)) || W <= 0 || 256 % W != 0) return false;
+    if (off || conv_ep_mode(p) != 3 || W <= 0 || 256 % W != 0) return false;      // inference only (in training it measured slower)
     const int TR = 256 / W;
     if (TR <= H) { if (H % TR != 0) return false; g->multi = 0; g->HR = TR + 2; }
     else { if (TR % H != 0) return false; g->multi = 1; g->HR = (TR / H) * (H + 2); }
@@ -1224,18 +1212,9 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------
-// conv3x3_pws_kernel (conv_pws.h): persistent blocks, LDS flag hand-off.  VPD_PWS=0 restores conv3x3_ws_kernel.
+// conv3x3_pws_kernel (conv_pws.h): persistent blocks, one barrier per K-step.  VPD_PWS=0 restores conv3x3_ws_kernel.
 // ---------------------------------------------------------------------------
 // ring depths per tile class (NS = A + 2: two readable steps + A weight bundles in flight); -D overrides for same-box A/B builds
-#ifndef PWS_L1_DEFAULT
-#define PWS_L1_DEFAULT 0
-#endif
-#ifndef PWS_PREFER_C6
-#define PWS_PREFER_C6 0
-#endif
-#ifndef PWS_C1_ALWAYS
-#define PWS_C1_ALWAYS 0
-#endif
 #ifndef PWS_NS_C1
 #define PWS_NS_C1 4
 #endif
@@ -1259,21 +1238,16 @@ int pws_cu_count() {
     }
     return ncu;
 }
-static int pws_variant(const ConvParams& p) {      // experiments: train-forward launches only (bench_conv.py)
-    static const int v = getenv("VPD_PWS_VAR") ? atoi(getenv("VPD_PWS_VAR")) : 0;
-    return conv_ep_mode(p) == 1 ? v : 0;
-}
 static bool pws_enabled(const ConvParams& p) {
     static const int on = getenv("VPD_PWS") ? atoi(getenv("VPD_PWS")) : 1;
     const int mode = conv_ep_mode(p);
     // (global output rows below 2^21: the kernel's float-reciprocal divisions, vpd_fdiv)
     return on && mode != 4 && mode != 5 && (long)p.N * p.Hs < VPD_FDIV_MAX;
 }
-// EXP: an experimental variant (VPD_PWS_VAR): only the train-forward epilogue is instantiated
-template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE, bool EXP = false, bool RESW = false>
+template <int BM, int BN, int HROWS, int NS, int NMW, bool PIPE>
 static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     constexpr int WN = BN / 64, WM = NMW / WN;
-    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + (RESW ? 0 : 1024) + (size_t)3 * WM * BN * 4;
+    constexpr size_t lds = (size_t)2 * HROWS * 128 + (size_t)NS * BN * 128 + 1024 + (size_t)3 * WM * BN * 4;
     static_assert(lds <= 160 * 1024, "LDS");
     PwsGrid sg;
     sg.MT = (p.M + BM - 1) / BM;
@@ -1323,26 +1297,20 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
         fprintf(stderr, "%llu cycles\n", emax - lo);
     } };
 #endif
-    if constexpr (EXP) {
-        if (conv_ep_mode(q) != 1) return hipErrorInvalidValue;
-        VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg);
-        return hipGetLastError();
-    } else {
     switch (conv_ep_mode(q)) {
-        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 3, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 6, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 7, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
-        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 8, NMW, PIPE, RESW>), grid, block, lds, stream, q, g, sg); break;
+        case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 3: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 3, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 6: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 6, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 7: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 7, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
+        case 8: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 8, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
         default: return hipErrorInvalidValue;
     }
 #ifdef PWS_STAMPS
     if (++nlaunch == 30) { char tag[64]; snprintf(tag, sizeof tag, "<%d,%d> NS %d mode %d", BM, BN, NS, conv_ep_mode(q)); Dump::run((int)grid.x, tag); }
 #endif
     return hipGetLastError();
-    }
 }
 
 template <int BM, int BN, int HROWS, int HB, int WPS, int NS>
@@ -1373,8 +1341,6 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
         case 0: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 0, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 1: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 1, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 2: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 2, NS>), grid, dim3(512), lds, stream, q, g); break;
-        case 4: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 4, NS>), grid, dim3(512), lds, stream, q, g); break;
-        case 5: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 5, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 6: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 6, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 7: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 7, NS>), grid, dim3(512), lds, stream, q, g); break;
         case 8: VPD_LAUNCH((conv3x3_ws_kernel<BM, BN, HROWS, HB, WPS, 8, NS>), grid, dim3(512), lds, stream, q, g); break;
@@ -1382,13 +1348,10 @@ static hipError_t launch_ws_ns(const ConvParams& p, const HaloGeom& g, hipStream
     }
     return hipGetLastError();
 }
-// NSMAX: the deepest weight ring that fits LDS beside the two halo buffers.  VPD_WS_NS=3 selects the 3-stage ring (A/B).
-template <int BM, int BN, int HROWS, int HB, int WPS, int NSMAX>
+// NS: weight-ring depth (four stages: profiles/r02_ring_depth.txt)
+template <int BM, int BN, int HROWS, int HB, int WPS, int NS>
 static hipError_t launch_ws(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
-    static const int ns = getenv("VPD_WS_NS") ? atoi(getenv("VPD_WS_NS")) : NSMAX;
-    if (NSMAX >= 5 && ns >= 5) return launch_ws_ns<BM, BN, HROWS, HB, WPS, NSMAX >= 5 ? 5 : 3>(p, g, stream);
-    if (NSMAX >= 4 && ns >= 4) return launch_ws_ns<BM, BN, HROWS, HB, WPS, NSMAX >= 4 ? 4 : 3>(p, g, stream);
-    return launch_ws_ns<BM, BN, HROWS, HB, WPS, 3>(p, g, stream);
+    return launch_ws_ns<BM, BN, HROWS, HB, WPS, NS>(p, g, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -1559,15 +1522,14 @@ static bool conv1x1_ws_eligible(const ConvParams& p) {
     static const int on = getenv("VPD_CONV1X1_WS") ? atoi(getenv("VPD_CONV1X1_WS")) : 1;
     // K >= 512 (8+ steps), or 4+ steps when the launch is at most a few rounds of blocks: layer1's 256 -> 64 convs (2,048
     // blocks of four steps) stream their 168 MB faster through the gather kernel's two small blocks per CU
-    static const int kmin = getenv("VPD_CONV1X1_KMIN") ? atoi(getenv("VPD_CONV1X1_KMIN")) : 256;
-    static const int mmax = getenv("VPD_CONV1X1_MMAX") ? atoi(getenv("VPD_CONV1X1_MMAX")) : 32768;
-    const bool common = on && !p.bnb.mode && !p.bst_z2 && p.xC == p.Kc && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
+    const int kmin = 256, mmax = 32768;
+    const bool common = on && !p.bst_z2 && p.xC == p.Kc && p.Kc % 64 == 0 && p.Co % 64 == 0 &&
                         (long)p.N * p.xHp * p.xWp * p.xC < (1l << 31) && (long)9 * p.Co * p.Kc < (1l << 31);
     if (!common) return false;
     // the merged parity classes of a stride-2 3x3 data gradient (+ the 1x1 branch's as extra K-steps of class 0) at the layer3
     // and layer4 boundaries (layer2's has 2,048 blocks of 2-8 K-steps: gather kernel)
     static const int dgon = getenv("VPD_CONV_S2_DGRAD_WS") ? atoi(getenv("VPD_CONV_S2_DGRAD_WS")) : 1;
-    static const int dgk = getenv("VPD_CONV_S2_DGRAD_KMIN") ? atoi(getenv("VPD_CONV_S2_DGRAD_KMIN")) : 256;
+    const int dgk = 256;      // (layer2's boundary, K = 128, on the ring GEMM: measured slower, DESIGN_HISTORY.md round 4)
     if (p.ncls > 1 || p.x2 || p.osub != 1)
         return dgon && p.ncls == 4 && p.osub == 2 && p.istr == 1 && !p.alt_w && !p.accumulate && !p.ep_scale && p.Kc >= dgk &&
                p.Co % 128 == 0 && (!p.x2 || p.Kc2 == p.Kc) && (!p.bst_z || (p.yC == p.Co && p.ypad == 0));
@@ -1668,8 +1630,7 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
 extern "C" int vpd_conv_bm(int M, int Co) {
     const int bn = (Co % 128 == 0) ? 128 : 64;
     if (bn == 128) {
-        static const long thr = getenv("VPD_IGEMM_T128") ? atol(getenv("VPD_IGEMM_T128")) : 384;
-        if ((long)((M + 127) / 128) * (Co / 128) >= thr) return 128;
+        if ((long)((M + 127) / 128) * (Co / 128) >= 384) return 128;
         return 64;
     }
     return 128;
@@ -1691,8 +1652,7 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             // 256 x 64 tiles on the pipelined persistent kernel where 256 x 128 tiles would give every block exactly one tile: twice
             // the tiles, so a block overlaps one tile's epilogue with the next one's loads (layer2 at 256 crops: 23.2 vs 25.2 us;
             // with several 256 x 128 tiles per block the eight-wave kernel below is faster: 83.7 vs 90.6 us at 1000 crops)
-            static const int w64_first = getenv("VPD_PWS_PREFER_C6") ? atoi(getenv("VPD_PWS_PREFER_C6")) : PWS_PREFER_C6;
-            if ((w64_first || (p.M + 255) / 256 <= pws_cu_count() / (p.Co / 128)) && pws_enabled(p) && t256 >= 200 &&
+            if ((p.M + 255) / 256 <= pws_cu_count() / (p.Co / 128) && pws_enabled(p) && t256 >= 200 &&
                 halo_geom(p, 256, 416, g))
                 return 6;
             if (t256 >= 200 && halo_geom(p, 256, 352, g)) return 1;
@@ -1703,33 +1663,17 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
             if (w64 && t128 >= 200 && (long)((p.M + 255) / 256) * (p.Co / 64) >= 200 && halo_geom(p, 256, 416, g)) return 6;
             if (halo_geom(p, 128, 288, g)) return t128 >= 200 ? 2 : 3;    // few pixel tiles: 64-channel tiles fill the chip
         } else if (p.Kc == 64 && p.Co == 64) {
-            // 64 -> 64 channels (layer1).  VPD_PWS_L1: 256 x 64 tiles on the pipelined persistent kernel (64 x 64 wave tiles: 0.5
-            // fragment reads per MFMA instead of the 0.75 of conv3x3_c64_persistent_kernel's 32 x 64, whose LDS pipe is 75 % busy);
-            // the nine weight taps are re-streamed per tile (8 KB per K-step out of L2) instead of staying resident
-            static const int l1 = getenv("VPD_PWS_L1") ? atoi(getenv("VPD_PWS_L1")) : PWS_L1_DEFAULT;
-            if (l1 == 2 && pws_enabled(p) && halo_geom(p, 256, 416, g)) return 6;      // (measured negative: weights re-streamed)
-            if (halo_geom(p, 128, 224, g)) return 0;      // persistent blocks with resident weights
+            // 64 -> 64 channels (layer1): persistent blocks with resident weights
+            if (halo_geom(p, 128, 224, g)) return 0;
         }
     }
     return 4;
 }
 int vpd_conv_kernel_class(const ConvParams& p) { HaloGeom g; return vpd_conv_kernel_class(p, &g); }
 
-// true when `p` (with bnb.mode set) can run the fused data-gradient + BatchNorm-backward epilogue: a warp-specialised
-// kernel whose whole grid is resident (one block per CU)
-bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu) {
-    HaloGeom g;
-    const int kc = vpd_conv_kernel_class(p, &g);
-    // (the 256-pixel tile keeps 128 accumulator registers: the epilogue's kept g / z fragments spill there)
-    if (kc < 2 || kc > 3) return false;
-    const int bm = kc == 1 ? 256 : 128, bn = kc == 3 ? 64 : 128;
-    const long blocks = (long)((p.M + bm - 1) / bm) * (p.Co / bn);
-    return blocks <= ncu;
-}
-
 // true when this launch's kernel can take the sums of the consuming BatchNorm's backward in its epilogue (bst_z / bst_mask)
 bool vpd_conv_takes_bn_sums(const ConvParams& p) {
-    if (p.bnb.mode || p.ep_scale || p.alt_w || p.yC != p.Co || p.ypad != 0) return false;
+    if (p.ep_scale || p.alt_w || p.yC != p.Co || p.ypad != 0) return false;
     HaloGeom g;
     const int kc = vpd_conv_kernel_class(p, &g);
     if (kc == 4) {      // gather kernel: the merged parity classes of a stride-2 data gradient (plain store only)
@@ -1753,11 +1697,6 @@ bool vpd_conv_takes_bn_sums(const ConvParams& p) {
 
 hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
-    if (p0.bnb.mode) {
-        HaloGeom gg;
-        const int kc = vpd_conv_kernel_class(p0, &gg);
-        if (kc < 2 || kc > 3) return hipErrorInvalidValue;        // the caller asks vpd_conv_bnbwd_ok first
-    }
     if (p0.bst_z && !vpd_conv_takes_bn_sums(p0)) return hipErrorInvalidValue;      // (the caller asks first)
     // epilogue modes 6 / 7 / 8 are selected by bst_z alone, and their statistics flush (with its workgroup barriers, which the
     // loader waves of the warp-specialised kernels match one for one) runs only with rows to add to
@@ -1770,17 +1709,13 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     switch (vpd_conv_kernel_class(p, &g)) {
         case 0: {
             HaloGeom g2;
-            // (VPD_PWS_L1=1, round 3: 256-pixel tiles with the nine taps resident on the pipelined kernel -- measured slower, 30.2 vs
-            //  25.9 us, profiles/r03_layer1_resident_weights_negative.txt; its instantiation went when the block's running
-            //  statistics took the LDS words its filler transfers used to land in)
             if (c64x2_geom(p, &g2)) return launch_c64x2(p, g2, stream);      // inference: two MFMA wave groups on 256-pixel tiles
             return launch_c64<224>(p, g, stream);
         }
         case 1:
             // (eight MFMA waves, no fragment pipeline: two waves per SIMD cover each other's LDS round trips.  With ONE tile per
             //  block conv3x3_ws_kernel, whose loaders run three bundles ahead instead of two, is 3 % faster: 25.5 vs 26.3 us)
-            if (pws_enabled(p) && (PWS_C1_ALWAYS || (p.M + 255) / 256 > pws_cu_count() / (p.Co / 128))) {
-                if (pws_variant(p) == 1) return launch_pws<256, 128, 352, 3, 8, false, true>(p, g, stream);
+            if (pws_enabled(p) && (p.M + 255) / 256 > pws_cu_count() / (p.Co / 128)) {
                 return launch_pws<256, 128, 352, PWS_NS_C1, 8, false>(p, g, stream);
             }
             return launch_ws<256, 128, 352, 2, 2, 4>(p, g, stream);      // 88 + 64 KiB
@@ -1788,22 +1723,16 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         // profiles/r02_ring_depth.txt (4 is +0.5 % on the step, 5 is slower than 3)
         case 2:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<128, 128, 288, 4, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<128, 128, 288, 3, 4, true, true>(p, g, stream);
                 return launch_pws<128, 128, 288, PWS_NS_C2, 4, true>(p, g, stream);
             }
             return launch_ws<128, 128, 288, 2, 2, 4>(p, g, stream);      // 72 + 64 KiB
         case 3:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<128, 64, 288, 4, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<128, 64, 288, 5, 4, true, true>(p, g, stream);
                 return launch_pws<128, 64, 288, PWS_NS_C3, 4, true>(p, g, stream);
             }
             return launch_ws<128, 64, 288, 2, 2, 4>(p, g, stream);       // 72 + 32 KiB
         case 6:
             if (pws_enabled(p)) {
-                if (pws_variant(p) == 1) return launch_pws<256, 64, 416, 5, 4, true, true>(p, g, stream);
-                if (pws_variant(p) == 2) return launch_pws<256, 64, 416, 3, 4, true, true>(p, g, stream);
                 // (round 4: layer2's 18 x 18 halo needs 328 rows, not 416, and the 22 KB that frees were given to a deeper weight ring,
                 //  NS 7 and 9 -- same-box 72.02 / 72.02 / 71.86 k crops/s for NS 7 / 9 / 5, profiles/r04_ab_layer2_ring_depth.txt: the K
                 //  loop is not bound by the loaders' bytes in flight; instantiations removed)

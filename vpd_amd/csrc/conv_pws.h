@@ -194,16 +194,8 @@ struct PwsSched {
     static constexpr int max_inflight() { int m = 0; for (int t = 0; t < 9; ++t) m = inflight(t) > m ? inflight(t) : m; return m; }
 };
 
-// RESW (64 -> 64 channels, layer1: ONE 64-channel chunk, nine K-steps per tile, NS = 9): the nine weight taps are loaded once
-// and stay in their ring stages (stage = tap); the loaders then only move halos -- the next tile's, in the bundles behind READY
-// of taps 0 .. HT - 1, all landed in front of READY of tap 8, whose pipeline reads the next tile's first fragments.
-// conv3x3_c64_persistent_kernel keeps the weights resident too, but on 128-pixel tiles with 32 x 64 wave tiles (0.75 fragment
-// reads per MFMA: its LDS pipe is 75 % busy); here 256-pixel tiles give 64 x 64 wave tiles (0.5) and the fragment pipeline.
-// (the kernel's body as a function: conv3x3_pws_kernel and conv3x3_pws_xf_kernel -- XFT = ConvXf, the transforming loaders --
-//  are thin wrappers below)
-template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE, bool RESW, class XFT>
-static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloGeom& g, const PwsGrid& sg, const XFT& xf) {
-    constexpr bool XF = std::is_same<XFT, ConvXf>::value;
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
+static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloGeom& g, const PwsGrid& sg) {
     constexpr int WN = BN / 64;
     constexpr int WM = NMW / WN;
     constexpr int WTM = BM / WM;
@@ -213,21 +205,18 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     constexpr int W_PER = BN / 32;                   // weight-tile DMA instructions per loader wave and step
     constexpr int HINSTR = HROWS / 8;                // 1-KiB LDS-DMA instructions per halo
     constexpr int HPASS = (HINSTR + 3) / 4;          // ... per loader wave (the last one may be a filler when HINSTR % 4 != 0)
-    constexpr int A = RESW ? 4 : NS - 2;             // weight bundles beyond the two readable steps (RESW: halo bundles only)
+    constexpr int A = NS - 2;                        // weight bundles beyond the two readable steps
     constexpr int HT = 9 - A;                        // READYs of a chunk behind which the next chunk's halo slices may be issued
-    using SC = PwsSched<RESW ? 0 : W_PER, HPASS, HT, A>;
+    using SC = PwsSched<W_PER, HPASS, HT, A>;
     static_assert(HROWS % 8 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
-    static_assert(!RESW || (NS == 9 && BN == 64), "resident weights: one stage per tap");
     static_assert(EPM == 0 || EPM == 1 || EPM == 2 || EPM == 3 || EPM == 6 || EPM == 7 || EPM == 8, "epilogue mode");
     constexpr unsigned OFF_W = 2u * HBUF * 2u;                       // bytes
-    // (RESW: two 44-KB halos + nine weight taps leave exactly the statistics scratch: fillers land there, nobody reads it
-    //  before every transfer has been waited for)
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
-    constexpr unsigned OFF_RED = OFF_DUMP + (RESW ? 0u : 1024u);
+    constexpr unsigned OFF_RED = OFF_DUMP + 1024u;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][HBUF] halos, [NS][WSTAGE] weight ring, dump, scratch
     unsigned char* red = smem + OFF_RED;
-    pws_kernarg_touch<sizeof(ConvParams) + sizeof(HaloGeom) + sizeof(PwsGrid) + (XF ? sizeof(XFT) : 0)>();
+    pws_kernarg_touch<sizeof(ConvParams) + sizeof(HaloGeom) + sizeof(PwsGrid)>();
 
     const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
     const int tid = threadIdx.x;
@@ -307,216 +296,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             for (int k = 0; k < W_PER; ++k)
                 pws_dma16s(wbp, wrow[k], lds0 + OFF_W + stg * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
         };
-        if constexpr (XF) {
-            // ---------------- transforming loaders (ConvXf): z -> relu(scale * z + shift) -> LDS (+ activation, bit map) ----------------
-            // A halo slice (8 pixels x 64 channels per instruction, as the LDS-DMA path) is REQUESTED into registers behind READY of
-            // tap t < HTX and PROCESSED behind READY of tap t + A: the counted wait in front of that READY has retired the bundle the
-            // request rode in, so processing never waits on its own; the last slices are written behind READY of tap 7 and are
-            // complete (lgkmcnt) in front of READY of tap 8, the first step whose pipeline reads the new chunk.  Tiles are whole
-            // padded images here (launcher: multi, or TR == H), so a tile's halo has no pixel in common with another tile's: every
-            // pixel of the activation is produced once per channel tile.  It is written out by the MFMA waves, from the centre
-            // tap's pixel fragments (see there): stores issued by THIS wave would sit in its vmcnt queue between the weight
-            // transfers, where they cannot be counted (stores and loads retire out of order with respect to each other) and so
-            // make every counted wait cover younger weights too -- measured: 4 us per launch.
-            constexpr unsigned OFF_XF = OFF_RED + 3u * WM * BN * 4u;     // scale[Ci], shift[Ci]
-            // The prologue below is ~800 vector ALU instructions per loader wave (slice constants, the first chunk's transform) in
-            // front of the block's first MFMA, while the SIMD's OTHER wave -- older, so the winner of every issue arbitration -- runs
-            // its own set-up with slack to spare: priority to the loaders until the first chunk is written (stamps: first READY at
-            // 9,950 instead of 10,800 cycles; same-box 72.52 vs 72.27 k crops/s, profiles/r04_xf_ab.txt)
-            if (!(xf.ablate & 8)) __builtin_amdgcn_s_setprio(3);
-            constexpr int HTX = 8 - A;
-            using SX = PwsSched<W_PER, HPASS, HTX, A>;
-            static_assert(!RESW && HINSTR % 4 == 0 && HTX >= 1 && SX::max_inflight() < 64, "transforming loader geometry");
-            float* const s_sc = reinterpret_cast<float*>(smem + OFF_XF);
-            float* const s_sh = s_sc + Ci;
-            const int Hp = H + 2;
-            // per-slice constants of the launch: zoff = byte offset of the lane's 16 bytes inside the tile's dense z block | image-in-
-            // tile << 26 (all ones: border pixel, or beyond the halo); loff = LDS byte offset inside a halo buffer, XOR key applied
-            // to the DESTINATION slot (the DMA path applies it to the source piece: same layout)
-            unsigned zoff[HPASS], loff[HPASS];
-            u32x4 hz[HPASS];
-            // (zoff[k] is computed right in front of slice k's first request, loff[k] while the requests fly: see the prologue)
-            auto slice_zoff = [&](int k) __attribute__((always_inline)) {
-                const int hp = (lw + 4 * k) * 8 + lrow;
-                const int hr = vpd_fdiv(hp, g.rWp);
-                const int xp = hp - hr * Wp;
-                const int bi = vpd_fdiv(hr, xf.rHp);
-                const int yr = hr - bi * Hp;
-                const bool inside = hp < g.NHP && yr >= 1 && yr <= H && xp >= 1 && xp <= W;
-                return inside ? ((unsigned)((((bi * H + yr - 1) * W + xp - 1) * Ci + piece * 8) * 2) | ((unsigned)bi << 26)) : ~0u;
-            };
-            auto slice_loff = [&](int k) __attribute__((always_inline)) {
-                const int hp = (lw + 4 * k) * 8 + lrow;
-                const int hr = vpd_fdiv(hp, g.rWp);
-                const int xp = hp - hr * Wp;
-                const int key = (xp & g.kmask) ^ ((hr & g.rowmask) << g.kshift);
-                return (unsigned)(lw + 4 * k) * 1024u + (unsigned)lrow * 128u + (unsigned)((piece ^ key) << 4);
-            };
-            auto tile_b0 = [&](int mtile) __attribute__((always_inline)) {
-                return __builtin_amdgcn_readfirstlane(vpd_fdiv(mtile * g.TR, g.rH));
-            };
-            // wave-uniform part of a (tile, chunk): the dense z block's / the padded activation's / the bit map's base, and the
-            // bound on zoff that excludes border pixels and images beyond the batch (the tensor's ragged last tile)
-            struct XfTile { const char* zb; unsigned lim; };
-            auto xf_tile = [&](int mtile, int cc) __attribute__((always_inline)) {
-                const int b0 = tile_b0(mtile);
-                const int left = p.N - b0;
-                XfTile t;
-                {      // (wave-uniform, and told so: the 64-bit multiply may be done on the vector ALU, and an "s" operand does not move it back)
-                    const unsigned long long a = (unsigned long long)(reinterpret_cast<const char*>(xf.z) + ((size_t)b0 * H * W * Ci + cc * 64) * 2);
-                    const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-                    t.zb = reinterpret_cast<const char*>(((unsigned long long)ahi << 32) | alo);
-                }
-                t.lim = left >= 63 ? 0xfffffffeu : ((unsigned)left << 26) - 1u;      // zoff <= lim: interior pixel of an image that exists
-                return t;
-            };
-            auto req = [&](const XfTile& t, int k) __attribute__((always_inline)) {
-                const unsigned zo = zoff[k];
-                const unsigned vo = zo <= t.lim ? (zo & 0x3ffffffu) : 0u;       // (others read the tile's first bytes: valid, unused)
-                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(hz[k]) : "v"(vo), "s"(t.zb) : "memory");
-            };
-            auto coef = [&](int cc, float (&sc)[8], float (&sh)[8]) __attribute__((always_inline)) {
-                const float4* a = reinterpret_cast<const float4*>(s_sc + cc * 64 + piece * 8);
-                const float4* b = reinterpret_cast<const float4*>(s_sh + cc * 64 + piece * 8);
-                const float4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-                sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
-                sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
-            };
-            // (a slice's registers are tied to the counted wait first, ALL slices of a group, then the groups' arithmetic follows
-            //  without an asm statement in between: the slices are independent chains, and hipcc interleaves them only then --
-            //  one after the other a slice cost ~270 cycles of dependent vector ALU latency, three of them a whole K-step)
-            auto tie = [&](int k) __attribute__((always_inline)) { asm volatile("" : "+v"(hz[k])); };
-            auto put = [&](const XfTile& t, int buf, int k, const float (&sc)[8], const float (&sh)[8])
-                           __attribute__((always_inline)) {
-                // border pixels are never written: their slots in both buffers were zeroed once, in the prologue (a tile is made of
-                // whole padded images: the same slots are border for every tile and chunk); pixels of images beyond the batch (the
-                // tensor's ragged last tile) keep stale finite bytes -- they only reach output pixels that are never stored or counted
-                const u32x4 zv = hz[k];
-                const unsigned w[4] = {zv.x, zv.y, zv.z, zv.w};
-                // ReLU on the PACKED pair, as signed 16-bit lanes: a negative bf16 (-0 included) is a negative int16, so max(x, 0)
-                // is the ReLU of the rounded value -- the same bits as rounding the ReLU of the fp32 value (bn_fwd_fused_kernel)
-                // for every non-NaN input.  (Computed on every lane, only the LDS write is predicated: straight-line code that
-                // hipcc can interleave with the other slices of the group.)
-                typedef short s16x2 __attribute__((ext_vector_type(2)));
-                const s16x2 zero = {0, 0};
-                unsigned o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float lo = __builtin_bit_cast(float, w[j] << 16), hi = __builtin_bit_cast(float, w[j] & 0xffff0000u);
-                    lo = lo * sc[2 * j] + sh[2 * j]; hi = hi * sc[2 * j + 1] + sh[2 * j + 1];
-                    o[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pack2bf(lo, hi)), zero));
-                }
-                const u32x4 ov = {o[0], o[1], o[2], o[3]};
-                if (zoff[k] <= t.lim)
-                    *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>((size_t)(lds0 + (unsigned)buf * (HBUF * 2u) + loff[k])) = ov;
-            };
-            // prologue: the first chunk's z, the weights of steps 0 .. A, then the BatchNorm's coefficients while they fly
-            const XfTile t00 = xf_tile(lane0, 0);
-#pragma unroll
-            for (int k = 0; k < HPASS; ++k) { zoff[k] = slice_zoff(k); req(t00, k); }
-            int w_tap = 0, w_cc = 0;
-            unsigned w_st = 0;
-            int w_step = 0;
-#pragma unroll
-            for (int k = 0; k <= A; ++k) {
-                if (w_step < total) issue_w(w_tap, w_cc, w_st);
-                ++w_step;
-                if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
-                if (++w_st == NS) w_st = 0;
-            }
-#pragma unroll
-            for (int k = 0; k < HPASS; ++k) {
-                loff[k] = slice_loff(k);
-                if (zoff[k] == ~0u) {      // border pixel (or beyond the halo): zero in both buffers, once
-                    const u32x4 z4 = {0u, 0u, 0u, 0u};
-                    *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>((size_t)(lds0 + loff[k])) = z4;
-                    *reinterpret_cast<u32x4 __attribute__((address_space(3)))*>((size_t)(lds0 + HBUF * 2u + loff[k])) = z4;
-                }
-            }
-            // TABLE: the MFMA waves (idle until the first bytes are there, and with nothing in front of their loads) have finalized
-            // the BatchNorm into scale[] / shift[] while this wave issued its requests
-            PWS_STAMP(9);                                                // requests issued
-            __builtin_amdgcn_s_barrier();
-            PWS_STAMP(12);                                               // table there
-            pws_vmwait<0>();
-            PWS_STAMP(10);                                               // first chunk landed
-            {
-                float sc[8], sh[8];
-                coef(0, sc, sh);
-#pragma unroll
-                for (int k = 0; k < HPASS; ++k) tie(k);
-#pragma unroll
-                for (int k = 0; k < HPASS; ++k) put(t00, 0, k, sc, sh);
-            }
-            PWS_STAMP(13);                                               // first chunk written
-            __builtin_amdgcn_s_setprio(0);
-            const int total_chunks = njobs * nchunks;
-            int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0;
-#ifdef PWS_STAMPS
-            unsigned long long xs_work = 0, xs_wait = 0, xs_bar = 0, xs_last = 0;      // loader cycles: issuing / in the counted wait / at the barrier
-#endif
-            for (int c = 0; c < total_chunks; ++c) {
-                const bool has_next = c + 1 < total_chunks;
-                const XfTile ht = xf_tile(has_next ? lane0 + h_job * sg.lanes : lane0, h_cc);
-                const int h_buf = (c + 1) & 1;
-                float sc[8], sh[8];
-                auto step = [&](auto tc) __attribute__((always_inline)) {
-                    constexpr int t = decltype(tc)::value;
-#ifdef PWS_STAMPS
-                    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
-                    if (has_next) pws_vmwait<SX::inflight(t)>();
-                    else pws_vmwait<0>();
-                    pws_lgkm0();                                         // this wave's halo writes are in the LDS
-#ifdef PWS_STAMPS
-                    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-#endif
-                    __builtin_amdgcn_s_barrier();                        // READY_s
-#ifdef PWS_STAMPS
-                    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-                    if (c > 0 || t > 0) { xs_work += ts0 - xs_last; xs_wait += ts1 - ts0; xs_bar += ts2 - ts1; }
-                    xs_last = ts2;
-#endif
-                    if (w_step < total) {
-                        issue_w(w_tap, w_cc, w_st);
-                        ++w_step;
-                        if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
-                        if (++w_st == NS) w_st = 0;
-                    }
-                    if constexpr (SX::cnt(t) > 0) {
-                        if (has_next) {
-#pragma unroll
-                            for (int u = 0; u < SX::cnt(t); ++u) req(ht, SX::first(t) + u);
-                        }
-                    }
-                    if constexpr (t >= A) {
-                        if constexpr (SX::cnt(t - A) > 0) {
-                            if (has_next) {
-                                if constexpr (t == A) coef(h_cc, sc, sh);
-#pragma unroll
-                                for (int u = 0; u < SX::cnt(t - A); ++u) tie(SX::first(t - A) + u);
-#pragma unroll
-                                for (int u = 0; u < SX::cnt(t - A); ++u)
-                                    put(ht, h_buf, SX::first(t - A) + u, sc, sh);
-                            }
-                        }
-                    }
-                };
-                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-                step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-                if (++h_cc == nchunks) { h_cc = 0; ++h_job; }
-            }
-            pws_vmwait<0>();
-#ifdef PWS_STAMPS
-            if (p.err && lane == 0 && wave == NMW) {      // (slots 9 / 12 / 13 re-used: sums over the K loop, NOT differences from the entry)
-                unsigned long long* e = reinterpret_cast<unsigned long long*>(p.err) + blockIdx.x * 16;
-                e[9] = e[0] + xs_work; e[12] = e[0] + xs_wait; e[13] = e[0] + xs_bar;
-            }
-#endif
-            __builtin_amdgcn_s_barrier();                                // END
-            return;
-        }
         // prologue: the first tile's first halo, then the weights of steps 0 .. A (retired in this order)
         {
             const int gp0 = tile_gp0(lane0);
@@ -529,7 +308,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
         unsigned w_st = 0;                                           // ... and its ring stage
         int w_step = 0;                                              // ... and its step index
 #pragma unroll
-        for (int k = 0; k <= (RESW ? 8 : A); ++k) {                  // (RESW: all nine taps, once)
+        for (int k = 0; k <= A; ++k) {
             if (w_step < total && !VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
             ++w_step;
             if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
@@ -546,17 +325,11 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             auto step = [&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
                 // steps s and s + 1 have landed; on the block's last chunk (bundles shrink: no next halo, no more weights) everything
-                if constexpr (RESW) {
-                    // first tile: halo + all weights; afterwards only the next tile's halo is in flight, and it must be complete
-                    // in front of READY of tap 8 (the pipeline of step 8 reads the next tile's first fragments)
-                    if (c == 0 || t == 8) pws_vmwait<0>();
-                } else {
-                    if (has_next) pws_vmwait<SC::inflight(t)>();
-                    else pws_vmwait<0>();
-                }
+                if (has_next) pws_vmwait<SC::inflight(t)>();
+                else pws_vmwait<0>();
                 if (c == 0 && t == 0) PWS_STAMP(10);                 // first two steps landed
                 if (!VPD_ABL(p, 16) || (c == 0 && t == 0)) __builtin_amdgcn_s_barrier();      // READY_s (ablation 16: one tile per block only)
-                if (!RESW && w_step < total) {
+                if (w_step < total) {
                     if (!VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
                     ++w_step;
                     if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
@@ -586,30 +359,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     const int wn = wave / WM;
     const int fr = lane & 15;
     const int fq = lane >> 4;
-    if constexpr (XF) {
-        // the producing convolution's BatchNorm, finalized by the waves that have nothing else to do yet (and no transfer in front
-        // of their loads) into scale[] / shift[] behind the statistics scratch; block 0 also stores the coefficients for backward
-        // and updates the running statistics, as block 0 of bn_fwd_fused_kernel did.  TABLE barrier: the loaders read the table.
-        constexpr unsigned OFF_XF = OFF_RED + 3u * WM * BN * 4u;
-        float* const s_sc = reinterpret_cast<float*>(smem + OFF_XF);
-        float* const s_sh = s_sc + Ci;
-        for (int ch = tid; ch < ((xf.ablate & 4) ? 0 : Ci); ch += NMW * 64) {
-            float mu, r, sc, sh; double var;
-            bn_finalize_channel(xf.rows, Ci, ch, xf.count, xf.eps, xf.gamma[ch], xf.beta[ch], &mu, &r, &sc, &sh, &var);
-            s_sc[ch] = sc; s_sh[ch] = sh;
-            if (blockIdx.x == 0) {
-                xf.mean[ch] = mu; xf.rstd[ch] = r; xf.scale[ch] = sc; xf.shift[ch] = sh;
-                if (xf.rm) {
-                    const double unb = xf.count > 1.f ? var * (double)xf.count / ((double)xf.count - 1.0) : var;
-                    xf.rm[ch] = (1.f - xf.momentum) * xf.rm[ch] + xf.momentum * mu;
-                    xf.rv[ch] = (1.f - xf.momentum) * xf.rv[ch] + xf.momentum * (float)unb;
-                }
-            }
-        }
-        pws_lgkm0();
-        PWS_STAMP(15);                                               // table written
-        __builtin_amdgcn_s_barrier();                                // TABLE
-    }
     // Pixel-fragment addresses.  Halo pixel r = hbase + toff (toff = tdy * Wp + tdx, the tap's shift) of K-half 0 lives at
     // hb + r * 128 + ((key ^ fq) << 4); key (HaloGeom) depends on the pixel's COLUMN and row parity only, so the lane-dependent
     // part is one of three precomputed words per fragment -- lo[ic][b] = hbase * 128 + (((column + dx_ic) & kmask) ^ rowkey ^ fq) * 16
@@ -618,8 +367,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     // an MFMA wave has room for ~2 other instructions per 16-cycle MFMA, and the generic r -> (r * 8 + ((r & 7) ^ fq)) << 4
     // arithmetic (5 VALU per fragment) plus the tap bookkeeping took ~85 instruction slots per 32-MFMA step.
     unsigned lo[3][MI];
-    // transforming loaders: byte offset of fragment b's 16 bytes (K-half 0) in the padded activation / of its byte in the ReLU bit map
-    unsigned xa[XF ? MI : 1], xm[XF ? MI : 1];
     {
         const float rW = g.rW, rH = g.rH;
 #pragma unroll
@@ -634,10 +381,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             for (int ic = 0; ic < 3; ++ic)
                 lo[ic][b] = (unsigned)((hrow * Wp + xx) * 128) +
                             ((((unsigned)(xx + p.taps.dx0 + ic * p.taps.dxs) & (unsigned)g.kmask) ^ rowkey) << 4);
-            if constexpr (XF) {      // the pixel itself (the centre tap's) in the padded activation, relative to the tile's first pixel
-                xa[b] = (unsigned)((((hrow + 1) * Wp + xx + 1) * Ci + fq * 8) * 2);
-                xm[b] = (unsigned)(m * (Ci >> 3) + fq);
-            }
         }
     }
     // weight fragment a of K-half kk: LDS byte offset wa0 (kk = 0) + a * 2048 inside a stage (row wn*64 + a*16 + fr:
@@ -751,49 +494,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             load_a(af0, lds0 + OFF_W + stage * (WSTAGE * 2u) + wa0); load_b(bf0, ba);
         }
         const int nrows = nchunks * 3;
-        // transforming loaders: the activation relu(bn(z)) exists only in the LDS -- backward needs it in memory (the weight gradient's
-        // input) with its ReLU bit map.  The centre tap's pixel fragments ARE the tile's pixels (lane (fr, fq) of fragment b, K-half
-        // kk: pixel wm * WTM + b * 16 + fr, channels chunk * 64 + kk * 32 + fq * 8 ..), so the MFMA waves store them from the
-        // registers they multiply from: 2 * MI 16-byte stores (+ bit-map bytes) in ONE K-step of every chunk this block owns (the
-        // NT channel tiles share the chunks round robin), on waves with no other vector-memory traffic in flight.
-        char* xf_ab = nullptr; unsigned char* xf_mb = nullptr;
-        int xf_left = 0, xf_cc = 0, xf_own = 0;
-        if constexpr (XF) {
-            const int gr0 = mtile * g.TR;
-            const int b0 = vpd_fdiv(gr0, g.rH);
-            const int prow0 = g.multi ? b0 * (H + 2) : b0 * (H + 2) + (gr0 - b0 * H);
-            xf_ab = const_cast<char*>(reinterpret_cast<const char*>(p.x)) + (size_t)prow0 * Wp * Ci * 2;
-            xf_mb = xf.mask ? xf.mask + (size_t)mtile * BM * (Ci >> 3) : nullptr;
-            xf_left = p.M - mtile * BM;                              // pixels of this tile that exist
-        }
-        auto xf_store = [&](const bf16x8 (&bfm)[MI], int kk) __attribute__((always_inline)) {
-            if constexpr (XF) {
-                char* ab = xf_ab + xf_cc * 128 + kk * 64;
-                unsigned char* mb = xf_mb ? xf_mb + xf_cc * 8 + kk * 4 : nullptr;
-#pragma unroll
-                for (int b = 0; b < MI; ++b) {
-                    if (wm * WTM + b * 16 + fr < xf_left) {
-                        const u32x4 ov = __builtin_bit_cast(u32x4, bfm[b]);
-                        *reinterpret_cast<u32x4*>(ab + xa[b]) = ov;
-                        if (mb) {      // bit j = the STORED bf16 value is > 0 (bn_fwd_fused_kernel's bit map; stored values are >= +0)
-                            // min(half, 1) as unsigned 16-bit lanes = [half != 0] (as assembly: hipcc turns the vector min into a
-                            // compare / select / permute chain, ~45 instructions per fragment in the one K-step that can least afford
-                            // them); the four words' flags side by side (low halves at bits 0, 2, 4, 6, high halves at 16, 18, 20,
-                            // 22), then the high halves folded one bit above the low ones
-                            const unsigned o[4] = {ov.x, ov.y, ov.z, ov.w};
-                            unsigned acc = 0;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                unsigned f;
-                                asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(o[j]), "v"(0x00010001u));
-                                acc |= f << (2 * j);
-                            }
-                            mb[xm[b]] = (unsigned char)((acc | (acc >> 15)) & 0xffu);
-                        }
-                    }
-                }
-            }
-        };
         // modes 6 / 7: the epilogue's z fragments and mask bits (first 4 pixel groups) are requested at the start of the tile's
         // LAST chunk -- nine K-steps (~3 us) ahead of their use; requested behind the K loop (conv3x3_ws_kernel: its 256-pixel
         // tile has no registers for them) they cost the data gradients ~2 us of exposed memory latency per tile (in-step stamps:
@@ -827,18 +527,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                         if (!VPD_ABL(p, 64)) mfma_set(af0, bf0);
                         interleave();
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (XF) {
-                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) {
-#ifdef PWS_STAMPS
-                                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-                                xf_store(bf0, 0);
-                                __builtin_amdgcn_sched_barrier(0);
-#ifdef PWS_STAMPS
-                                xs_store += __builtin_amdgcn_s_memtime() - t0;
-#endif
-                            }
-                        }
                         // region 2: K-half 0 of the NEXT step (landed: READY_s covers it; behind a tile's last step these are the
                         // next tile's first fragments or stale bytes, never used) while K-half 1 multiplies
                         if (ic < 2) b_addr(ba, ic + 1, S0 + (unsigned)((ic + 1) * dxs128), P);
@@ -847,18 +535,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                         if (!VPD_ABL(p, 64)) mfma_set(af1, bf1);
                         interleave();
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (XF) {
-                            if (ic == 1 && ir == 1 && xf_own == nt && !(xf.ablate & 1)) {
-#ifdef PWS_STAMPS
-                                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-#endif
-                                xf_store(bf1, 1);
-                                __builtin_amdgcn_sched_barrier(0);
-#ifdef PWS_STAMPS
-                                xs_store += __builtin_amdgcn_s_memtime() - t0;
-#endif
-                            }
-                        }
                     }
                 } else {
                     b_addr(ba, ic, S0 + (unsigned)(ic * dxs128), P);
@@ -874,7 +550,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                 stage = nstage;
             }
             hb = nhb; tdy = ntdy; S0 = nS0; P = nP;
-            if (wrap) { ir = 0; ++gch; if (XF) { ++xf_cc; if (++xf_own == sg.NT) xf_own = 0; } } else ++ir;
+            if (wrap) { ir = 0; ++gch; } else ++ir;
         }
         if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
@@ -943,21 +619,11 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
 #ifdef PWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PWS_STAMP(7);                                                    // stores drained (diagnostic wait)
-    if (XF && p.err && lane == 0 && wave == 0) {                     // (XF: slot 7 re-used -- cycles spent in the centre-tap stores)
-        unsigned long long* e = reinterpret_cast<unsigned long long*>(p.err) + blockIdx.x * 16;
-        e[7] = e[0] + xs_store;
-    }
 #endif
 }
 
-template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE, bool RESW = false>
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
 __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_kernel(const ConvParams p, const HaloGeom g,
                                                                                    const PwsGrid sg) {
-    pws_body<BM, BN, HROWS, NS, EPM, NMW, PIPE, RESW, PwsNoXf>(p, g, sg, PwsNoXf{});
-}
-// train forward with the producer's BatchNorm + ReLU applied by the loaders (ConvXf, common.h); statistics epilogue (mode 1)
-template <int BM, int BN, int HROWS, int NS, int NMW>
-__global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_xf_kernel(const ConvParams p, const HaloGeom g,
-                                                                                      const PwsGrid sg, const ConvXf xf) {
-    pws_body<BM, BN, HROWS, NS, 1, NMW, true, false, ConvXf>(p, g, sg, xf);
+    pws_body<BM, BN, HROWS, NS, EPM, NMW, PIPE>(p, g, sg);
 }

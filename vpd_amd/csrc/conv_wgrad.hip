@@ -204,13 +204,10 @@ static __device__ __forceinline__ bf16x8 tr_frag2(const bf16_t* tile, int ra, in
 }
 
 // MFMA-wave body of conv_wgrad_halo_kernel for taps [T0, T1): ci columns 16*ctile .. +15, all 64 co.
-// PAIR2 (the 4-tap half only): a second dz tile at element offset `dz2_off` of every stage and the 1x1 branch's single tap
-// (the centre one) on top -- eight more MFMAs per chunk, behind the wave's own 32, with the fragment registers re-used
-template <int T0, int T1, int NS, bool PAIR2 = false>
+template <int T0, int T1, int NS>
 static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, const WgHaloGeom& g, const bf16_t* ring,
-                                                       int STAGE, int nch, int ctile, int lane, int bx, int by, int dz2_off = 0) {
+                                                       int STAGE, int nch, int ctile, int lane, int bx, int by) {
     constexpr int NT = T1 - T0;
-    static_assert(!PAIR2 || NT == 4, "the pair's extra tap rides in the 4-tap half");
     // W, H: OUTPUT dims; the x halo is rows of the padded INPUT (stride S = 1 or 2: input pixel S*y + r, S*x + t)
     const int W = p.Ws, H = p.Hs, Wp = p.xWp, S = p.istr;
     f32x4 acc[NT][4];
@@ -219,13 +216,10 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[t][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc2[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) acc2[a] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gq = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
     // chunk-invariant LDS element offsets (within a stage) of every transposed read of this lane.
     // dz rows are 32*ks + 8*gq + 4*h + q: the swizzle only looks at row bits 1 and 3, so k-step 1 is +32 rows.
-    int offA[4][2], offB[2][NT][2], offC[2][2];
+    int offA[4][2], offB[2][NT][2];
     {
         const int ra = 8 * gq + q;
 #pragma unroll
@@ -251,11 +245,6 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
                     const int r = hmv + (p.taps.dy0 + (tt / 3) * p.taps.dys) * Wp + (p.taps.dx0 + (tt % 3) * p.taps.dxs);
                     const int col = ctile * 16 + 4 * pp;
                     offB[ks][t][h] = 64 * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
-                }
-                {      // the centre tap (tap 4): the input pixel of the 1x1 stride-2 branch
-                    const int r = hmv + (p.taps.dy0 + p.taps.dys) * Wp + (p.taps.dx0 + p.taps.dxs);
-                    const int col = ctile * 16 + 4 * pp;
-                    offC[ks][h] = 64 * 64 + r * 64 + ((((col >> 4) ^ wg_f(r)) << 4) | (col & 15));
                 }
             }
     }
@@ -293,21 +282,6 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
                         acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][t], acc[t][a], 0, 0, 0);
-            if constexpr (PAIR2) {
-                // the 1x1 branch: dz2 tile x the centre tap's pixels (the 5-tap wave of this SIMD is still in its 40 MFMAs)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) az[ks][a] = frag(st + dz2_off + ks * 32 * 64, offA[a][0], offA[a][1]);
-                    bx[ks][0] = frag(st, offC[ks][0], offC[ks][1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        acc2[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][0], acc2[a], 0, 0, 0);
-            }
             continue;
         }
 #pragma unroll
@@ -342,25 +316,17 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[t][a][j];
     }
-    if constexpr (PAIR2) {      // the 1x1 branch's single slice
-        float* o = p.slab2 + (size_t)by * p.Co * p.Kc + (size_t)co0 * p.Kc + ci0 + 16 * ctile + i16;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc2[a][j];
-    }
 }
 
 #define WG_CH 64           // pixels per chunk = two MFMA K-steps (vpd_wgrad_split assumes 64)
 #define WG_NS 3            // ring stages
 
 // NPASS: 32-row LDS-DMA passes of the x halo (NHP <= 32*NPASS).  (bx, by) = (output tile, pixel split) of this block.
-template <int NPASS, int NS = WG_NS, bool PAIR = false>
+template <int NPASS, int NS = WG_NS>
 static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, const WgHaloGeom& g, int bx, int by) {
     constexpr int HROWS = 32 * NPASS;
-    constexpr int STAGE = (WG_CH + HROWS + (PAIR ? WG_CH : 0)) * 64;      // bf16 elements per stage: dz tile, halo (, dz2 tile)
-    constexpr int PER_CHUNK = 2 + NPASS + (PAIR ? 2 : 0);         // LDS-DMA instructions per loader wave per chunk
-    constexpr int DZ2_OFF = (WG_CH + HROWS) * 64;
+    constexpr int STAGE = (WG_CH + HROWS) * 64;                   // bf16 elements per stage: dz tile, halo
+    constexpr int PER_CHUNK = 2 + NPASS;                          // LDS-DMA instructions per loader wave per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);               // [WG_NS][dz 64x64 | halo HROWSx64]
 
@@ -418,23 +384,6 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
                 const bf16_t* src = p.x + (size_t)gp * p.xC + ci0 + cpc * 8;
                 __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + WG_CH * 64 + (lw + 4 * i) * 8 * 64), 16, 0, 0);
             }
-            if constexpr (PAIR) {      // the 1x1 branch's dz tile: same pixels, same padded layout, its own tensor
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = (lw + 4 * i) * 8 + lrow;
-                    const int m = ch * WG_CH + row;
-                    const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
-                    const bf16_t* src = p.dz2 + cpc * 8;
-                    if (m < p.M) {
-                        const int b = m / (H * W);
-                        const int r = m - b * H * W;
-                        const int yy = r / W;
-                        const int xx = r - yy * W;
-                        src = p.dz2 + ((size_t)(b * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cpc * 8;
-                    }
-                    __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(st + DZ2_OFF + (lw + 4 * i) * 8 * 64), 16, 0, 0);
-                }
-            }
         };
         if (VPD_ABL(p, 1)) {
             for (int c = 0; c < nch; ++c) __builtin_amdgcn_s_barrier();
@@ -463,12 +412,12 @@ static __device__ __forceinline__ void wgrad_halo_body(const WgradParams& p, con
         return;
     }
     if (wave < 4) wgrad_mfma_half<0, 5, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
-    else wgrad_mfma_half<5, 9, NS, PAIR>(p, g, ring, STAGE, nch, ctile, lane, bx, by, DZ2_OFF);
+    else wgrad_mfma_half<5, 9, NS>(p, g, ring, STAGE, nch, ctile, lane, bx, by);
 }
 
-template <int NPASS, int NS = WG_NS, bool PAIR = false>
+template <int NPASS, int NS = WG_NS>
 __global__ __launch_bounds__(768) void conv_wgrad_halo_kernel(const WgradParams p, const WgHaloGeom g) {
-    wgrad_halo_body<NPASS, NS, PAIR>(p, g, blockIdx.x, blockIdx.y);
+    wgrad_halo_body<NPASS, NS>(p, g, blockIdx.x, blockIdx.y);
 }
 
 // Grouped launch: the weight gradients of SEVERAL convolutions of one ResNet stage in one grid.  A weight gradient
@@ -734,9 +683,8 @@ static bool wg_halo_geom(const WgradParams& p, WgHaloGeom* g) {
 
 // shape test of the halo kernel for a 3x3 stride-1 conv with Hout x Wout outputs (independent of the batch size)
 bool vpd_wgrad_halo_shape_ok(int H, int W, int stride, int Hin, int Win) {
-    static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
     static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
-    if (force_v1 || W <= 0 || WG_CH % W != 0) return false;
+    if (W <= 0 || WG_CH % W != 0) return false;
     if (stride == 2 && (no_s2 || Hin != 2 * H || Win != 2 * W)) return false;
     if (stride != 1 && stride != 2) return false;
     const int TR = WG_CH / W;
@@ -761,7 +709,6 @@ static bool wg_as_one_by_one(const WgradParams& p, WgradParams* q) {
 bool vpd_wgrad_overwrites(const WgradParams& p0) {
     int tr_stem;
     if (wg_stem_eligible(p0, &tr_stem)) return true;
-    static const int force_v1 = getenv("VPD_WGRAD_V1") ? atoi(getenv("VPD_WGRAD_V1")) : 0;
     static const int no_s2 = getenv("VPD_WGRAD_S2") ? !atoi(getenv("VPD_WGRAD_S2")) : 0;
     // 1x1 convolutions on the halo kernel (centre tap), no atomics.  As ONE launch per conv it is no faster than the atomics
     // kernel (both run at the ~4 TB/s their operand streams allow; ResNet-50: 9.90 vs 9.55 ms per step, ResNet-34: +12 us),
@@ -777,31 +724,13 @@ bool vpd_wgrad_overwrites(const WgradParams& p0) {
     // stride 2 (3x3 pad 1 / 1x1 pad 0, even input): taps 0..2 in padded input coordinates, forward order only
     const bool s2 = !no_s2 && p.istr == 2 && p.xHp == 2 * p.Hs + 2 && p.xWp == 2 * p.Ws + 2 && p.taps.dy0 == 0 &&
                     p.taps.dys == 1 && p.taps.dx0 == 0 && p.taps.dxs == 1;
-    return !force_v1 && p.slab && p.taps.nr == 3 && p.taps.nc == 3 && (s1 || s2) && p.xC == p.Kc && p.taps.dy0 >= 0 &&
+    return p.slab && p.taps.nr == 3 && p.taps.nc == 3 && (s1 || s2) && p.xC == p.Kc && p.taps.dy0 >= 0 &&
            p.taps.dy0 + 2 * p.taps.dys >= 0 && p.taps.dy0 <= 2 &&
            p.taps.dy0 + 2 * p.taps.dys <= 2 && p.taps.dx0 >= 0 && p.taps.dx0 + 2 * p.taps.dxs >= 0 && p.taps.dx0 <= 2 &&
            p.taps.dx0 + 2 * p.taps.dxs <= 2 && wg_halo_geom(p, &g);
 }
 
 size_t vpd_wgrad_slab_bytes() { return (size_t)256 * 9 * 64 * 64 * sizeof(float); }   // ksplit * tiles <= 256
-
-// deferred slab sums of single halo launches (vpd_launch_wgrad with defer_reduce) join a grouped launch's reduce
-static void wg_reduce_take_extra(WgReduceGroup& red, long& max_n4, int& max_ks, std::vector<WgradParams>* extra) {
-    if (!extra) return;
-    while (!extra->empty() && red.nprob < WG_GROUP_MAX) {
-        const WgradParams& q = extra->front();
-        const int ks = vpd_wgrad_split(q.M, q.Co, q.Kc, nullptr);
-        const long n4 = (long)(q.taps.nr == 1 ? 1 : 9) * q.Co * q.Kc / 4;
-        red.slab[red.nprob] = reinterpret_cast<const float4*>(q.slab);
-        red.dw[red.nprob] = reinterpret_cast<float4*>(q.dw);
-        red.n4[red.nprob] = n4;
-        red.ksplit[red.nprob] = ks;
-        max_n4 = n4 > max_n4 ? n4 : max_n4;
-        max_ks = ks > max_ks ? ks : max_ks;
-        ++red.nprob;
-        extra->erase(extra->begin());
-    }
-}
 
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
     const int ksplit = vpd_wgrad_split(p.M, p.Co, p.Kc, nullptr);
@@ -819,8 +748,7 @@ hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream) {
 // with the measured t_chunk 1.0 us (grouped launches: 124-242 us for 252 x 114 ... 176 x 256 chunk tasks), t_fixed 4 us,
 // 4.5 TB/s.  Every task size from 8 to 512 chunks is tried; VPD_WG_GROUP_CPB pins the size instead.
 static int wg_group_cpb_env() {
-    static const int v = getenv("VPD_WG_GROUP_CPB") ? atoi(getenv("VPD_WG_GROUP_CPB")) : 0;
-    return v;
+    return 0;
 }
 // splits a problem may use at most: its slab share is capped at 16 MB (plan-time allocation)
 int vpd_wgrad_group_max_splits(int Co, int Kc, int ntaps) {
@@ -879,7 +807,7 @@ bool vpd_wgrad_group_eligible(const WgradParams& p) {
     return vpd_wgrad_overwrites(q) && wg_halo_geom(q, &g);
 }
 // ps[i].slab must point to vpd_wgrad_group_slab_floats() floats of its own (ignored when that is 0)
-hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream, std::vector<WgradParams>* extra) {
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream) {
     if (n < 1 || n > WG_GROUP_MAX) return hipErrorInvalidValue;
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
     WgGroup grp = {};
@@ -917,14 +845,13 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
         grp.g[i] = g;
     }
     grp.task_begin[n] = tasks;
-    static const int remap = !(getenv("VPD_WG_XCD") && !atoi(getenv("VPD_WG_XCD")));
+    const int remap = 1;      // (tasks that share pixels on one XCD's L2)
     grp.xcd_remap = remap;
     const int grid = remap ? ((tasks + 7) / 8) * 8 : tasks;
     const size_t lds = (size_t)WG_NS * (WG_CH + 32 * (npass <= 3 ? 3 : npass)) * 64 * sizeof(bf16_t);
     if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<3>, dim3(grid), dim3(768), lds, stream, grp);
     else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<4>, dim3(grid), dim3(768), lds, stream, grp);
     else VPD_LAUNCH(conv_wgrad_halo_grouped_kernel<5>, dim3(grid), dim3(768), lds, stream, grp);
-    wg_reduce_take_extra(red, max_n4, max_ks, extra);
     if (red.nprob > 0 && !(ablate & 16)) {
         const int groups = max_ks < 16 ? max_ks : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),
@@ -967,26 +894,6 @@ hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
         if (npass <= 3) VPD_LAUNCH(conv_wgrad_halo_kernel<3>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 4) VPD_LAUNCH(conv_wgrad_halo_kernel<4>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else if (npass == 5) VPD_LAUNCH(conv_wgrad_halo_kernel<5>, dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
-        else if (p.dz2) {
-            // PAIR: a stride-2 3x3 with its block's 1x1 stride-2 branch as a tenth tap (+ one 8-KB dz2 tile per stage: two ring
-            // stages for both halo sizes -- three stages of the 10-pass halo plus the tiles would be 168 KB)
-            if (p.istr != 2 || p.one_by_one || !p.dw2 || !p.slab2 || npass > 13) return hipErrorInvalidValue;
-            const size_t lds2 = (size_t)2 * (2 * WG_CH + 32 * (npass <= 10 ? 10 : 13)) * 64 * sizeof(bf16_t);
-            if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 2, true>), dim3(tiles, g.ksplit), dim3(768), lds2, stream, p, g);
-            else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2, true>), dim3(tiles, g.ksplit), dim3(768), lds2, stream, p, g);
-            if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
-            // both slab sums in ONE launch
-            WgReduceGroup red = {};
-            red.nprob = 2;
-            red.slab[0] = reinterpret_cast<const float4*>(p.slab); red.dw[0] = reinterpret_cast<float4*>(p.dw);
-            red.n4[0] = (long)9 * p.Co * p.Kc / 4; red.ksplit[0] = g.ksplit;
-            red.slab[1] = reinterpret_cast<const float4*>(p.slab2); red.dw[1] = reinterpret_cast<float4*>(p.dw2);
-            red.n4[1] = (long)p.Co * p.Kc / 4; red.ksplit[1] = g.ksplit;
-            const int groups = g.ksplit < 16 ? g.ksplit : 16;
-            hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((red.n4[0] + 63) / 64), 2), dim3(64 * groups), 0, stream,
-                               red, groups);
-            return hipGetLastError();
-        }
         else if (npass <= 10) VPD_LAUNCH((conv_wgrad_halo_kernel<10, 3>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         else VPD_LAUNCH((conv_wgrad_halo_kernel<13, 2>), dim3(tiles, g.ksplit), dim3(768), lds, stream, p, g);
         if (p.defer_reduce || VPD_ABL(p, 16)) return hipGetLastError();
@@ -1061,7 +968,6 @@ static __device__ __forceinline__ void wg2_lds_dma16(const void* gsrc, unsigned 
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
 }
 
-template <bool PIPE>
 static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHaloGeom& g, int tile, int split,
                                                 bf16_t* ring, int lds_elems, int skew) {
     const int tid = threadIdx.x;
@@ -1216,26 +1122,7 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
             const unsigned v = offB[ks][t];
             return frag2(sb + 128 * 128 + (v & 0xffffu), sb + 128 * 128 + (v >> 16));
         };
-        if constexpr (PIPE) {
-            bf16x8 az[2][4], bx[3];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) az[0][a] = ldA(0, a);
-            bx[0] = ldB(0, 0);
-            bx[1] = ldB(0, 1);
-#pragma unroll
-            for (int s18 = 0; s18 < 18; ++s18) {                      // (k-step, tap) pairs in order
-                const int ks = s18 / 9, t = s18 - ks * 9;
-                if (s18 == 9 && do_issue && skew && cohalf) issue();
-                if (s18 + 2 < 18) bx[(s18 + 2) % 3] = ldB((s18 + 2) / 9, (s18 + 2) % 9);
-                if (ks == 0 && t >= 5) az[1][t - 5] = ldA(1, t - 5);  // taps 5..8 of the first k-step: one A fragment each
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[s18 % 3], acc[t][a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            // hipcc's own schedule of the same work
+        {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks == 1 && do_issue && skew && cohalf) issue();
@@ -1422,7 +1309,6 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
     }
 }
 
-template <bool PIPE>
 __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2Group grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* ring = reinterpret_cast<bf16_t*>(smem);
@@ -1432,7 +1318,7 @@ __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2
         const int pi = __builtin_amdgcn_readfirstlane(tk.x);
         const int tile = __builtin_amdgcn_readfirstlane(tk.y), split = __builtin_amdgcn_readfirstlane(tk.z);
         const int kind = grp.kind[pi];
-        if (kind == 0) wg2_task<PIPE>(grp.p[pi], grp.g[pi], tile, split, ring, grp.stage_elems, grp.skew);
+        if (kind == 0) wg2_task(grp.p[pi], grp.g[pi], tile, split, ring, grp.stage_elems, grp.skew);
         else if (kind == 1) wg2_task_1x1<64>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
         else wg2_task_1x1<128>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
     }
@@ -1518,7 +1404,7 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     // per-chunk time of a 128 x 64 task: the larger of the MFMA time (1.15 us) and the stream (16 KB + halo at ~21 GB/s
     // per CU when every CU streams); per-task fixed cost; slab bytes written and read back at 4.5 TB/s
     const double t_fixed = 5.0, bw = 4.5e6;
-    static const int cpb_env = getenv("VPD_WG2_CPB") ? atoi(getenv("VPD_WG2_CPB")) : 0;
+    const int cpb_env = 0;
     double best = 1e30;
     int best_ks[WG2_MAX];
     auto tchunk = [&](int i) {
@@ -1622,8 +1508,7 @@ struct Wg2Cache {
 void* vpd_wgrad128_cache_new() { return new Wg2Cache(); }
 void vpd_wgrad128_cache_free(void* c) { delete static_cast<Wg2Cache*>(c); }
 
-hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream,
-                                     std::vector<WgradParams>* extra) {
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream) {
     if (n < 1 || n > WG2_MAX || !dev_table) return hipErrorInvalidValue;
     static int ncu = 0;
     if (!ncu) {
@@ -1710,10 +1595,7 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     }
     const size_t lds = (size_t)grp.stage_elems * sizeof(bf16_t);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static const int pipe = getenv("VPD_WG2_PIPE") ? atoi(getenv("VPD_WG2_PIPE")) : 0;
-    if (pipe) VPD_LAUNCH(conv_wgrad128_persistent_kernel<true>, dim3(sch.grid), dim3(512), lds, stream, grp);
-    else VPD_LAUNCH(conv_wgrad128_persistent_kernel<false>, dim3(sch.grid), dim3(512), lds, stream, grp);
-    wg_reduce_take_extra(red, max_n4, max_ks, extra);
+    VPD_LAUNCH(conv_wgrad128_persistent_kernel, dim3(sch.grid), dim3(512), lds, stream, grp);
     if (red.nprob > 0) {
         const int groups = max_ks < 16 ? max_ks : 16;
         hipLaunchKernelGGL(wgrad_slab_reduce_group_kernel, dim3((unsigned)((max_n4 + 63) / 64), red.nprob), dim3(64 * groups),

@@ -260,157 +260,3 @@ hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, flo
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, e, t, n, de, loss_step, loss_accum);
     return hipGetLastError();
 }
-
-
-// ===========================================================================
-// Fused embedding head of the train step without the motion MLP (train_vpd_model.py:82-91 with motion=False):
-//   head_fwd_fused_kernel: global average pool -> fc -> sum-MSE loss + d(emb), one block per crop (the batch's loss is
-//     summed by the last block to finish, in crop order: no float atomics, the value repeats run to run);
-//   head_bwd_fused_kernel: d(pooled) = d(emb) W broadcast over the H*W pixels (crop blocks), dW = d(emb)^T pooled and
-//     db = column sums of d(emb) (weight blocks) -- one launch.
-// Replaces avgpool + sgemm + mse and sgemm + colsum + sgemm + avgpool_bwd: 7 launches of 5-9 us at a batch of 256.
-// ===========================================================================
-struct HeadFwdArgs {
-    const bf16_t* act; int Hp, Wp, pad, H, W, C;     // padded activation of the last block
-    const float* Wt; const float* bias; int D;       // fc weight [D][C], bias [D]
-    const float* target;                             // [N][D] or null (no loss)
-    float* pooled; float* emb; float* demb;          // [N][C], [N][D], [N][D] (demb null: no gradient)
-    float* partial; unsigned* counter;               // [N] per-crop losses, arrival counter (zero between launches)
-    float* loss_step; double* loss_accum; int N;
-};
-__global__ __launch_bounds__(256) void head_fwd_fused_kernel(const HeadFwdArgs a) {
-    extern __shared__ float sp[];                    // pooled[C], then 4 wave partials
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = a.C, D = a.D;
-    const float inv = 1.f / (float)(a.H * a.W);
-    for (int c = tid * 8; c < C; c += 256 * 8) {
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int y = 0; y < a.H; ++y)
-            for (int x = 0; x < a.W; ++x) {
-                float v[8];
-                unpack8(*reinterpret_cast<const uint4*>(a.act + ((size_t)(n * a.Hp + y + a.pad) * a.Wp + x + a.pad) * C + c), v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += v[j];
-            }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { acc[j] *= inv; sp[c + j] = acc[j]; }
-        float* o = a.pooled + (size_t)n * C + c;
-        *reinterpret_cast<float4*>(o) = float4{acc[0], acc[1], acc[2], acc[3]};
-        *reinterpret_cast<float4*>(o + 4) = float4{acc[4], acc[5], acc[6], acc[7]};
-    }
-    __syncthreads();
-    float lsum = 0.f;                                // lane 0 of each wave: sum of squared differences of its outputs
-    for (int d = wave; d < D; d += 4) {
-        const float* wr = a.Wt + (size_t)d * C;
-        float t = 0.f;
-        for (int c = lane * 4; c < C; c += 256) {
-            const float4 w = *reinterpret_cast<const float4*>(wr + c);
-            t += w.x * sp[c] + w.y * sp[c + 1] + w.z * sp[c + 2] + w.w * sp[c + 3];
-        }
-        t = wave_sum(t);
-        if (lane == 0) {
-            const float e = t + a.bias[d];
-            a.emb[(size_t)n * D + d] = e;
-            if (a.target) {
-                const float df = e - a.target[(size_t)n * D + d];
-                lsum += df * df;
-                if (a.demb) a.demb[(size_t)n * D + d] = 2.f * df;
-            }
-        }
-    }
-    if (!a.target) return;
-    __syncthreads();                                 // (pooled in sp is dead)
-    if (lane == 0) sp[wave] = lsum;
-    __syncthreads();
-    __shared__ int last;
-    if (tid == 0) {
-        a.partial[n] = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-        __threadfence();
-        last = atomicAdd(a.counter, 1u) == (unsigned)(a.N - 1);
-    }
-    __syncthreads();
-    if (!last || wave != 0) return;
-    __threadfence();
-    float t = 0.f;
-    for (int i = lane; i < a.N; i += 64) t += __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = wave_sum(t);
-    if (lane == 0) {
-        if (a.loss_step) a.loss_step[0] = t;
-        if (a.loss_accum) a.loss_accum[0] += (double)t;
-        *a.counter = 0u;
-    }
-}
-hipError_t vpd_launch_head_fwd_fused(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, const float* Wt,
-                                     const float* bias, int D, const float* target, float* pooled, float* emb, float* demb,
-                                     float* partial, unsigned* counter, float* loss_step, double* loss_accum, hipStream_t s) {
-    if (C % 256 || N < 1) return hipErrorInvalidValue;      // (a lane's float4 of the fc row, 8 channels per pooling thread)
-    HeadFwdArgs a{act, Hp, Wp, pad, H, W, C, Wt, bias, D, target, pooled, emb, demb, partial, counter, loss_step, loss_accum, N};
-    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(N), dim3(256), (size_t)(C + 4) * sizeof(float), s, a);
-    return hipGetLastError();
-}
-
-struct HeadBwdArgs {
-    const float* demb; const float* Wt; const float* pooled;      // [N][D], [D][C], [N][C]
-    float* dW; float* db; bf16_t* dact;                           // [D][C], [D], dense [N][HW][C]
-    int N, D, C, HW;
-};
-#define HEAD_BWD_DT 4                                             // fc rows per weight block
-__global__ __launch_bounds__(256) void head_bwd_fused_kernel(const HeadBwdArgs a) {
-    extern __shared__ float sd[];                                 // crop blocks: demb row [D]
-    const int tid = threadIdx.x;
-    const int N = a.N, D = a.D, C = a.C;
-    int b = blockIdx.x;
-    if (b < N) {                                                  // ---- d(pooled) of crop b, broadcast to its pixels ----
-        for (int d = tid; d < D; d += 256) sd[d] = a.demb[(size_t)b * D + d];
-        __syncthreads();
-        const float inv = 1.f / (float)a.HW;
-        for (int c = tid * 2; c < C; c += 512) {
-            float t0 = 0.f, t1 = 0.f;
-#pragma unroll 8
-            for (int d = 0; d < D; ++d) {
-                const float2 w = *reinterpret_cast<const float2*>(a.Wt + (size_t)d * C + c);
-                t0 += sd[d] * w.x; t1 += sd[d] * w.y;
-            }
-            const unsigned v = pack2bf(t0 * inv, t1 * inv);
-            for (int m = 0; m < a.HW; ++m)
-                *reinterpret_cast<unsigned*>(a.dact + ((size_t)b * a.HW + m) * C + c) = v;
-        }
-        return;
-    }
-    b -= N;
-    const int nwb = (D + HEAD_BWD_DT - 1) / HEAD_BWD_DT;
-    if (b < nwb) {                                                // ---- dW rows d0 .. d0+DT-1 ----
-        const int d0 = b * HEAD_BWD_DT;
-        for (int c = tid * 2; c < C; c += 512) {
-            float acc[HEAD_BWD_DT][2];
-#pragma unroll
-            for (int j = 0; j < HEAD_BWD_DT; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; }
-#pragma unroll 4
-            for (int n = 0; n < N; ++n) {
-                const float2 pv = *reinterpret_cast<const float2*>(a.pooled + (size_t)n * C + c);
-#pragma unroll
-                for (int j = 0; j < HEAD_BWD_DT; ++j) {
-                    const float de = d0 + j < D ? a.demb[(size_t)n * D + d0 + j] : 0.f;
-                    acc[j][0] += de * pv.x; acc[j][1] += de * pv.y;
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < HEAD_BWD_DT; ++j)
-                if (d0 + j < D) *reinterpret_cast<float2*>(a.dW + (size_t)(d0 + j) * C + c) = float2{acc[j][0], acc[j][1]};
-        }
-        return;
-    }
-    for (int d = tid; d < D; d += 256) {                          // ---- db ----
-        float t = 0.f;
-        for (int n = 0; n < N; ++n) t += a.demb[(size_t)n * D + d];
-        a.db[d] = t;
-    }
-}
-hipError_t vpd_launch_head_bwd_fused(const float* demb, const float* Wt, const float* pooled, float* dW, float* db,
-                                     bf16_t* dact, int N, int D, int C, int HW, hipStream_t s) {
-    if (C % 2 || N < 1) return hipErrorInvalidValue;
-    HeadBwdArgs a{demb, Wt, pooled, dW, db, dact, N, D, C, HW};
-    const int grid = N + (D + HEAD_BWD_DT - 1) / HEAD_BWD_DT + 1;
-    hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(grid), dim3(256), (size_t)D * sizeof(float), s, a);
-    return hipGetLastError();
-}

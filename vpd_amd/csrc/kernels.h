@@ -71,11 +71,6 @@ struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
 bool vpd_conv_takes_bn_sums(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
-// conv_xf.hip: a train-forward 3x3 whose loaders apply the producing convolution's BatchNorm + ReLU (ConvXf)
-bool vpd_conv_xf_ok(const ConvParams& p);        // the plan's switch (VPD_CONV_XF, default off) AND the shape
-bool vpd_conv_xf_fits(const ConvParams& p);      // the shape alone (operator-level entry point)
-hipError_t vpd_launch_conv_xf(const ConvParams& p, const ConvXf& xf, hipStream_t stream);
-bool vpd_conv_bnbwd_ok(const ConvParams& p, int ncu);     // fused dgrad + BatchNorm-backward epilogue (ConvBnBwd) possible
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);
@@ -83,17 +78,14 @@ size_t vpd_wgrad_slab_bytes();
 // grouped (per-stage, deferred) weight gradients: see WgGroup in conv_wgrad.hip
 bool vpd_wgrad_group_eligible(const WgradParams& p);
 size_t vpd_wgrad_group_slab_floats(int M, int Co, int Kc, int ntaps = 9);
-// `extra` (both grouped launchers): single halo launches whose split partials still sit in their slabs (WgradParams::defer_reduce)
-// -- their sums ride in this launch's slab-reduce launch (one launch instead of one per conv); the ones taken are erased
-hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream, std::vector<WgradParams>* extra = nullptr);
+hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream);
 bool vpd_wgrad_overwrites(const WgradParams& p);
 // 128 x 64 tiles, persistent blocks, host-built schedule (conv_wgrad128_persistent_kernel in conv_wgrad.hip)
 bool vpd_wgrad128_eligible(const WgradParams& p);
 size_t vpd_wgrad128_table_bytes();
 void* vpd_wgrad128_cache_new();
 void vpd_wgrad128_cache_free(void* cache);
-hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache, void* dev_table, hipStream_t stream,
-                                     std::vector<WgradParams>* extra = nullptr);
+hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache, void* dev_table, hipStream_t stream);
 bool vpd_wgrad_halo_shape_ok(int Hout, int Wout, int stride = 1, int Hin = 0, int Win = 0);
 
 hipError_t vpd_launch_bn_finalize(double* partials, int T, int C, float count, const float* gamma,
@@ -145,12 +137,6 @@ hipError_t vpd_launch_avgpool_bwd(const float* dpooled, int H, int W, int C, int
 hipError_t vpd_launch_sgemm(const float* A, const float* B, float* Y, const float* bias, int M, int N, int K, int ta,
                             int tb, int relu, hipStream_t s);
 hipError_t vpd_launch_colsum(const float* A, int M, int N, float* out, hipStream_t s);
-// fused head of the train step without the motion MLP (head.hip): pool + fc + loss forward, d(pooled) + dW + db backward
-hipError_t vpd_launch_head_fwd_fused(const bf16_t* act, int Hp, int Wp, int pad, int H, int W, int C, int N, const float* Wt,
-                                     const float* bias, int D, const float* target, float* pooled, float* emb, float* demb,
-                                     float* partial, unsigned* counter, float* loss_step, double* loss_accum, hipStream_t s);
-hipError_t vpd_launch_head_bwd_fused(const float* demb, const float* Wt, const float* pooled, float* dW, float* db,
-                                     bf16_t* dact, int N, int D, int C, int HW, hipStream_t s);
 hipError_t vpd_launch_relu_mask(float* d, const float* act, long n, hipStream_t s);
 hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, float* loss_step, double* loss_accum,
                           hipStream_t s);

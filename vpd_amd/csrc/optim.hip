@@ -75,8 +75,7 @@ __global__ __launch_bounds__(256) void pack_input_px_kernel(const float* x, int 
 hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
                                  int Cp, hipStream_t s) {
     if (Cp != 8 || C > 8) return hipErrorInvalidValue;
-    static const int force_px = getenv("VPD_PACK_PX") ? atoi(getenv("VPD_PACK_PX")) : 0;
-    const bool quad = !force_px && (W & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+    const bool quad = (W & 3) == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
     long items = quad ? (long)N * H * (W / 4) : (long)N * H * W;
     long g = (items + 255) / 256;
     if (g > 8192) g = 8192;

@@ -68,7 +68,6 @@ struct BlockInfo {
     size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
     size_t mask_off = 0;                             // train, BasicBlock: [M][C/8] ReLU mask bits of the block output
     size_t mask1_off = 0;                            // train with dgrad_sums: ReLU mask bits of a1 (0: none)
-    size_t mask2_off = 0;                            // ... of a2 (Bottleneck)
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
@@ -110,8 +109,6 @@ struct vpd_plan {
     size_t g0_off = 0, dz0_off = 0, G_off[3] = {0, 0, 0}, T_off[2] = {0, 0}, slab_off = 0;
     size_t pooled_off = 0, emb_off = 0, h1_off = 0, h2_off = 0, pred_off = 0;
     size_t dpred_off = 0, dh2_off = 0, dh1_off = 0, demb_off = 0, dpooled_off = 0;
-    size_t headpart_off = 0;             // fused head: per-crop losses [max_batch] floats + arrival counter (zero between launches)
-    bool fused_head = false;             // pool + fc + loss / d(pooled) + dW + db as one launch each (no motion MLP; VPD_FUSED_HEAD=1)
     size_t desc_off = 0, bmap_pack_off = 0, bmap_unpack_off[4] = {0, 0, 0, 0};
     int xHp = 0, xWp = 0;
     int H0 = 0, W0 = 0, H1 = 0, W1 = 0;   // stem conv output, pooled output
@@ -510,17 +507,14 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                         // 1x1 convolutions: tasks of the stage's persistent launch when it takes them (Co % 128 == 0 ...).
                         // Bottleneck students: ResNet-50 step 9.32 -> 8.74 ms (36 launches of the atomics kernel at 47 us each
                         // become tasks; no atomics left).  BasicBlock students keep their three down-sampling convs on
-                        // launches of their own (same-box: 3.945 vs 3.951 ms grouped); VPD_WG2_1X1_BASIC=1 groups them too.
-                        static const bool basic_too = getenv("VPD_WG2_1X1_BASIC") && atoi(getenv("VPD_WG2_1X1_BASIC"));
-                        if ((!bottleneck && !basic_too) || !vpd_wgrad128_eligible(wq(*cv))) continue;
+                        // launches of their own (same-box: 3.945 vs 3.951 ms grouped).
+                        if (!bottleneck || !vpd_wgrad128_eligible(wq(*cv))) continue;
                     } else if (cv->k != 3) {
                         continue;
                     } else if (cv->stride != 1) {
-                        // stride-2 3x3: OFF by default (VPD_WG2_S2=1 enables): inside the stage's launch the three stride-2 problems
-                        // cost 86 us per step against 78 us as launches of their own -- their 55-66 KB per chunk leave room for
-                        // a two-stage ring only, one chunk of prefetch, and the tasks run at the DMA latency
-                        static const bool s2_grouped = getenv("VPD_WG2_S2") && atoi(getenv("VPD_WG2_S2"));
-                        if (!s2_grouped || !vpd_wgrad128_eligible(wq(*cv))) continue;
+                        // stride-2 3x3: launches of their own (inside the stage's launch the three stride-2 problems cost 86 us
+                        // per step against 78 us: their 55-66 KB per chunk leave room for a two-stage ring only)
+                        continue;
                     }
                     cv->dz_own_off = bp.take(padded_elems(NB, cv->Hout, cv->Wout, cv->Co, 1) * 2);
                     const int grp = (p->wg_merge34 && B.stage == 3) ? 2 : B.stage;
@@ -533,33 +527,25 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
             p->gslab_off = bp.take(mx * 4);
             for (int s2 = 0; s2 < 8; ++s2) p->wg2_tbl_off[s2] = bp.take(vpd_wgrad128_table_bytes());
         }
-        // OFF by default: measured 49 us per step SLOWER than the seven separate launches (3.716 -> 3.765 ms same-box) -- one
-        // block per crop / per four fc rows walks its 128-256-long dot products behind dependent global loads, where the
-        // MFMA sgemm kernels it replaces are launch-bound at 5-9 us each.  Kept for the A/B and its parity test.
-        p->fused_head = getenv("VPD_FUSED_HEAD") && atoi(getenv("VPD_FUSED_HEAD"));
         p->relu_bits = !(getenv("VPD_RELU_BITS") && !atoi(getenv("VPD_RELU_BITS")));
         if (p->relu_bits)
             for (auto& B : p->blocks) {
                 const ConvInfo& last = bottleneck ? B.c3 : B.c2;      // the conv whose BatchNorm feeds the block-output ReLU
                 B.mask_off = bp.take((size_t)NB * last.Hout * last.Wout * last.Co / 8 + 16);
             }
-        // Bottleneck students: OFF unless VPD_DGRAD_SUMS_BNECK=1 -- their BatchNorm tensors are 4x wider, the backward
-        // launches run at the memory system's rate rather than on the barrier's latency chain, and the second read of z in the
-        // 1x1 data gradients' (exposed) epilogues costs what the shorter BatchNorm launch saves: ResNet-50 8.73 -> 8.76 ms
-        // with every sum moved, 8.71 / 8.73 with the 3x3 ones only (same-box, two alternations each)
-        p->dgrad_sums = p->relu_bits && p->fused_bn && !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS"))) &&
-                        (!bottleneck || (getenv("VPD_DGRAD_SUMS_BNECK") && atoi(getenv("VPD_DGRAD_SUMS_BNECK"))));
+        // BasicBlock students only: a Bottleneck student's BatchNorm tensors are 4x wider, its backward launches run at the
+        // memory system's rate rather than on the barrier's latency chain, and the second read of z in the 1x1 data gradients'
+        // epilogues costs what the shorter BatchNorm launch saves (ResNet-50 8.73 -> 8.76 ms, rounds 2 and 4)
+        p->dgrad_sums = p->relu_bits && p->fused_bn && !bottleneck && !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS")));
         if (p->dgrad_sums)
             for (auto& B : p->blocks) {
                 B.mask1_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co / 8 + 16);
-                if (bottleneck) B.mask2_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co / 8 + 16);
             }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
         p->g0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dz0_off = bp.take((size_t)NB * p->H0 * p->W0 * 64 * 2);
         p->dpred_off = bp.take((size_t)NB * 2 * emb_dim * 4);
-        p->headpart_off = bp.take((size_t)NB * 4 + 256);
         p->dh2_off = bp.take((size_t)NB * 128 * 4);
         p->dh1_off = bp.take((size_t)NB * 128 * 4);
         p->demb_off = bp.take((size_t)NB * emb_dim * 4);
@@ -700,8 +686,7 @@ bool conv_pair_ok(const Ctx& c, const ConvInfo& c1, const ConvInfo& cd, bool tra
 // kernel takes the shape; *pooled tells the caller whether it did (false: plain conv into y, the pooling launch follows)
 hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* y, int ypad, bool stats,
                         const float* ep_scale, const float* ep_shift, const bf16_t* res, int ep_relu,
-                        const AltConv* alt = nullptr, bf16_t* pool_y = nullptr, bool* pooled = nullptr,
-                        const ConvXf* xf = nullptr, bool* xf_query = nullptr) {
+                        const AltConv* alt = nullptr, bf16_t* pool_y = nullptr, bool* pooled = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
     q.x = x;
@@ -731,15 +716,10 @@ hipError_t run_conv_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_
         if (!ok) { q.pool_y = nullptr; q.ep_scale = nullptr; q.ep_shift = nullptr; q.ep_relu = 0; }
         if (pooled) *pooled = ok;
     }
-    if (xf_query) { *xf_query = vpd_conv_xf_ok(q); return hipSuccess; }      // (would conv_xf.hip take this launch?)
     const int kc = vpd_conv_kernel_class(q);
     // slot 7: stem kernel (5, 6 are the wgrads); ws<256,64> shares slot 2 -- except layer1's 64 -> 64 convs, which stay in slot 0
     const int tcls = kc == 5 ? 7 : (kc == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kc);
-    // (class 8: conv3x3_pws_xf_kernel -- a convolution that also does a BatchNorm launch's work is not the same kernel; readers
-    //  that ask for fewer than nine classes get it under the class of its plain twin)
-    TimeScope ts(c.p, c.s, xf ? (8 | (tcls << 8)) : tcls, flops);
-    // xf: the producing convolution's BatchNorm + ReLU applied by this launch's loaders; `x` is then the activation it WRITES
-    if (xf) return vpd_launch_conv_xf(q, *xf, c.s);
+    TimeScope ts(c.p, c.s, tcls, flops);
     return vpd_launch_conv(q, c.s);
 }
 
@@ -783,20 +763,6 @@ ConvParams conv_dgrad_s1_params(const Ctx& c, const ConvInfo& cv, const bf16_t* 
     return q;
 }
 
-// can the data gradient of `cv` carry a BatchNorm backward in its epilogue (ConvBnBwd) at this batch size?
-bool dgrad_takes_bn(const Ctx& c, const ConvInfo& cv) {
-    // OFF by default: measured +0.4 % on the step (4.27 -> 4.25 ms, inside the box-to-box noise) -- a fused launch gets
-    // ~17 us longer where the separate bn_bwd_fused_kernel costs 15.5-17 us: the chain rows-atomics -> barrier arrival
-    // (two atomic hops) -> flag -> acquire -> row loads is ~8-10 us of dependent memory round trips wherever it runs, and
-    // only the launch itself (~3 us) and the store + load of d(activation) are saved.  VPD_DGRAD_BN=1 enables it;
-    // tests/test_model_gpu.py runs a step both ways.
-    static const bool on = getenv("VPD_DGRAD_BN") && atoi(getenv("VPD_DGRAD_BN"));
-    if (!on || !c.p->fused_bn || cv.stride != 1 || cv.k != 3 || cv.Ci > 1024) return false;
-    ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), 0);
-    q.bnb.mode = 1;
-    return vpd_conv_bnbwd_ok(q, device_cu_count());
-}
-
 // The sums of a BatchNorm backward (sum g, sum g * z with g = d * mask) taken in the epilogue of the data gradient that
 // produces d (ConvParams::bst_z); the BatchNorm launch is then finalize + apply only (run_bn_bwd_apply).
 // z2 / rows2: a second BatchNorm fed with the same g (the 1x1 branch of a down-sampling block), or null
@@ -812,11 +778,10 @@ bool dgrad_takes_sums(const Ctx& c, const ConvInfo& cv, int accumulate, bool pai
     return vpd_conv_takes_bn_sums(q);
 }
 
-// bnb: BatchNorm backward fused into this launch's epilogue (the caller has checked dgrad_takes_bn)
 // ds / dzd: the block's 1x1 stride-2 down-sampling conv and its dz -- its data gradient lands on the even-even input pixels,
 // which are class 0 of the 3x3's: extra K-steps of those blocks instead of a read-modify-write launch of its own
 hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate,
-                          const ConvBnBwd* bnb = nullptr, const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr,
+                          const ConvInfo* ds = nullptr, const bf16_t* dzd = nullptr,
                           const unsigned char* acc_mask = nullptr, const BnSums* sums = nullptr) {
     ConvParams q;
     memset(&q, 0, sizeof q);
@@ -832,15 +797,10 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
             q.stats = sums->rows; q.stat_rows = VPD_FUSED_ROWS;
             q.bst_z2 = sums->z2; q.stats2 = sums->rows2;
         }
-        if (bnb) {
-            q.bnb = *bnb;
-            q.stats = bnb->rows; q.stat_rows = VPD_FUSED_ROWS;      // the epilogue's sums go to the BatchNorm's own rows
-        }
         const int kcd = vpd_conv_kernel_class(q);
         TimeScope ts(c.p, c.s, kcd == 6 ? (cv.Co == 64 && cv.Ci == 64 ? 0 : 2) : kcd, conv_flops(cv, c.n));
         return vpd_launch_conv(q, c.s);
     }
-    if (bnb) return hipErrorInvalidValue;
     // stride 2: the four input-pixel parity classes are ONE launch (grid.z = class).  Only taps r with
     // (ph + pad - r) even contribute: r = rf, rf+2, ... reading dz row  y + (ph + pad - r)/2  (+1 for the border).
     TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n) + (ds ? conv_flops(*ds, c.n) : 0.0));
@@ -882,10 +842,7 @@ hipError_t run_conv_dgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf
 }
 
 hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x,
-                          hipStream_t st, ZeroRanges* collect_zero = nullptr, bool prezeroed = false,
-                          std::vector<WgradParams>* defer_to = nullptr, const ConvInfo* cv2 = nullptr,
-                          const bf16_t* dz2 = nullptr) {
-    // cv2 / dz2: the block's 1x1 stride-2 down-sampling conv and its dz, taken along as a tenth tap (WgradParams::dz2)
+                          hipStream_t st, ZeroRanges* collect_zero = nullptr, bool prezeroed = false) {
     WgradParams q;
     memset(&q, 0, sizeof q);
     q.dz = dz; q.dzHp = cv.Hout + 2 * dzpad; q.dzWp = cv.Wout + 2 * dzpad; q.dzC = cv.Co; q.dzpad = dzpad;
@@ -901,10 +858,6 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     q.taps = conv_taps_fwd(cv);
     q.prefer_halo_1x1 = !c.p->bottleneck;      // BasicBlock students: the three down-sampling 1x1 convs without atomics
     if (cv.slab_off >= 0 && !vpd_wgrad_overwrites(q)) q.slab = nullptr;      // (an A/B switch turned the halo form off: generic kernel)
-    if (cv2) {
-        if (!q.slab || cv2->slab_off < 0 || cv2->slab_off == cv.slab_off) return hipErrorInvalidValue;      // (the caller asks wgrad_pair_ok)
-        q.dz2 = dz2; q.dw2 = c.f32(c.p->wg_off) + cv2->wg_off; q.slab2 = slab + cv2->slab_off;
-    }
     if (collect_zero) {                  // dry run at the start of backward: which ranges need zeroing
         if (!vpd_wgrad_overwrites(q) && collect_zero->count < ZR_MAX) {
             collect_zero->ptr[collect_zero->count] = q.dw;
@@ -918,28 +871,14 @@ hipError_t run_conv_wgrad(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, in
     }
     if (vpd_wgrad_overwrites(q) && !q.defer_reduce && !cv.stem) {      // time the MFMA kernel alone, then sum its slab
         hipError_t e;
-        if (defer_to) {      // a slab region is summed before it is written again
-            for (size_t i = 0; i < defer_to->size();) {
-                if ((*defer_to)[i].slab == q.slab) {
-                    e = vpd_launch_wgrad_reduce((*defer_to)[i], st);
-                    if (e != hipSuccess) return e;
-                    defer_to->erase(defer_to->begin() + i);
-                } else ++i;
-            }
-        }
         {
             // class 5 = the grouped per-stage launches (and single stride-1 halo launches); a stride-2 conv's own halo
             // launch (two output tiles, 128 splits) is a different regime: class 6 with the other per-conv launches
-            TimeScope ts(c.p, st, cv.stride == 1 ? 5 : 6, conv_flops(cv, c.n) + (cv2 ? conv_flops(*cv2, c.n) : 0.0));
-            q.defer_reduce = cv2 ? 0 : 1;      // (the pair's launcher sums both slabs in one launch of its own)
+            TimeScope ts(c.p, st, cv.stride == 1 ? 5 : 6, conv_flops(cv, c.n));
+            q.defer_reduce = 1;
             e = vpd_launch_wgrad(q, st);
         }
         if (e != hipSuccess) return e;
-        if (cv2) return hipSuccess;
-        if (defer_to) {      // the slab sum rides in the stage's grouped slab-reduce launch (or is launched by whoever flushes the list)
-            defer_to->push_back(q);
-            return hipSuccess;
-        }
         return vpd_launch_wgrad_reduce(q, st);
     }
     TimeScope ts(c.p, st, cv.stem ? 7 : (vpd_wgrad_overwrites(q) ? 5 : 6), conv_flops(cv, c.n));      // 7: stem kernels
@@ -1063,24 +1002,6 @@ hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, 
     return vpd_launch_bn_bwd_apply_fused(b, f, c.s);
 }
 
-// ConvBnBwd of BatchNorm `bncv.bn` for a data-gradient launch whose output gradient is the BatchNorm's dy.
-// mode 1: ReLU mask recomputed from z; mode 2: mask from the padded activation `act` (residual block output).
-ConvBnBwd make_bnb(const Ctx& c, const ConvInfo& bncv, int mode, const bf16_t* act, bf16_t* dz, float* grads) {
-    ConvBnBwd f;
-    memset(&f, 0, sizeof f);
-    f.mode = mode;
-    f.z = c.b16(bncv.z_off);
-    f.mean = c.bn_mean(bncv.bn); f.rstd = c.bn_rstd(bncv.bn);
-    f.mscale = c.bn_scale(bncv.bn); f.mshift = c.bn_shift(bncv.bn);
-    f.act = act; f.aHp = bncv.Hout + 2; f.aWp = bncv.Wout + 2; f.apad = 1;
-    f.gamma = c.params + bncv.bn.w_off; f.dgamma = grads + bncv.bn.w_off; f.dbeta = grads + bncv.bn.b_off;
-    f.rows = c.bn_rows(bncv.bn); f.sync = c.ws + bncv.bn.sync_off;
-    f.err = reinterpret_cast<unsigned*>(c.ws + c.p->syncerr_off);
-    f.count = (float)(c.n * bncv.Hout * bncv.Wout);
-    f.dz = dz; f.dzHp = bncv.Hout + 2; f.dzWp = bncv.Wout + 2; f.dzpad = 1;
-    return f;
-}
-
 #define LCHECK(expr)                                   \
     do {                                               \
         hipError_t _e = (expr);                        \
@@ -1101,15 +1022,6 @@ int run_head(const Ctx& c, const bf16_t* last_act, float* emb_out, const float* 
              float* loss_step, double* loss_accum) {
     vpd_plan* p = c.p;
     const StageInfo& S = p->stages[3];
-    if (target && !p->motion && p->fused_head && p->headpart_off && p->feat % 256 == 0) {
-        float* emb = emb_out ? emb_out : c.f32(p->emb_off);
-        float* part = c.f32(p->headpart_off);
-        LCHECK(vpd_launch_head_fwd_fused(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.params + p->fc.w_off,
-                                         c.params + p->fc.b_off, p->D, target, c.f32(p->pooled_off), emb,
-                                         need_grad ? c.f32(p->dpred_off) : nullptr, part,
-                                         reinterpret_cast<unsigned*>(part + p->max_batch), loss_step, loss_accum, c.s));
-        return 0;
-    }
     LCHECK(vpd_launch_avgpool(last_act, S.H + 2, S.W + 2, 1, S.H, S.W, p->feat, c.n, c.f32(p->pooled_off), c.s));
     // without the motion head nothing re-reads the embedding (the fc backward uses the pooled features and d(emb)): the fc
     // GEMM writes the caller's buffer directly; with it, the head's first layer and its weight gradient read the workspace copy
@@ -1263,19 +1175,13 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
         } else {
             LCHECK(run_conv_train(c, B.c1, cur, bn_running));
         }
-        // BasicBlock: bn1 + ReLU applied by conv2's loader waves (conv_xf.hip) -- no launch between the two convolutions
-        bool xf2 = false;
-        if (!p->bottleneck && c.fused(B.c1) && c.fused(B.c2))
-            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
-                                nullptr, &xf2));
-        if (!xf2)
-            LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1,
-                              B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr));
+        LCHECK(run_bn_fwd(c, B.c1, bn_running, 0, nullptr, nullptr, a1, 1,
+                          B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr));
         if (p->bottleneck) {
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1,
-                              B.mask2_off ? reinterpret_cast<unsigned char*>(ws + B.mask2_off) : nullptr));
+                              nullptr));
             LCHECK(run_conv_train(c, B.c3, a2, bn_running));
             unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
             if (B.ds) {
@@ -1287,20 +1193,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             cur = outp;
             continue;
         }
-        if (xf2) {
-            ConvXf xf;
-            memset(&xf, 0, sizeof xf);
-            const BnInfo& b1 = B.c1.bn;
-            xf.z = c.b16(B.c1.z_off); xf.rows = c.bn_rows(b1);
-            xf.gamma = params + b1.w_off; xf.beta = params + b1.b_off;
-            xf.rm = bn_running ? bn_running + b1.rm_off : nullptr; xf.rv = bn_running ? bn_running + b1.rv_off : nullptr;
-            xf.mean = c.bn_mean(b1); xf.rstd = c.bn_rstd(b1); xf.scale = c.bn_scale(b1); xf.shift = c.bn_shift(b1);
-            xf.mask = B.mask1_off ? reinterpret_cast<unsigned char*>(ws + B.mask1_off) : nullptr;
-            xf.count = (float)(n * B.c1.Hout * B.c1.Wout); xf.momentum = kBnMomentum; xf.eps = kBnEps;
-            LCHECK(run_conv_fwd(c, B.c2, a1, c.b16(B.c2.z_off), 0, true, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, &xf));
-        } else {
-            LCHECK(run_conv_train(c, B.c2, a1, bn_running));
-        }
+        LCHECK(run_conv_train(c, B.c2, a1, bn_running));
         unsigned char* mbits = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
         if (B.ds) {
             if (!pair) LCHECK(run_conv_train(c, B.cd, cur, bn_running));
@@ -1370,11 +1263,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     int gi = 0;      // index of the G buffer holding d(out) of the current block
     bf16_t* G[3] = {c.b16(p->G_off[0]), c.b16(p->G_off[1]), c.b16(p->G_off[2])};
     bool pool_pending = false;      // d(out) of the last block has not been written yet: d(pooled) is what there is
-    if (!p->motion && p->fused_head && p->feat % 2 == 0) {
-        const StageInfo& S = p->stages[3];
-        LCHECK(vpd_launch_head_bwd_fused(demb, params + p->fc.w_off, c.f32(p->pooled_off), grads + p->fc.w_off,
-                                         grads + p->fc.b_off, G[gi], n, p->D, p->feat, S.H * S.W, s));
-    } else {
+    {
         LCHECK(vpd_launch_sgemm(demb, c.f32(p->pooled_off), grads + p->fc.w_off, nullptr, p->D, p->feat, n, 1, 0, 0, s));
         LCHECK(vpd_launch_colsum(demb, n, p->D, grads + p->fc.b_off, s));
         LCHECK(vpd_launch_sgemm(demb, params + p->fc.w_off, c.f32(p->dpooled_off), nullptr, n, p->feat, p->D, 0, 0, 0, s));
@@ -1388,22 +1277,6 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     const bool grouped = p->wg_group;
     struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
     std::vector<Pending> pending;
-    // VPD_WG_REDUCE_MERGE=1 (round 4, MEASURED NEGATIVE, default off): single halo launches (the stride-2 3x3 and 1x1 convs of
-    // a down-sampling block) leave their split partials in their slab regions for the stage's grouped slab-reduce launch -- 6
-    // launches of ~5-8 us per ResNet-34 step become extra rows of 3.  Same box: 72.5 k vs 73.4 k crops/s
-    // (profiles/r04_ab_reduce_merge_negative.txt): behind the 120-250 us grouped weight-gradient launch the ~40 MB of
-    // partials per boundary have left the caches, which costs more than the launches saved (the same lesson as round 1's
-    // per-bucket sums).
-    std::vector<WgradParams> reduce_later;
-    static const int merge_reduce = getenv("VPD_WG_REDUCE_MERGE") ? atoi(getenv("VPD_WG_REDUCE_MERGE")) : 0;
-    auto flush_reduce_later = [&]() -> hipError_t {
-        for (const WgradParams& q : reduce_later) {
-            const hipError_t e = vpd_launch_wgrad_reduce(q, s);
-            if (e != hipSuccess) return e;
-        }
-        reduce_later.clear();
-        return hipSuccess;
-    };
     auto make_q = [&](const Pending& pd) {
         const ConvInfo& cv = *pd.cv;
         WgradParams q;
@@ -1419,7 +1292,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     };
     // `slot`: the stage whose table / schedule cache the 128 x 64 launch uses
     auto flush_group = [&](int slot) -> hipError_t {
-        if (pending.empty()) return flush_reduce_later();
+        if (pending.empty()) return hipSuccess;
         hipError_t r = hipSuccess;
         // persistent 128-wide tiles (conv_wgrad128_persistent_kernel) for every conv it takes: one launch per 18 problems
         // (a ResNet-50 stage has up to 19: two balanced launches)
@@ -1445,7 +1318,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 }
                 if (!p->wg2_cache[sl]) p->wg2_cache[sl] = vpd_wgrad128_cache_new();
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad128_group(elig.data() + at, cnt, p->wg2_cache[sl], ws + p->wg2_tbl_off[sl], s, &reduce_later);
+                r = vpd_launch_wgrad128_group(elig.data() + at, cnt, p->wg2_cache[sl], ws + p->wg2_tbl_off[sl], s);
                 at += cnt;
             }
         }
@@ -1463,31 +1336,12 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             }
             {
                 TimeScope ts(p, s, 5, flops);
-                r = vpd_launch_wgrad_group(qs, take, s, &reduce_later);
+                r = vpd_launch_wgrad_group(qs, take, s);
             }
             done += take;
         }
         pending.clear();
-        if (r == hipSuccess) r = flush_reduce_later();      // (whatever no grouped reduce launch had room for)
         return r;
-    };
-    // VPD_WG_PAIR=1: the 1x1 stride-2 branch of a down-sampling BasicBlock inside its 3x3 stride-2 sibling's weight-gradient launch
-    // (round 4, VERDICT r3 #4b): same input halo, second dz tile, a tenth tap -- one launch + one slab-sum launch instead of two +
-    // two.  Parity-green (tests/test_ops_gpu.py::test_wgrad_pair_downsampling_block) and MEASURED NEGATIVE, default off: 71.55 vs
-    // 71.94 k crops/s same box, the three merged launches 148 us against 128 us for the six they replace
-    // (profiles/r04_ab_wgrad_pair_negative.txt).  The 8-KB dz2 tile per stage leaves the 10-pass halo two ring stages instead of
-    // three (three would be 168 KB), and the tenth tap's fragments have no registers to be read early in: its eight MFMAs sit
-    // behind an exposed LDS round trip at the end of every chunk.
-    static const int wg_pair = getenv("VPD_WG_PAIR") ? atoi(getenv("VPD_WG_PAIR")) : 0;
-    auto wgrad_pair_ok = [&](const BlockInfo& B, const bf16_t* dz1, const bf16_t* dzd) -> bool {
-        if (!wg_pair || !B.ds || p->bottleneck) return false;
-        const ConvInfo& a = B.c1; const ConvInfo& d = B.cd;
-        if (!(a.k == 3 && a.stride == 2 && a.pad == 1 && d.k == 1 && d.stride == 2 && d.pad == 0)) return false;
-        if (d.Co != a.Co || d.Ci != a.Ci || d.Hout != a.Hout || d.Wout != a.Wout || a.slab_off < 0 || d.slab_off < 0 || d.slab_off == a.slab_off)
-            return false;
-        // (neither joins the stage's grouped launch)
-        if (grouped && ((a.dz_own_off && dz1 == c.b16(a.dz_own_off)) || (d.dz_own_off && dzd == c.b16(d.dz_own_off)))) return false;
-        return a.Hin == 2 * a.Hout && a.Win == 2 * a.Wout;
     };
     // wgrad of `cv` may start once everything enqueued on the main stream so far (its dz) is done
     auto queue_wgrad = [&](const ConvInfo& cv, const bf16_t* dz, int dzpad, const bf16_t* x) -> hipError_t {
@@ -1496,7 +1350,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             return hipSuccess;
         }
         // (a bucket is handed over -- unpacked, its event recorded -- only behind its stage's flush_group, i.e. behind these sums)
-        return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed, grouped && merge_reduce ? &reduce_later : nullptr);
+        return run_conv_wgrad(c, cv, dz, dzpad, x, s, nullptr, prezeroed);
     };
     // lazy: the caller asked for it (vpd_plan_set_lazy_grads).  With bucket events the reducer then sums the scratch ranges
     // (vpd_plan_bucket_scratch_range) and the non-conv tensors of the flat buffer instead of the whole flat buffer
@@ -1504,7 +1358,6 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     p->lazy_next = false;
     p->grads_in_scratch = lazy;
     auto unpack_bucket = [&](int b) -> int {
-        LCHECK(flush_reduce_later());      // (nothing left in the normal order of events)
         int nb = (int)p->bmap_unpack[b].size() / 2;
         if (lazy) nb = b == 3 ? p->nstem_unpack_blocks : 0;      // the stem's row-tap packing is undone here either way
         if (nb > 0)
@@ -1557,7 +1410,6 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         *done = true;
         return 0;
     };
-    std::vector<char> bn2_fused_for(p->blocks.size(), 0);      // block-output BatchNorm backward done by the next block's dgrad
     std::vector<char> bn2_sums_for(p->blocks.size(), 0);       // ... its sums taken by the next block's dgrad (BnSums)
     static const bool pair_sums = !(getenv("VPD_DGRAD_SUMS_PAIR") && !atoi(getenv("VPD_DGRAD_SUMS_PAIR")));
     for (int bi = (int)p->blocks.size() - 1; bi >= 0; --bi) {
@@ -1570,7 +1422,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         bf16_t* dnew = G[(gi + 2) % 3];
         bf16_t* dz2 = c.b16(grouped && B.c2.dz_own_off ? B.c2.dz_own_off : S.dz2_off[par]);
         bf16_t* dz1 = c.b16(grouped && B.c1.dz_own_off ? B.c1.dz_own_off : S.dz1_off[par]);
-        if (pool_pending && (p->bottleneck || B.ds || bn2_sums_for[bi] || bn2_fused_for[bi])) {      // (not the path that produces d(out) itself)
+        if (pool_pending && (p->bottleneck || B.ds || bn2_sums_for[bi])) {      // (not the path that produces d(out) itself)
             LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, dout, s));
             pool_pending = false;
         }
@@ -1585,28 +1437,14 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             if (B.ds)
                 if (bn_bwd_pair(B.c3, B.cd, dout, c.b16(B.out_off), dz3,
                                 c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn3_pair)) return -1;
-            if (bn2_sums_for[bi]) LCHECK(run_bn_bwd_apply(c, B.c3, dout, dz3, 1, grads, mb3));      // (sums: next block's conv1 dgrad)
-            else if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
+            if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
-            if (B.mask2_off && dgrad_takes_sums(c, B.c3, 0)) {      // bn2's sums ride in conv3's data gradient
-                const unsigned char* m2 = reinterpret_cast<const unsigned char*>(ws + B.mask2_off);
-                const BnSums sm{c.b16(B.c2.z_off), m2, c.bn_rows(B.c2.bn), nullptr, nullptr};
-                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0, nullptr, nullptr, nullptr, nullptr, &sm));
-                LCHECK(run_bn_bwd_apply(c, B.c2, da2, dz2, 1, grads, m2));
-            } else {
-                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
-                LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
-            }
+            // (the BatchNorm sums are not taken in a Bottleneck student's data gradients: vpd_plan_create, dgrad_sums)
+            LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
+            LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
             LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-            if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {      // bn1's in conv2's (3x3, stride 1 or 2)
-                const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
-                const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn), nullptr, nullptr};
-                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0, nullptr, nullptr, nullptr, nullptr, &sm));
-                LCHECK(run_bn_bwd_apply(c, B.c1, da1b, dz1, 1, grads, m1));
-            } else {
-                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
-                LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
-            }
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
+            LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
             LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
                 bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);
@@ -1616,20 +1454,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the pixels the strided 1x1 reads
                 gi = (gi + 2) % 3;
             } else {
-                // identity path + conv path = d(out) of the previous block: when that one is a plain block too, the sums of its
-                // bn3 are taken here
-                const BnSums* smp = nullptr;
-                BnSums sm;
-                if (bi > 0 && mb3) {
-                    const BlockInfo& Bp = p->blocks[bi - 1];
-                    if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c3) && dgrad_takes_sums(c, B.c1, 1)) {
-                        sm = BnSums{c.b16(Bp.c3.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c3.bn),
-                                    nullptr, nullptr};
-                        smp = &sm;
-                        bn2_sums_for[bi - 1] = true;
-                    }
-                }
-                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mb3, smp));
+                // identity path + conv path = d(out) of the previous block
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, mb3));
             }
             if (stage_end(bi)) return -1;
             continue;
@@ -1642,45 +1468,39 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mb, &B.cd,
                                     c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off)));
             bn_pair = true;
-        } else if (B.ds && !bn2_fused_for[bi])
+        } else if (B.ds)
             if (bn_bwd_pair(B.c2, B.cd, dout, c.b16(B.out_off), dz2,
                             c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn_pair)) return -1;
         // plain (identity) blocks: ReLU mask from the forward's bit map; g = dout * mask is neither written back nor re-read --
         // conv1's data gradient, which adds the identity path, masks dout itself (ConvParams::acc_mask)
         const unsigned char* mbits = nullptr;
-        if (!B.ds && !bn2_fused_for[bi] && relu_bits_ok(c, B.c2) && !(bi > 0 && dgrad_takes_bn(c, B.c1)))
+        if (!B.ds && relu_bits_ok(c, B.c2))
             mbits = reinterpret_cast<const unsigned char*>(ws + B.mask_off);
         if (bn2_sums_for[bi] && !B.ds)      // (the next block's conv1 data gradient took the sums: mbits is set, dout is left alone)
             LCHECK(run_bn_bwd_apply(c, B.c2, dout, dz2, 1, grads, mbits));
         else if (bn2_sums_for[bi]) { /* down-sampling block: applied above */ }
-        else if (!bn2_fused_for[bi] && !bn_pair) {
+        else if (!bn_pair) {
             LCHECK(run_bn_bwd(c, B.c2, dout, c.b16(B.out_off), dz2, 1, 1, grads, false, false, mbits,
                               pool_pending ? c.f32(p->dpooled_off) : nullptr));
             pool_pending = false;
         }
         LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-        if (dgrad_takes_bn(c, B.c2)) {
-            // conv2's data gradient with bn1's whole backward in its epilogue: da1 is never stored, dz1 comes out padded
-            const ConvBnBwd f = make_bnb(c, B.c1, 1, nullptr, dz1, grads);
-            LCHECK(run_conv_dgrad(c, B.c2, dz2, nullptr, 0, &f));
-        } else if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {
+        if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {
             // bn1's sums ride in conv2's data gradient; its BatchNorm launch only finalizes and applies
             const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
             const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn), nullptr, nullptr};
-            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, nullptr, nullptr, nullptr, nullptr, &sm));
+            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0, nullptr, nullptr, nullptr, &sm));
             LCHECK(run_bn_bwd_apply(c, B.c1, da1, dz1, 1, grads, m1));
         } else {
             LCHECK(run_conv_dgrad(c, B.c2, dz2, da1, 0));
             LCHECK(run_bn_bwd(c, B.c1, da1, nullptr, dz1, 1, 0, grads, true));
         }
         bf16_t* const dzd_pre = B.ds ? c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off) : nullptr;
-        const bool pair_wg = B.ds && wgrad_pair_ok(B, dz1, dzd_pre);
-        if (!pair_wg) LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
+        LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
         if (B.ds) {
             bf16_t* dzd = dzd_pre;      // (its own buffer when it joins the stage's launch)
             if (!bn_pair) LCHECK(run_bn_bwd(c, B.cd, dout, nullptr, dzd, 1, 0, grads));
-            if (pair_wg) LCHECK(run_conv_wgrad(c, B.c1, dz1, 1, xin, s, nullptr, prezeroed, nullptr, &B.cd, dzd));
-            else LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
+            LCHECK(queue_wgrad(B.cd, dzd, 1, xin));
             if (conv_pair_ok(c, B.c1, B.cd, true)) {
                 // one launch: the 1x1 branch's data gradient is extra K-steps of the even-even class.  Its result is d(out) of
                 // the previous stage's last block: the sums of that block's bn2 are taken here
@@ -1689,26 +1509,18 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                 static const bool s2sums = !(getenv("VPD_DGRAD_SUMS_S2") && !atoi(getenv("VPD_DGRAD_SUMS_S2")));
                 if (bi > 0 && p->dgrad_sums && s2sums && (B.c1.Hin % 2) == 0 && (B.c1.Win % 2) == 0) {
                     const BlockInfo& Bp = p->blocks[bi - 1];
-                    if (!Bp.ds && relu_bits_ok(c, Bp.c2) && !(bi - 1 > 0 && dgrad_takes_bn(c, Bp.c1))) {
+                    if (!Bp.ds && relu_bits_ok(c, Bp.c2)) {
                         sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn), nullptr, nullptr};
                         smp = &sm;
                         bn2_sums_for[bi - 1] = true;
                     }
                 }
-                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0, nullptr, &B.cd, dzd, nullptr, smp));
+                LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0, &B.cd, dzd, nullptr, smp));
             } else {
                 LCHECK(run_conv_dgrad(c, B.c1, dz1, dnew, 0));      // writes every input pixel (3x3 covers all classes)
                 LCHECK(run_conv_dgrad(c, B.cd, dzd, dnew, 1));      // adds onto the even-even pixels
             }
             gi = (gi + 2) % 3;
-        } else if (bi > 0 && dgrad_takes_bn(c, B.c1)) {
-            // dout holds g: identity path + conv path = d(out) of the previous block, whose bn2 backward (ReLU mask from its
-            // stored output, g written back for ITS identity path) rides in this launch's epilogue
-            BlockInfo& Bp = p->blocks[bi - 1];
-            bf16_t* dz2p = c.b16(grouped && Bp.c2.dz_own_off ? Bp.c2.dz_own_off : S.dz2_off[(bi - 1) & 1]);
-            const ConvBnBwd f = make_bnb(c, Bp.c2, 2, c.b16(Bp.out_off), dz2p, grads);
-            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, &f));
-            bn2_fused_for[bi - 1] = true;
         } else {
             // dout holds g (or, with the bit map, d(out) and the mask is applied here): identity path + conv path.
             // The result is d(out) of the previous block: when that block is a plain one too, the sums of its bn2 are taken here
@@ -1716,7 +1528,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             BnSums sm;
             if (bi > 0 && mbits) {
                 const BlockInfo& Bp = p->blocks[bi - 1];
-                if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c2) && !dgrad_takes_bn(c, Bp.c1) &&
+                if (!Bp.ds && Bp.stage == B.stage && relu_bits_ok(c, Bp.c2) &&
                     dgrad_takes_sums(c, B.c1, 1)) {
                     sm = BnSums{c.b16(Bp.c2.z_off), reinterpret_cast<const unsigned char*>(ws + Bp.mask_off), c.bn_rows(Bp.c2.bn), nullptr, nullptr};
                     smp = &sm;
@@ -1730,7 +1542,7 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
                     bn2_sums_for[bi - 1] = true;
                 }
             }
-            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, nullptr, mbits, smp));
+            LCHECK(run_conv_dgrad(c, B.c1, dz1, dout, 1, nullptr, nullptr, mbits, smp));
         }
         if (stage_end(bi)) return -1;
     }
@@ -1882,8 +1694,8 @@ extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
         HCHECK(hipEventSynchronize(t.b));
         float ms = 0.f;
         HCHECK(hipEventElapsedTime(&ms, t.a, t.b));
-        int cls = t.cls & 0xff;
-        if (cls >= nclasses) cls = t.cls >> 8;
+        const int cls = t.cls;
+        if (cls < 0 || cls >= nclasses) continue;
         out[3 * cls + 0] += 1.0; out[3 * cls + 1] += ms; out[3 * cls + 2] += t.flops;
         p->ev_pool.push_back(t.a); p->ev_pool.push_back(t.b);
     }
@@ -1970,32 +1782,6 @@ extern "C" int vpd_op_conv2d_bnsums(const void* x, const void* w, void* y, const
     return 0;
 }
 
-// A train-forward 3x3 whose loaders apply the producing convolution's BatchNorm + ReLU (conv_xf.hip): z dense [n][H][W][Kc],
-// act_out padded [n][H+2][W+2][Kc] (zero border, interior written here), y dense [n][H][W][Co], rows_out [VPD_FUSED_ROWS][2][Co]
-extern "C" int vpd_op_conv2d_bn_in(const void* z, const double* rows_in, const float* gamma, const float* beta,
-                                   float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
-                                   void* act_out, unsigned char* mask_bits, const void* w, void* y, double* rows_out, int n, int H,
-                                   int W, int Kc, int Co, float momentum, float eps, void* stream) {
-    if (!z || !rows_in || !gamma || !beta || !mean || !rstd || !scale || !shift || !act_out || !w || !y || !rows_out)
-        return fail("null argument");
-    ConvParams q;
-    memset(&q, 0, sizeof q);
-    q.x = (const bf16_t*)act_out; q.xHp = H + 2; q.xWp = W + 2; q.xC = Kc; q.w = (const bf16_t*)w;
-    q.y = (bf16_t*)y; q.yHp = H; q.yWp = W; q.yC = Co; q.ypad = 0;
-    q.stats = rows_out; q.stat_rows = VPD_FUSED_ROWS;
-    q.N = n; q.Hs = H; q.Ws = W; q.osub = 1; q.istr = 1; q.Kc = Kc; q.Co = Co; q.M = n * H * W;
-    q.taps.nr = 3; q.taps.nc = 3; q.taps.dy0 = 0; q.taps.dys = 1; q.taps.dx0 = 0; q.taps.dxs = 1;
-    q.taps.w0 = 0; q.taps.wrs = 3; q.taps.wcs = 1;
-    if (!vpd_conv_xf_fits(q)) return fail("conv_xf.hip does not take this shape");
-    ConvXf xf;
-    memset(&xf, 0, sizeof xf);
-    xf.z = (const bf16_t*)z; xf.rows = rows_in; xf.gamma = gamma; xf.beta = beta; xf.rm = running_mean; xf.rv = running_var;
-    xf.mean = mean; xf.rstd = rstd; xf.scale = scale; xf.shift = shift; xf.mask = mask_bits;
-    xf.count = (float)q.M; xf.momentum = momentum; xf.eps = eps;
-    LCHECK(vpd_launch_conv_xf(q, xf, (hipStream_t)stream));
-    return 0;
-}
-
 extern "C" int vpd_op_bn_forward(const void* z, const double* rows, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, float* mean, float* rstd, float* scale, float* shift, const void* res,
                                  void* out, unsigned char* mask_bits, int n, int H, int W, int C, int relu, float momentum,
@@ -2041,21 +1827,6 @@ extern "C" int vpd_op_wgrad(const void* dz, const void* x, float* dw, int n, int
     q.N = n; q.Hs = Hs; q.Ws = Ws; q.istr = istr; q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws;
     q.taps = tapset_from(tapset9);
     if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
-    LCHECK(vpd_launch_wgrad(q, (hipStream_t)stream));
-    return 0;
-}
-
-extern "C" int vpd_op_wgrad_pair(const void* dz, const void* dz2, const void* x, float* dw, float* dw2, int n, int Ho, int Wo, int Ci,
-                                 int Co, float* slab, float* slab2, void* stream) {
-    if (!dz || !dz2 || !x || !dw || !dw2 || !slab || !slab2) return fail("null argument");
-    WgradParams q;
-    memset(&q, 0, sizeof q);
-    q.dz = (const bf16_t*)dz; q.dzHp = Ho + 2; q.dzWp = Wo + 2; q.dzC = Co; q.dzpad = 1;
-    q.x = (const bf16_t*)x; q.xHp = 2 * Ho + 2; q.xWp = 2 * Wo + 2; q.xC = Ci; q.dw = dw; q.slab = slab;
-    q.N = n; q.Hs = Ho; q.Ws = Wo; q.istr = 2; q.Kc = Ci; q.Co = Co; q.M = n * Ho * Wo;
-    q.taps = TapSet{3, 3, 0, 1, 0, 1, 0, 3, 1};
-    q.dz2 = (const bf16_t*)dz2; q.dw2 = dw2; q.slab2 = slab2;
-    if (!vpd_wgrad_overwrites(q)) return fail("shape not taken by the halo weight-gradient kernel");
     LCHECK(vpd_launch_wgrad(q, (hipStream_t)stream));
     return 0;
 }

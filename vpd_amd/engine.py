@@ -395,16 +395,15 @@ class StudentEngine:
         check(lib().vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
 
     def read_timing(self, pl):
-        out = (C.c_double * 27)()
-        check(lib().vpd_plan_read_timing(pl.handle, out, 9), "vpd_plan_read_timing")
+        out = (C.c_double * 24)()
+        check(lib().vpd_plan_read_timing(pl.handle, out, 8), "vpd_plan_read_timing")
         # (class 1 -> conv3x3_pws_kernel<256,128,352> only with > 1 tile per block, else the class-6 tile; the non-persistent
         #  conv3x3_ws_kernel twins of every class remain behind VPD_PWS=0)
         names = ["conv3x3_c64_persistent_kernel<224>", "conv3x3_pws_kernel<256,128,352>", "conv3x3_pws_kernel<256,64,416> | <128,128,288>",
                  "conv3x3_pws_kernel<128,64,288>", "conv1x1_ws_kernel (stride-2 / 1x1 ring GEMM) + conv_igemm_kernel (gather)", "conv_wgrad128_persistent_kernel (layer2-4) + conv_wgrad_halo_grouped_kernel (layer1)",
                  "conv_wgrad_halo_kernel<10|13> (stride 2) + conv_wgrad_kernel (1x1)",
-                 "conv_stem_persistent_kernel<160> + conv_wgrad_stem_kernel",
-                 "conv3x3_pws_xf_kernel<256,64,416> | <128,64,288> (conv2 of a BasicBlock + bn1 / ReLU in its loaders)"]
-        return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(9)}
+                 "conv_stem_persistent_kernel<160> + conv_wgrad_stem_kernel"]
+        return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(8)}
 
     def launch_eval_graph(self, pl, n):
         self._ensure_packed(pl)
