@@ -445,6 +445,13 @@ def main():
         multi["ms_per_step_overlap_on"] = 1e3 * dt / args.steps
         multi["ms_per_step_overlap_off"] = 1e3 * float(t_off.item()) / args.steps
         multi["lazy_gradients"] = os.environ.get("VPD_DDP_LAZY", "1") != "0"
+        multi["early_bucket0"] = bool(pl.early_bucket0)      # layer4's weight gradients at layer4's end: bucket 0 handed over early
+        # replicas: every rank must hold the same bits after the timed steps (same initial weights, same all-reduced gradients)
+        chk = torch.stack([eng.params.double().sum(), (eng.params.double() ** 2).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        multi["replicas_identical"] = bool(torch.equal(lo, hi))
 
     # a grid-barrier time-out (fused BatchNorm backward; vpd_amd/csrc/sync.h) means the timed steps were not valid steps
     nerr = eng.sync_errors()

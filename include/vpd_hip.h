@@ -41,6 +41,10 @@ int vpd_abi_version(void);
  * activations / gradients a train step needs. */
 int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
                     int max_batch, int train, vpd_plan_t** out);
+/* `train`: 0 = inference plan, 1 = train plan; OR-ed with VPD_TRAIN_EARLY_BUCKET0 for data-parallel runs: the weight gradients of
+ * layer4 are launched at the end of layer4's backward instead of together with layer3's, so gradient bucket 0 (fc + layer4 +
+ * motion head, 61 % of the bytes) is final -- and its event recorded -- with three quarters of backward still ahead. */
+#define VPD_TRAIN_EARLY_BUCKET0 2
 void vpd_plan_destroy(vpd_plan_t* plan);
 
 /* Trainable-tensor table in reference state_dict order (SURVEY.md 8b "state_dict schema").

@@ -12,12 +12,19 @@ from oracle import vpd_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_bucket_reducer_world1_matches_plain_run():
     import torch.distributed as dist
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
     from vpd_amd.trainer import ModelTrainer
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(_free_port())
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         sd = O.procedural_state_dict(O.encoder_schema("resnet18", 5, 32), 2)
@@ -41,6 +48,14 @@ def test_bucket_reducer_world1_matches_plain_run():
             if use_group:
                 # the reducer takes its mode from the plan: a caller's word that disagrees is an error, not a
                 # silent all-reduce of stale ranges
+                # (compared with an EAGER backward + reduce of the same batch at the same weights -- a lazy reduce that
+                #  summed stale flat-buffer ranges instead of the scratch would differ by the whole gradient, not by rounding)
+                tr._forward_loss(img, tgt, train=True)
+                pe = enc.engine.backward(tr._reducer.event_handles(len(enc.engine._last[0].buckets)), lazy=False)
+                tr._reducer.reduce(pe)
+                torch.cuda.synchronize()
+                g_eager = enc.engine.grads.clone()
+                enc.engine._grads.zero_()                   # nothing of the eager result may survive into the comparison
                 tr._forward_loss(img, tgt, train=True)
                 pl = enc.engine.backward(tr._reducer.event_handles(len(enc.engine._last[0].buckets)), lazy=True)
                 with pytest.raises(RuntimeError):
@@ -48,8 +63,8 @@ def test_bucket_reducer_world1_matches_plain_run():
                 tr._reducer.reduce(pl)                      # lazy, as the plan says
                 enc.engine.materialize_grads()
                 torch.cuda.synchronize()
-                rel2 = float((enc.engine.grads - g).norm() / g.norm())
-                assert rel2 < 2.0 and np.isfinite(rel2)     # (two optimizer steps later: same order of magnitude, finite)
+                rel2 = float((enc.engine.grads - g_eager).norm() / g_eager.norm())
+                assert rel2 < 1e-3, rel2                    # (fp32 atomics of the BatchNorm rows: summation order, ~1e-6)
         # BN statistics and the generic weight-gradient kernel use fp32 atomics (summation order varies run to run,
         # measured 1e-6 .. 3e-5 on these gradients): a tight tolerance, not bitwise
         rel = np.linalg.norm(res[0][0] - res[1][0]) / np.linalg.norm(res[0][0])
@@ -101,7 +116,7 @@ def test_lazy_gradients_under_data_parallelism_equal_the_eager_path():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     runs = {}
-    for tag, lazy, overlap, port in (("eager", "0", "1", 29581), ("lazy", "1", "1", 29583), ("lazy_inline", "1", "0", 29585)):
+    for tag, lazy, overlap, port in (("eager", "0", "1", _free_port()), ("lazy", "1", "1", _free_port()), ("lazy_inline", "1", "0", _free_port())):
         q = ctx.Queue()
         procs = [ctx.Process(target=_rank_main_ragged, args=(r, 2, port, q, lazy, overlap)) for r in range(2)]
         for p in procs:
@@ -126,7 +141,8 @@ def test_zero_crop_rank_joins_the_collective():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main_ragged, args=(r, 2, 29571, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_ragged, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -180,7 +196,8 @@ def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
     from vpd_amd.trainer import ModelTrainer
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, 29547, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -246,7 +263,8 @@ def test_two_ranks_on_a_bottleneck_student_with_the_reducer_attached():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main_bottleneck, args=(r, 2, 29653, q)) for r in range(2)]
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_bottleneck, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
@@ -267,7 +285,7 @@ def test_train_cli_two_ranks_keep_identical_replicas(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "run")
-    env = dict(os.environ, VPD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29623", WORLD_SIZE="2",
+    env = dict(os.environ, VPD_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2",
                LOCAL_RANK="0")
     args = [sys.executable, os.path.join(root, "train_vpd_model.py"), "diving48", "--save_dir", out, "--flow_img", "flow",
             "--synthetic", "64", "--num_epochs", "2", "--batch_size", "16", "--motion", "--encoder_arch", "resnet18"]
@@ -317,3 +335,99 @@ def test_bench_self_launches_two_ranks_from_a_bare_shell():
                         "--arch", "no_such_arch", "--no-cpu-baseline", "--no-apply"], cwd=root, env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def _rank_main_c4(rank, world, port, q, early):
+    """BASELINE configs[3] per rank (fs normalisation, motion head, ResNet-34), scaled to 64 crops per rank so that four ranks share the
+    one GPU of this box: one full global batch and the RAGGED final one (3,616 = 8 x 452 in the config; here 4 x 57 of 4 x 64)
+    through ModelTrainer.epoch with the bucket reducer attached."""
+    import hashlib
+    import torch.distributed as dist
+    from vpd_amd.data import RGB_MEAN_STD
+    from vpd_amd.ddp import shard_slice
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    from vpd_amd.trainer import ModelTrainer
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["VPD_DDP_EARLY_BUCKET0"] = early
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        torch.manual_seed(0)
+        enc = RGBF_EmbeddingModel("resnet34", bench.EMB_DIM, True, "cuda")
+        enc.reset_parameters(seed=0)
+        tr = ModelTrainer(enc, True, process_group=dist.group.WORLD)
+        dist.broadcast(enc.engine.params, 0)            # the motion head is initialised in the trainer: rank 0's everywhere
+        enc.engine.mark_weights_changed()
+        opt, sc = tr.get_optimizer(5e-4)
+        per, ragged = 64, 57
+        batches = []
+        for gb, n in ((0, per * world), (1, ragged * world)):
+            img, emb = bench.synthetic_batch(n, "cuda", seed=10 + gb, c_in=5, mean_std=RGB_MEAN_STD["fs"], target_dim=2 * bench.EMB_DIM)
+            sl = shard_slice(n, rank, world)
+            batches.append({"img": img[sl], "emb": emb[sl]})
+        ep = tr.epoch(batches, optimizer=opt, scaler=sc)
+        torch.cuda.synchronize()
+        assert enc.engine.sync_errors() == 0
+        pl = enc.engine._step_plan
+        digest = hashlib.sha256(enc.engine.params.cpu().numpy().tobytes()).hexdigest()
+        q.put((rank, ep, digest, bool(pl.early_bucket0), int(batches[1]["img"].shape[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("early", ["1", "0"], ids=["bucket0_early", "bucket0_merged"])
+def test_four_ranks_ragged_final_batch_keep_identical_replicas(early):
+    """VERDICT r4 #7 (as far as one GPU goes: the pool allows at most six processes on a card and the test runner is one of them,
+    so four ranks here; all eight run on the CPU in tests/test_ddp_cpu.py::test_eight_ranks_ragged_final_batch_and_lazy_exchange): the
+    configs[3] recipe -- fs normalisation, motion head -- over a full and a ragged global batch through ModelTrainer.epoch, every rank
+    with the reducer attached and lazy gradients; all replicas hold the same bits afterwards, the epoch value is the same on
+    every rank, and the data-parallel creation flag (layer4's weight gradients launched at layer4's end: bucket 0 early) is set
+    by default and not with VPD_DDP_EARLY_BUCKET0=0 (the flag only moves launches: the two settings agree to rounding)."""
+    import torch.multiprocessing as mp
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main_c4, args=(r, world, port, q, early)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len({r[2] for r in res}) == 1, [r[2][:12] for r in res]          # bit-identical replicas
+    assert len({r[1] for r in res}) == 1 and np.isfinite(res[0][1])           # the all-reduced epoch value
+    assert all(r[3] == (early == "1") for r in res)
+    assert all(r[4] == 57 for r in res)
+    # (the two settings split layer3 / layer4's weight-gradient sums over blocks differently -- the cost model sees other launches --
+    #  so their fp32 partial sums round differently: the epoch values agree closely, the bits need not)
+    _C4_EPOCH[early] = res[0][1]
+    if len(_C4_EPOCH) == 2:
+        assert abs(_C4_EPOCH["1"] / _C4_EPOCH["0"] - 1) < 1e-3, _C4_EPOCH
+
+
+_C4_EPOCH = {}
+
+
+def test_bench_c4_four_ranks_reports_its_multi_gpu_block():
+    """`bench.py --config c4 --gpus 4` (gloo, shared GPU, 32 crops per rank): one JSON line whose multi_gpu block is well formed --
+    backend, world size, per-bucket all-reduce timings, overlap on / off, the early-bucket-0 flag and `replicas_identical`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VPD_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--config", "c4", "--steps", "2", "--warmup", "1",
+                        "--repeats", "1", "--batch", "32", "--profile-steps", "0", "--no-cpu-baseline", "--no-apply"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 128 and out["config"]["workload"].startswith("configs[3]")
+    mg = out["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["world_size"] == 4 and mg["lazy_gradients"] is True
+    assert mg["early_bucket0"] is True and mg["replicas_identical"] is True
+    assert len(mg["allreduce_per_bucket"]) == 4 and all(b["busbw_GBps"] > 0 for b in mg["allreduce_per_bucket"])
+    assert mg["ms_per_step_overlap_on"] > 0 and mg["ms_per_step_overlap_off"] > 0

@@ -377,3 +377,23 @@ def test_pretrained_checkpoint_lookup_prefers_the_v1_file_and_refuses_to_guess(t
     (tmp_path / "hub" / "checkpoints" / "resnet18-f37072fd.pth").write_bytes(b"v1")
     monkeypatch.delenv("VPD_PRETRAINED_WEIGHTS")
     assert find_imagenet_weights("resnet18").endswith("resnet18-f37072fd.pth")
+
+
+def test_streaming_writer_merges_late_frames_of_a_flushed_video(tmp_path):
+    """StreamingWriter (row f4; reference apply_vpd_model.py:171-178 writes every video once, at the end): a video whose frame
+    count was under-estimated is flushed early; frames that arrive afterwards must end up in the SAME pickle, sorted, not in a
+    file that holds the late frames only."""
+    from vpd_amd.apply import StreamingWriter
+    w = StreamingWriter(str(tmp_path), ["a", "b"], [2, 3])          # "a" really has 4 frames
+    e = lambda f: (f, np.full((2, 4), f, np.float32), {})
+    w.add_many(0, [e(0), e(1)])                                     # -> flushed (count reached)
+    w.add_many(1, [e(0), e(1)])
+    w.add_many(0, [e(3), e(2)])                                     # late frames: a second flush of "a"
+    w.add(1, e(2))
+    w.close()
+    assert sorted(w.written) == ["a", "b"]
+    with open(os.path.join(str(tmp_path), "a.emb.pkl"), "rb") as fp:
+        got = pickle.load(fp)
+    assert [g[0] for g in got] == [0, 1, 2, 3] and all(float(g[1][0, 0]) == g[0] for g in got)
+    with open(os.path.join(str(tmp_path), "b.emb.pkl"), "rb") as fp:
+        assert [g[0] for g in pickle.load(fp)] == [0, 1, 2]

@@ -4,6 +4,7 @@ batches of BATCH_SIZE frames x k views -> embed -> per-video sorted list of
 hipGraph-captured per batch shape; embeddings leave the GPU once per batch."""
 import gc
 import os
+import pickle
 
 import numpy as np
 import torch
@@ -32,6 +33,7 @@ class StreamingWriter:
         self.remaining = list(frames_per_video)
         self.pending = [list() for _ in self.videos]
         self.written = []
+        self._flushed = set()
         if out_dir is not None:
             os.makedirs(out_dir, exist_ok=True)
 
@@ -51,9 +53,17 @@ class StreamingWriter:
     def flush(self, video_id):
         embs = self.pending[video_id]
         if embs and self.out_dir is not None:
+            path = os.path.join(self.out_dir, '{}.emb.pkl'.format(self.videos[video_id]))
+            if self.videos[video_id] in self._flushed:
+                # frames of a video whose pickle is already on disk (its frame count was under-estimated): the file would be
+                # overwritten with the late frames only -- merge with what was written instead of losing it silently
+                with open(path, 'rb') as fp:
+                    embs = pickle.load(fp) + embs
             embs.sort(key=lambda t: t[0])
-            store_pickle(os.path.join(self.out_dir, '{}.emb.pkl'.format(self.videos[video_id])), embs)
-            self.written.append(self.videos[video_id])
+            store_pickle(path, embs)
+            if self.videos[video_id] not in self._flushed:
+                self.written.append(self.videos[video_id])
+            self._flushed.add(self.videos[video_id])
         self.pending[video_id] = []
 
     def close(self):
@@ -107,11 +117,15 @@ def embed_dataset(encoder, loader, n_videos, progress_cb=None, use_graph=True, w
     # crops/s into 95 k) with the GPU idle behind it.  gc.freeze() parks everything allocated so far in the permanent
     # generation: the collector stays ON for the whole job (hours for a large data set: cycles made by the loader, its
     # workers or the writer are still collected), its passes only walk what the job itself has allocated since.
-    gc.freeze()
+    # (a freeze the CALLER made is the caller's to undo: only our own is lifted)
+    ours = gc.get_freeze_count() == 0
+    if ours:
+        gc.freeze()
     try:
         return _embed_loop(encoder, eng, loader, graphs, host, drain, writer, all_embs, augmenter, flip, use_graph)
     finally:
-        gc.unfreeze()
+        if ours:
+            gc.unfreeze()
 
 
 def _embed_loop(encoder, eng, loader, graphs, host, drain, writer, all_embs, augmenter, flip, use_graph):

@@ -135,7 +135,9 @@ struct vpd_plan {
     bool relu_bits = true;      // block-output ReLU masks as bit maps (VPD_RELU_BITS=0: masks from the stored activation, g written back)
     bool lazy_next = false, grads_in_scratch = false;
     int nstem_unpack_blocks = 0;           // leading entries of bmap_unpack[3] that belong to the stem
-    bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0: per stage)
+    bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0, or the
+                                // data-parallel creation flag VPD_TRAIN_EARLY_BUCKET0: per stage)
+    bool early_bucket0 = false;
     size_t wg2_tbl_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // task tables of the persistent weight-gradient launches (two per stage)
     void* wg2_cache[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
@@ -237,6 +239,7 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
     vpd_plan* p = new vpd_plan();
     p->c_in = c_in; p->H = img_h; p->W = img_w; p->D = emb_dim; p->motion = motion ? 1 : 0;
     p->max_batch = max_batch; p->train = train ? 1 : 0; p->layers = layers;
+    p->early_bucket0 = (train & VPD_TRAIN_EARLY_BUCKET0) != 0;
     p->bottleneck = bottleneck; p->base_width = base_width; p->feat = bottleneck ? 2048 : 512;
 
     // ---- topology + flat tables (reference module order) ----
@@ -484,7 +487,10 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
         // grouped weight gradients: every eligible 3x3 stride-1 conv keeps its own dz until the
         // stage's grouped launch; the stage's slab holds every problem's splits at once
         p->wg_group = !(getenv("VPD_WG_GROUP") && !atoi(getenv("VPD_WG_GROUP")));
-        p->wg_merge34 = !(getenv("VPD_WG_MERGE") && !atoi(getenv("VPD_WG_MERGE")));
+        // data parallel (VPD_TRAIN_EARLY_BUCKET0): layer4's weight gradients get a launch of their own at the end of layer4's
+        // backward, so that bucket 0 -- fc + layer4, 61 % of the gradient bytes -- is handed to the reducer there instead of
+        // together with bucket 1 behind layer3 (single GPU: the merged launch fills the chip, +0.5 % on the step)
+        p->wg_merge34 = !(getenv("VPD_WG_MERGE") && !atoi(getenv("VPD_WG_MERGE"))) && !p->early_bucket0;
         if (p->wg_group) {
             // slabs of one LAUNCH live side by side: with wg_merge34 the stages 2 and 3 (layer3, layer4) share a launch
             size_t stage_slab[4] = {0, 0, 0, 0};

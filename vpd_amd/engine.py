@@ -19,6 +19,12 @@ BOTTLENECK_ARCHS = ("resnet50", "resnet101", "wide_resnet50_2", "wide_resnet101_
 _STAGE_WIDTH = (64, 128, 256, 512)
 
 
+def _world_size():
+    """Ranks of the default process group (1 when torch.distributed is not initialised)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def encoder_param_names(arch):
     """Trainable tensors / BN buffers of the encoder in reference state_dict order."""
     if arch not in ENCODER_LAYERS:
@@ -59,7 +65,13 @@ class _Plan:
         L = lib()
         self.h, self.w, self.max_batch, self.train, self.motion = h, w, max_batch, train, motion
         handle = C.c_void_p()
-        check(L.vpd_plan_create(eng.arch.encode(), eng.c_in, h, w, eng.emb_dim, int(motion), max_batch, int(train),
+        # data parallel: bucket 0 (fc + layer4, 61 % of the gradient bytes) is handed to the reducer at the end of layer4's backward
+        # instead of behind layer3's (include/vpd_hip.h, VPD_TRAIN_EARLY_BUCKET0); VPD_DDP_EARLY_BUCKET0=0 keeps the merged launch
+        flags = int(bool(train))
+        self.early_bucket0 = bool(train) and _world_size() > 1 and os.environ.get("VPD_DDP_EARLY_BUCKET0", "1") != "0"
+        if self.early_bucket0:
+            flags |= 2
+        check(L.vpd_plan_create(eng.arch.encode(), eng.c_in, h, w, eng.emb_dim, int(motion), max_batch, flags,
                                 C.byref(handle)), "vpd_plan_create")
         self.handle = handle
         # the C side is the source of truth for the flat layout: verify ours
