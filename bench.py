@@ -516,6 +516,7 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "repeats": {"n": len(region_s), "pick": "median", "crops_per_s": [args.batch * world * args.steps / t for t in region_s]},
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "gpu_unique_id": __import__("vpd_amd.boxid", fromlist=["gpu_unique_id"]).gpu_unique_id(local_rank),
                "config": {"workload": cfg["what"] % ("ResNet-34" if args.arch == ARCH else args.arch) + ", batch=%d per GPU" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "flop_per_crop": flop, "loss_last_step": loss_now},
