@@ -384,7 +384,7 @@ def test_four_ranks_ragged_final_batch_keep_identical_replicas(early):
     configs[3] recipe -- fs normalisation, motion head -- over a full and a ragged global batch through ModelTrainer.epoch, every rank
     with the reducer attached and lazy gradients; all replicas hold the same bits afterwards, the epoch value is the same on
     every rank, and the data-parallel creation flag (layer4's weight gradients launched at layer4's end: bucket 0 early) is set
-    by default and not with VPD_DDP_EARLY_BUCKET0=0 (the flag only moves launches: the two settings agree to rounding)."""
+    with VPD_DDP_EARLY_BUCKET0=1 and not otherwise (the flag only moves launches: the two settings agree to rounding)."""
     import torch.multiprocessing as mp
     world = 4
     ctx = mp.get_context("spawn")
@@ -420,6 +420,7 @@ def test_bench_c4_four_ranks_reports_its_multi_gpu_block():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["VPD_DIST_BACKEND"] = "gloo"
+    env["VPD_DDP_EARLY_BUCKET0"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--config", "c4", "--steps", "2", "--warmup", "1",
                         "--repeats", "1", "--batch", "32", "--profile-steps", "0", "--no-cpu-baseline", "--no-apply"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
@@ -428,6 +429,6 @@ def test_bench_c4_four_ranks_reports_its_multi_gpu_block():
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 128 and out["config"]["workload"].startswith("configs[3]")
     mg = out["multi_gpu"]
     assert mg["backend"] == "gloo" and mg["world_size"] == 4 and mg["lazy_gradients"] is True
-    assert mg["early_bucket0"] is True and mg["replicas_identical"] is True
+    assert mg["early_bucket0"] is True and mg["replicas_identical"] is True      # (VPD_DDP_EARLY_BUCKET0=1 in this run's environment)
     assert len(mg["allreduce_per_bucket"]) == 4 and all(b["busbw_GBps"] > 0 for b in mg["allreduce_per_bucket"])
     assert mg["ms_per_step_overlap_on"] > 0 and mg["ms_per_step_overlap_off"] > 0

@@ -65,10 +65,12 @@ class _Plan:
         L = lib()
         self.h, self.w, self.max_batch, self.train, self.motion = h, w, max_batch, train, motion
         handle = C.c_void_p()
-        # data parallel: bucket 0 (fc + layer4, 61 % of the gradient bytes) is handed to the reducer at the end of layer4's backward
-        # instead of behind layer3's (include/vpd_hip.h, VPD_TRAIN_EARLY_BUCKET0); VPD_DDP_EARLY_BUCKET0=0 keeps the merged launch
+        # data parallel, VPD_DDP_EARLY_BUCKET0=1: bucket 0 (fc + layer4, 61 % of the gradient bytes) is handed to the reducer at the
+        # end of layer4's backward instead of behind layer3's (include/vpd_hip.h, VPD_TRAIN_EARLY_BUCKET0).  OFF by default: the two
+        # weight-gradient launches it takes cost 3.1 % of a rank's step (profiles/r05_ab_wg_unmerge.txt) for certain, what the earlier
+        # all-reduce buys is unmeasured until a multi-GPU node runs bench.py with the switch both ways
         flags = int(bool(train))
-        self.early_bucket0 = bool(train) and _world_size() > 1 and os.environ.get("VPD_DDP_EARLY_BUCKET0", "1") != "0"
+        self.early_bucket0 = bool(train) and _world_size() > 1 and os.environ.get("VPD_DDP_EARLY_BUCKET0", "0") == "1"
         if self.early_bucket0:
             flags |= 2
         check(L.vpd_plan_create(eng.arch.encode(), eng.c_in, h, w, eng.emb_dim, int(motion), max_batch, flags,
