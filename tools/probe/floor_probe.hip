@@ -215,6 +215,79 @@ static void part3(Ctx& c) {
     printf("%-34s %10.2f   (rw sc1 alone %.2f us per launch)\n", "finalize, rows fresh from rw sc1", (cold_chain<0>(c, s, N, false, 1, 3) - base_sc1) / N, base_sc1 / N);
 }
 
+// ---- part 4: do a kernel's plain stores survive in its XCD's L2 for the NEXT kernel?  rwx reads what block (b + shift) % 256 of its
+// predecessor wrote and writes its own slice: shift 0 / 8 = producer on the same XCD (round-robin placement), shift 1 = another XCD ----
+__global__ __launch_bounds__(1024) void rwx_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long per_block_items, int shift) {
+    const long rb = (long)((blockIdx.x + shift) % gridDim.x) * per_block_items, wb = (long)blockIdx.x * per_block_items;
+    u32x4 v[4];
+    for (long i = threadIdx.x; i < per_block_items; i += 4096) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k * 1024 < per_block_items) v[k] = src[rb + i + k * 1024];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i + k * 1024 < per_block_items) { v[k].x += 1u; dst[wb + i + k * 1024] = v[k]; }
+    }
+}
+static void part4(Ctx& c) {
+    hipStream_t s; CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (!c.dst2) CHECK(hipMalloc(&c.dst2, 64l << 20));
+    const int N = 100;
+    printf("# part 4: hipGraph chains of %d x [rwx(a->b), rwx(b->a)], 256 blocks x 1024 threads, contiguous slice per block; us per launch\n", N);
+    printf("%6s %12s %12s %12s\n", "MB", "shift 0", "shift 8", "shift 1");
+    for (int mb : {2, 4, 8, 16, 32}) {
+        double t[3];
+        int sh[3] = {0, 8, 1};
+        for (int q = 0; q < 3; ++q) {
+            const long per = ((long)mb << 20) / 16 / 256;
+            hipGraph_t g; hipGraphExec_t ge;
+            CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            for (int r = 0; r < N; ++r) {
+                hipLaunchKernelGGL(rwx_kernel, dim3(256), dim3(1024), 0, s, (const u32x4*)c.buf, (u32x4*)c.dst2, per, sh[q]);
+                hipLaunchKernelGGL(rwx_kernel, dim3(256), dim3(1024), 0, s, (const u32x4*)c.dst2, (u32x4*)c.buf, per, sh[q]);
+            }
+            CHECK(hipStreamEndCapture(s, &g)); CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+            double best = 1e30;
+            for (int rep = 0; rep < 4; ++rep) {
+                CHECK(hipEventRecord(a, s)); CHECK(hipGraphLaunch(ge, s)); CHECK(hipEventRecord(b, s)); CHECK(hipEventSynchronize(b));
+                float ms = 0; CHECK(hipEventElapsedTime(&ms, a, b));
+                if (rep > 0) best = std::min(best, (double)ms * 1e3 / (2 * N));
+            }
+            CHECK(hipGraphExecDestroy(ge)); CHECK(hipGraphDestroy(g));
+            t[q] = best;
+        }
+        printf("%6d %12.2f %12.2f %12.2f\n", mb, t[0], t[1], t[2]);
+    }
+}
+
+// ---- part 5: which XCD does block b run on?  (HW_REG_XCC_ID, hwreg 20 on gfx940+) for the two launch shapes of the step ----
+__global__ void xcc_kernel(unsigned* out) {
+    extern __shared__ unsigned char dyn[];
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) { out[blockIdx.x] = v; if (dyn[0] == 77) out[0] = 0; }
+}
+static void part5(Ctx& c) {
+    unsigned* d; CHECK(hipMalloc(&d, 4096 * 4));
+    std::vector<unsigned> h(4096);
+    struct Shape { int grid, threads, lds; const char* what; } shapes[] = {
+        {256, 1024, 4096, "BatchNorm launch: 256 x 1024 threads, 4 KB LDS"},
+        {256, 512, 150 * 1024, "3x3 launch: 256 x 512 threads, 150 KB LDS"},
+        {256, 768, 150 * 1024, "3x3 launch, eight MFMA waves: 256 x 768 threads, 150 KB LDS"},
+        {512, 256, 0, "512 x 256 threads"}};
+    for (auto& sh : shapes) {
+        CHECK(hipMemset(d, 0xff, 4096 * 4));
+        (void)hipFuncSetAttribute((const void*)xcc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(xcc_kernel, dim3(sh.grid), dim3(sh.threads), sh.lds, c.s, d);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(h.data(), d, sh.grid * 4, hipMemcpyDeviceToHost));
+        int match = 0;
+        for (int b = 0; b < sh.grid; ++b) match += (int)(h[b] & 0xf) == (b & 7);
+        printf("%-62s XCC_ID == blockIdx %% 8 for %d of %d blocks; first 16:", sh.what, match, sh.grid);
+        for (int b = 0; b < 16; ++b) printf(" %u", h[b] & 0xf);
+        printf("\n");
+    }
+}
+
 static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
@@ -236,6 +309,7 @@ int main(int argc, char** argv) {
     printf("# floor_probe: %s, %d CUs, stream=%s, events=%d, reps=%d (medians; us)\n", prop.name, prop.multiProcessorCount, created ? "created(nonblocking)" : "null", (int)events, reps);
     if (chains_only) { part2(c, false, false); part2(c, true, false); part2(c, true, true); return 0; }
     if (argc > 1 && !strcmp(argv[1], "--cold")) { part3(c); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "--xcd")) { part4(c); part5(c); return 0; }
     printf("# writer_us / succ_us: dispatch-packet events (= rocprofv3 durations).  gap_us: last writer wave's vmcnt(0) -> first successor wave (s_memrealtime).\n");
     printf("%-8s %6s %-9s %10s %9s %8s %10s\n", "flavour", "MB", "successor", "writer_us", "succ_us", "gap_us", "pair_us");
     static const char* SNAME[4] = {"empty1", "empty256", "finalize", "stream"};

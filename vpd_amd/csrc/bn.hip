@@ -746,6 +746,33 @@ hipError_t vpd_launch_stem_pool_bwd(const StemPoolBwdParams& p0, float count, co
 // ===========================================================================
 #include "sync.h"
 
+static int vpd_bn_xcd_on() {      // VPD_BN_XCD=0: plain grid-stride order (same-box A/B; bit-identical either way)
+    static const int on = getenv("VPD_BN_XCD") ? atoi(getenv("VPD_BN_XCD")) : 1;
+    return on;
+}
+
+// XCD-affine block order of the fused BatchNorm launches (round 5).  conv3x3_pws_kernel runs pixel tile t (BM pixels) on XCD t % 8
+// (blocks b and b + 8 share an XCD), writes its z there and reads its halo from there; a BatchNorm launch whose blocks take the
+// items of a grid-stride iteration in plain order spreads every such tile over all eight XCDs, so each of the two hand-overs
+// (z: conv -> BatchNorm, activation: BatchNorm -> conv) goes through memory.  Here the R = tile_px / (pixels per block and
+// iteration) consecutive virtual blocks that cover one tile run on physical blocks of XCD t % 8: both hand-overs can hit that
+// XCD's L2 (layer3: 1.0 + 1.6 MB of z + activation per XCD, layer4 half of that).  Same items, same arithmetic: bit-identical.
+static __device__ __forceinline__ int vpd_bn_virtual_block(int b, int grid, int R) {
+    if (R <= 0 || grid != 256) return b;
+    const int x = b & 7, jj = b >> 3;
+    const int u = jj / R, r = jj - u * R;
+    return (u * 8 + x) * R + r;
+}
+// R for a launch of `grid` blocks of 1024 threads over items of 8 channels, or 0 when the tile does not map (host side)
+static int vpd_bn_xcd_r(int tile_px, int C, int grid) {
+    const int cv = C / 8;
+    if (tile_px <= 0 || grid != 256 || cv <= 0 || 1024 % cv != 0) return 0;
+    const int pb = 1024 / cv;                                   // pixels per block and iteration
+    if (tile_px % pb != 0) return 0;
+    const int R = tile_px / pb;
+    return (R >= 1 && R <= 32 && 32 % R == 0) ? R : 0;
+}
+
 struct BnFusedFwdArgs {
     double* rows; float count;                 // this BatchNorm's accumulator rows [VPD_FUSED_ROWS][2][C]
     const float* gamma; const float* beta; float* rm; float* rv;
@@ -755,6 +782,7 @@ struct BnFusedFwdArgs {
     const float* gamma2; const float* beta2; float* rm2; float* rv2;
     float* mean2; float* rstd2; float* scale2; float* shift2;
     float momentum, eps;
+    int xcd_r;                                 // vpd_bn_virtual_block
 };
 
 __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams p, const BnFusedFwdArgs f) {
@@ -797,7 +825,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const BnApplyParams 
         else if (p.res_kind == 2) rv = vpd_load16<VPD_CL_BN>(p.res + (size_t)m * C + cc);
         o = ((size_t)(b * p.oHp + y + p.opad) * p.oWp + x + p.opad) * C + cc;
     };
-    long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long it = (long)vpd_bn_virtual_block(blockIdx.x, gridDim.x, f.xcd_r) * blockDim.x + threadIdx.x;
     bool have = it < total;
     uint4 zc = uint4{0u, 0u, 0u, 0u}, rc = zc; size_t oo = 0; int c = 0;
     if (have) load_item(it, zc, rc, oo, c);
@@ -907,6 +935,11 @@ hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f0,
     // every block pays the finalize prologue (2*C*VPD_FUSED_ROWS doubles): few, fat blocks -- one per CU
     if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
+    const int xcd_on = vpd_bn_xcd_on();
+    f.xcd_r = xcd_on ? vpd_bn_xcd_r(p.xcd_tile_px, p.C, (int)g) : 0;
+#ifdef VPD_ENABLE_ABLATE      // tools/bench_bn_chain.py: the operator-level entry point knows no neighbouring convolution
+    if (const char* e = getenv("VPD_BN_XCD_FORCE")) f.xcd_r = vpd_bn_xcd_r(atoi(e), p.C, (int)g);
+#endif
     hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)g), dim3(1024), (size_t)4 * p.C * sizeof(float), s, p, f);
     return hipGetLastError();
 }
@@ -1084,6 +1117,7 @@ struct BnBwdApplyArgs {
     // PAIR: a second BatchNorm fed with the same g (the 1x1 branch of a down-sampling block)
     const double* rows2; const float* gamma2; const float* mean2; const float* rstd2; float* dgamma2; float* dbeta2;
     const bf16_t* z2; bf16_t* dz2;
+    int xcd_r;                                 // vpd_bn_virtual_block
 };
 static __device__ __forceinline__ void bn_bwd_apply_coef(const double* rows, int C, int ch, float count, float gamma, float mean,
                                                          float rstd, float* A, float* B, float* D, float* dgamma, float* dbeta,
@@ -1139,7 +1173,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdPar
         bits = p.mask_bits[i];                                     // i = m * (C / 8) + c / 8
         o = ((size_t)(b * p.dzHp + y + p.dzpad) * p.dzWp + x + p.dzpad) * C + cc;
     };
-    long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long it = (long)vpd_bn_virtual_block(blockIdx.x, gridDim.x, f.xcd_r) * blockDim.x + threadIdx.x;
     bool have = it < total;
     uint4 gc = uint4{0u, 0u, 0u, 0u}, zc = gc, z2c = gc; unsigned bc = 0; size_t oo = 0; int c = 0;
     if (have) load_item(it, gc, zc, z2c, bc, oo, c);
@@ -1208,6 +1242,8 @@ hipError_t vpd_launch_bn_bwd_apply_fused(const BnBwdParams& p, const BnFusedBwd&
     long g = (items + 1023) / 1024;
     if (g > 256) g = 256;      // (one 1024-thread block per CU: same-box -10 us per step against two; 192 or fewer: +110 us)
     if (g < 1) g = 1;
+    const int xcd_on = vpd_bn_xcd_on();
+    f.xcd_r = xcd_on ? vpd_bn_xcd_r(p.xcd_tile_px, p.C, (int)g) : 0;
     if (fB) {
         f.rows2 = fB->rows; f.gamma2 = fB->gamma; f.mean2 = meanB; f.rstd2 = rstdB; f.dgamma2 = fB->dgamma; f.dbeta2 = fB->dbeta;
         f.z2 = zB; f.dz2 = dzB;

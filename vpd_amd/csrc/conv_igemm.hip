@@ -1671,6 +1671,27 @@ int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g) {
 }
 int vpd_conv_kernel_class(const ConvParams& p) { HaloGeom g; return vpd_conv_kernel_class(p, &g); }
 
+// Pixels per tile when `p` runs on conv3x3_pws_kernel with its XCD-affine tile order (launch_pws: lanes a multiple of 8, so that
+// pixel tile t -- and every later tile of its block -- sits on XCD t % 8), else 0.  The fused BatchNorm launches on either side of
+// such a convolution order their blocks to match (bn.hip, vpd_bn_virtual_block).
+int vpd_conv_xcd_tile_px(const ConvParams& p) {
+    HaloGeom g;
+    if (!pws_enabled(p)) return 0;
+    int bm = 0, bn = 0;
+    switch (vpd_conv_kernel_class(p, &g)) {
+        case 1: if ((p.M + 255) / 256 > pws_cu_count() / (p.Co / 128)) { bm = 256; bn = 128; } break;
+        case 2: bm = 128; bn = 128; break;
+        case 3: bm = 128; bn = 64; break;
+        case 6: bm = 256; bn = 64; break;
+        default: break;
+    }
+    if (!bm) return 0;
+    const int MT = (p.M + bm - 1) / bm, NT = p.Co / bn;
+    int lanes = pws_cu_count() / NT;
+    if (lanes > MT) lanes = MT;
+    return lanes >= 8 ? bm : 0;
+}
+
 // true when this launch's kernel can take the sums of the consuming BatchNorm's backward in its epilogue (bst_z / bst_mask)
 bool vpd_conv_takes_bn_sums(const ConvParams& p) {
     if (p.ep_scale || p.alt_w || p.yC != p.Co || p.ypad != 0) return false;

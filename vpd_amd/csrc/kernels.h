@@ -13,6 +13,7 @@ struct BnApplyParams {
     bf16_t* out; int oHp, oWp, opad;    // padded output
     int M, H, W, C, relu;
     unsigned char* mask_out;            // fused forward only: [M][C/8] bytes, bit j of byte (m, c8) = out[m][8*c8 + j] > 0, or null
+    int xcd_tile_px;                    // fused forward only: pixel tile of the neighbouring 3x3 launches (vpd_bn_virtual_block) or 0
 };
 
 struct StemPoolParams {
@@ -42,6 +43,7 @@ struct BnBwdParams {
     // bf16(dy_pooled[b][c] * dy_pool_scale) (avgpool_bwd_kernel's value).  The kernel computes it, uses it, and writes it to dy_rw
     // (unmasked: the identity path of the block adds onto it later) -- the avgpool_bwd launch in front of it is gone
     const float* dy_pooled; float dy_pool_scale;
+    int xcd_tile_px;                    // bn_bwd_apply_fused_kernel only: as BnApplyParams::xcd_tile_px
 };
 
 struct StemPoolBwdParams {
@@ -70,7 +72,9 @@ struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
-bool vpd_conv_takes_bn_sums(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
+bool vpd_conv_takes_bn_sums(const ConvParams& p);
+// pixels per tile when `p` runs on conv3x3_pws_kernel with its XCD-affine tile order (pixel tile t on XCD t % 8), else 0
+int vpd_conv_xcd_tile_px(const ConvParams& p);         // epilogue can take the consuming BatchNorm's backward sums (bst_z)
 hipError_t vpd_launch_wgrad_reduce(const WgradParams& p, hipStream_t stream);   // slab sum of a deferred halo wgrad
 extern "C" int vpd_conv_bm(int M, int Co);
 hipError_t vpd_launch_wgrad(const WgradParams& p, hipStream_t stream);

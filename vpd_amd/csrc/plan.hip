@@ -913,6 +913,15 @@ hipError_t run_conv_train(const Ctx& c, const ConvInfo& cv, const bf16_t* x, flo
 
 // BatchNorm (+ residual, ReLU) of a train-mode forward: statistics -> normalised padded activation.  rcv: the
 // down-sampling branch's conv (res_kind 2), whose BatchNorm is finalized here too.  One launch when fused.
+// Pixel tile of the pipelined 3x3 launches next to conv `cv`'s BatchNorm (its own forward / data gradient, and -- same stage, same
+// shape -- its neighbours'), when they run in their XCD-affine tile order: the fused BatchNorm launches then take their items in
+// the matching block order (bn.hip, vpd_bn_virtual_block).  3x3 stride-1 convolutions with Ci == Co only; 0 otherwise.
+int bn_xcd_tile_px(const Ctx& c, const ConvInfo& cv) {
+    if (cv.k != 3 || cv.stride != 1 || cv.stem || cv.Ci != cv.Co) return 0;
+    const ConvParams q = conv_dgrad_s1_params(c, cv, c.b16(0), c.b16(0), 0);
+    return vpd_conv_xcd_tile_px(q);
+}
+
 hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int res_kind, const bf16_t* res,
                       const ConvInfo* rcv, bf16_t* out, int relu, unsigned char* mask_out = nullptr) {
     if (!c.fused(cv)) return run_bn_apply(c, cv, res_kind, res, rcv, out, relu);      // (finalized by run_conv_train)
@@ -923,6 +932,7 @@ hipError_t run_bn_fwd(const Ctx& c, const ConvInfo& cv, float* bn_running, int r
     a.out = out; a.oHp = cv.Hout + 2; a.oWp = cv.Wout + 2; a.opad = 1;
     a.M = c.n * cv.Hout * cv.Wout; a.H = cv.Hout; a.W = cv.Wout; a.C = cv.Co; a.relu = relu;
     a.mask_out = mask_out;
+    a.xcd_tile_px = bn_xcd_tile_px(c, cv);
     BnFusedFwd f;
     memset(&f, 0, sizeof f);
     auto fill = [&](const ConvInfo& k, double** rows, float* count, const float** gamma, const float** beta, float** rm,
@@ -992,6 +1002,7 @@ hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, 
     b.dz = dz; b.dzHp = cv.Hout + 2 * dzpad; b.dzWp = cv.Wout + 2 * dzpad; b.dzpad = dzpad;
     b.M = c.n * cv.Hout * cv.Wout; b.H = cv.Hout; b.W = cv.Wout; b.C = cv.Co;
     b.mask_bits = mask_bits;
+    b.xcd_tile_px = bn_xcd_tile_px(c, cv);
     BnFusedBwd f;
     memset(&f, 0, sizeof f);
     f.rows = c.bn_rows(cv.bn);
