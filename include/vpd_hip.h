@@ -203,6 +203,15 @@ int vpd_op_conv2d(const void* x_bf16, const void* w_bf16, void* y_bf16, double* 
                   int xC, int yHp, int yWp, int yC, int ypad, int Hs, int Ws, int osub, int oph, int opw, int istr,
                   int Kc, int Co, const int* tapset9, int accumulate, void* stream);
 int vpd_op_conv_bm(int M, int Co);
+/* The same launch with the epilogues the plan uses besides store / statistics (stride-1 output grid, osub 1):
+ *  - eval (models/module.py:41-47 folded: BatchNorm's running statistics as scale / shift [Co] floats, the block's identity
+ *    path, ReLU): y = relu?(ep_scale * conv + ep_shift (+ res)), res = bf16 NHWC padded by 1 with Co channels or null;
+ *  - accumulate onto a dense y (a data gradient on top of the identity path), the OLD value first multiplied by the ReLU
+ *    bit map acc_mask [M][Co/8] (bit j of byte (m, c8) keeps channel 8 c8 + j) when given. */
+int vpd_op_conv2d_ep(const void* x_bf16, const void* w_bf16, void* y_bf16, int n, int xHp, int xWp, int xC, int yHp, int yWp,
+                     int yC, int ypad, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9, const float* ep_scale,
+                     const float* ep_shift, const void* res_padded_bf16, int ep_relu, int accumulate,
+                     const unsigned char* acc_mask, void* stream);
 /* The same launch as a DATA GRADIENT that also takes the sums of the BatchNorm backward consuming its output d (epilogue
  * modes 6 / 7, reference: the reductions inside torch's batch_norm backward for models/module.py:41-43): g = d * mask with
  * mask = the ReLU bit map [M][Co/8] of that BatchNorm's activation, rows f64 [4][2][Co] (pre-zeroed) receive sum g and

@@ -425,3 +425,113 @@ def test_conv_epilogue_batchnorm_sums(case, accumulate):
     want1, want2 = gm.sum(0), (gm * z.double()).sum(0)
     assert float((s[0] - want1).abs().max()) <= 2e-5 * float(gm.abs().sum(0).max())
     assert float((s[1] - want2).abs().max()) <= 2e-5 * float((gm * z.double()).abs().sum(0).max())
+
+
+# conv1x1_stream_kernel (conv_stream.hip): the persistent streaming kernel of the Bottleneck students' layer1 / layer2 1x1 convs.
+# It takes a launch only with >= 2 pixel tiles per CU, so these cases are large: every (input channels, channel tile) shape of
+# its launcher, stride 2 (a down-sampling branch), forward + statistics, data gradient, accumulate.
+STREAM_CASES = [
+    # name, N, Ci, Co, H, W, stride
+    ("k64_n64", 64, 64, 64, 32, 32, 1),
+    ("k64_n128", 64, 64, 128, 32, 32, 1),
+    ("k64_n256_and_k256_n64", 64, 64, 256, 32, 32, 1),
+    ("k128_n64", 256, 128, 64, 16, 16, 1),
+    ("k128_n128", 256, 128, 128, 16, 16, 1),
+    ("k128_n512", 128, 128, 512, 16, 16, 1),
+    ("k256_n128_and_k128_n256", 128, 256, 128, 16, 16, 1),
+    ("k256_n512_s2", 128, 256, 512, 32, 32, 2),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_conv1x1_stream_kernel(case):
+    name, n, ci, co, h, w, stride = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = bf16_round(torch.randn(n, ci, h, w, generator=g))
+    wt = bf16_round(torch.randn(co, ci, 1, 1, generator=g) * (2.0 / ci) ** 0.5)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wt, None, stride=stride)
+    dz = bf16_round(torch.randn(ref.shape, generator=g))
+    ref.backward(dz)
+    xp = to_padded_nhwc(x, 1, 1, 1, 1)
+    taps = tapset(1, 1, 1, 1, 1, 1, 0, 1, 1)
+    y, stats = run_conv(xp, pack_fwd(wt), n, h + 2, w + 2, ci, ho, wo, 0, ho, wo, 1, 0, 0, stride, ci, co, taps, want_stats=True)
+    got = from_nhwc(y, n, ho, wo, co, 0)
+    assert rel_l2(got, ref.detach()) < REL_TOL
+    s = stats.sum(dim=0).cpu()
+    assert rel_l2(s[0], got.sum(dim=(0, 2, 3))) < 1e-4
+    assert rel_l2(s[1], (got * got).sum(dim=(0, 2, 3))) < 1e-4
+    # padded output (the eval forward writes activations with their border): same values, border untouched
+    yp, _ = run_conv(xp, pack_fwd(wt), n, h + 2, w + 2, ci, ho, wo, 1, ho, wo, 1, 0, 0, stride, ci, co, taps)
+    ypv = yp.view(n, ho + 2, wo + 2, co)
+    assert torch.equal(ypv[:, 1:-1, 1:-1], y.view(n, ho, wo, co))
+    assert float(ypv[:, 0].abs().max()) == 0.0 and float(ypv[:, :, 0].abs().max()) == 0.0
+    if stride != 1:
+        return
+    # data gradient (Co -> Ci), then once more on top (accumulate)
+    dzp = to_padded_nhwc(dz, 1, 1, 1, 1)
+    dx = torch.zeros(n * h * w * ci, dtype=torch.bfloat16, device="cuda")
+    run_conv(dzp, pack_dgrad(wt), n, ho + 2, wo + 2, co, h, w, 0, h, w, 1, 0, 0, 1, co, ci, taps, y=dx)
+    assert rel_l2(from_nhwc(dx, n, h, w, ci, 0), xr.grad) < REL_TOL
+    run_conv(dzp, pack_dgrad(wt), n, ho + 2, wo + 2, co, h, w, 0, h, w, 1, 0, 0, 1, co, ci, taps, y=dx, accumulate=1)
+    assert rel_l2(from_nhwc(dx, n, h, w, ci, 0), 2 * xr.grad) < 2 * REL_TOL
+
+
+def _pack_mask_bits(keep):
+    """bool [M][C] -> uint8 [M][C/8], bit j of byte (m, c8) = keep[m][8 c8 + j] (the fused forward BatchNorm's bit map)."""
+    m, c = keep.shape
+    k = keep.view(m, c // 8, 8).to(torch.int32)
+    return (k * (2 ** torch.arange(8, dtype=torch.int32))).sum(dim=2).to(torch.uint8)
+
+
+STREAM_EP_CASES = [
+    # name, N, Ci, Co, H, W
+    ("k64_n256", 64, 64, 256, 32, 32),       # a Bottleneck's closing 1x1 (eval: BatchNorm + identity + ReLU in the epilogue)
+    ("k256_n64", 64, 256, 64, 32, 32),       # its opening 1x1; as data gradient 64 -> 256 it adds onto the masked identity path
+    ("k128_n512", 128, 128, 512, 16, 16),
+    ("k256_n128", 64, 256, 128, 32, 32),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_EP_CASES, ids=[c[0] for c in STREAM_EP_CASES])
+def test_conv1x1_stream_kernel_eval_epilogue_and_masked_accumulate(case):
+    """vpd_op_conv2d_ep on shapes conv1x1_stream_kernel takes: (a) the eval epilogue relu(scale * conv + shift + residual) into a
+    padded activation, against fp32 torch on the same bf16 operands; (b) y = old * mask + conv with the ReLU bit map, the way a
+    Bottleneck's first data gradient lands on d(block output)."""
+    name, n, ci, co, h, w = case
+    L = _lib()
+    g = torch.Generator().manual_seed(hash(name) % 1000 + 7)
+    x = bf16_round(torch.randn(n, ci, h, w, generator=g))
+    wt = bf16_round(torch.randn(co, ci, 1, 1, generator=g) * (2.0 / ci) ** 0.5)
+    conv = F.conv2d(x, wt)
+    taps = tapset(1, 1, 1, 1, 1, 1, 0, 1, 1)
+    xp = to_padded_nhwc(x, 1, 1, 1, 1)
+    # (a) eval epilogue
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.3
+    res = bf16_round(torch.randn(n, co, h, w, generator=g))
+    for with_res in (False, True):
+        y = torch.zeros(n * (h + 2) * (w + 2) * co, dtype=torch.bfloat16, device="cuda")
+        resp = to_padded_nhwc(res, 1, 1, 1, 1) if with_res else None
+        sc, sh = scale.cuda(), shift.cuda()
+        _check(L.vpd_op_conv2d_ep(ptr(xp), ptr(pack_fwd(wt)), ptr(y), n, h + 2, w + 2, ci, h + 2, w + 2, co, 1, h, w, 1, ci, co, taps,
+                                  ptr(sc), ptr(sh), ptr(resp) if with_res else None, 1, 0, None, stream()))
+        torch.cuda.synchronize()
+        ref = conv * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+        if with_res:
+            ref = ref + res
+        ref = ref.clamp_min(0)
+        assert rel_l2(from_nhwc(y, n, h + 2, w + 2, co, 1), ref) < REL_TOL, with_res
+        yv = y.view(n, h + 2, w + 2, co)
+        assert float(yv[:, 0].abs().max()) == 0.0 and float(yv[:, :, -1].abs().max()) == 0.0
+    # (b) masked accumulate onto a dense y
+    old = bf16_round(torch.randn(n, co, h, w, generator=g))
+    keep = torch.rand(n, h, w, co, generator=g) > 0.4
+    yd = old.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda().flatten()
+    bits = _pack_mask_bits(keep.view(-1, co)).cuda()
+    _check(L.vpd_op_conv2d_ep(ptr(xp), ptr(pack_fwd(wt)), ptr(yd), n, h + 2, w + 2, ci, h, w, co, 0, h, w, 1, ci, co, taps,
+                              None, None, None, 0, 1, ptr(bits), stream()))
+    torch.cuda.synchronize()
+    ref = conv + old * keep.permute(0, 3, 1, 2).float()
+    assert rel_l2(from_nhwc(yd, n, h, w, co, 0), ref) < REL_TOL

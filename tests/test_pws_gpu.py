@@ -100,3 +100,25 @@ def test_train_steps_are_bit_identical_with_the_pool_gradient_folded():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("losses ")][-1]
     assert outs["pool_launch"] == outs["default"], outs
+
+
+def test_bottleneck_student_on_the_streaming_1x1_kernel_matches_the_gather_kernel(tmp_path):
+    """conv1x1_stream_kernel takes layer1's 1x1 convolutions of a ResNet-50 only from 64 crops per step up -- more than the golden
+    cases hold.  The train-mode loss and the eval-mode embedding of a 64-crop batch on freshly initialised weights, with it
+    (default) and without (VPD_CONV1X1_STREAM=0: conv_igemm_kernel, which the goldens pin).  Its outputs are bit-identical to the
+    gather kernel's and its statistics agree to 1e-8 (tests/test_ops_gpu.py covers both against torch): eval embeddings must be
+    EQUAL, the train loss (batch statistics at 1e-8 flip a few bf16 roundings downstream) within 2e-3."""
+    import numpy as np
+    outs = {}
+    for name, extra in (("stream", {}), ("gather", {"VPD_CONV1X1_STREAM": "0"})):
+        env = dict(os.environ, **extra)
+        npy = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "step_digest.py"), "--arch", "resnet50", "--batch", "64",
+                            "--steps", "1", "--eval-first", "--eval-out", npy], env=env, capture_output=True, text=True, timeout=900,
+                           cwd=REPO)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("losses ")][-1]
+        outs[name] = (float(line.split()[1]), np.load(npy))
+    (ls, es), (lg, eg) = outs["stream"], outs["gather"]
+    assert abs(ls - lg) <= 2e-3 * abs(lg), (ls, lg)
+    assert np.array_equal(es, eg), float(np.abs(es - eg).max())

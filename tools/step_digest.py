@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--arch", default="resnet34")
+    ap.add_argument("--eval-out", default=None, help="also embed the batch in eval mode and save the array here (.npy)")
+    ap.add_argument("--eval-first", action="store_true", help="... before the steps (freshly initialised weights) instead of after them")
     args = ap.parse_args()
     from vpd_amd.data import RGB_MEAN_STD
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
@@ -29,6 +31,9 @@ def main():
     trainer = ModelTrainer(enc, motion=False)
     optimizer, scaler = trainer.get_optimizer(5e-4)
     img, emb = bench.synthetic_batch(args.batch, device, seed=1, c_in=5, mean_std=RGB_MEAN_STD["diving48"], target_dim=bench.EMB_DIM)
+    if args.eval_out and args.eval_first:
+        import numpy as np
+        np.save(args.eval_out, enc.embed(img))
     enc.train()
     eng = enc.engine
     losses = []
@@ -41,6 +46,9 @@ def main():
     h.update(eng.params.detach().cpu().numpy().tobytes())
     h.update(eng.bn_running.detach().cpu().numpy().tobytes())
     print("losses %s  params+bn sha256 %s" % (" ".join("%.9g" % v for v in losses), h.hexdigest()[:20]))
+    if args.eval_out and not args.eval_first:
+        import numpy as np
+        np.save(args.eval_out, enc.embed(img))
 
 
 if __name__ == "__main__":

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vpd_plan_read_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int]),
     "vpd_op_conv2d": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 16 + [c_int_p, C.c_int, vp]),
     "vpd_op_conv_bm": (C.c_int, [C.c_int, C.c_int]),
+    "vpd_op_conv2d_ep": (C.c_int, [vp, vp, vp] + [C.c_int] * 13 + [c_int_p, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "vpd_op_conv2d_bnsums": (C.c_int, [vp] * 6 + [C.c_int] * 8 + [c_int_p, C.c_int, vp]),
     "vpd_op_bn_forward": (C.c_int, [vp] * 13 + [C.c_int] * 5 + [C.c_float, C.c_float, vp]),
     "vpd_op_bn_backward_apply": (C.c_int, [vp] * 10 + [C.c_int] * 4 + [vp]),

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "conv_epilogue.h"
+#include "kernels.h"
 
 template <int BM, int BN, int WM, int WN, int EPM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p0) {
@@ -1763,6 +1764,7 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
         case 5: { int tr; stem_eligible(p, &tr); return launch_stem(p, tr, stream); }
         default: break;
     }
+    if (vpd_conv1x1_stream_eligible(p)) return vpd_launch_conv1x1_stream(p, stream);
     if (conv1x1_ws_eligible(p)) return launch_1x1(p, stream);
     // the statistics accumulator rows only depend on the block index, so the tile choice is free
     const int bm = vpd_conv_bm(p.M, p.Co);

@@ -71,6 +71,9 @@ struct PackDesc {                       // one convolution's weight tensors
 struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
+// conv_stream.hip: persistent streaming kernel for 1x1 convolutions with <= 256 input channels on many pixels
+bool vpd_conv1x1_stream_eligible(const ConvParams& p);
+hipError_t vpd_launch_conv1x1_stream(const ConvParams& p, hipStream_t stream);
 int vpd_conv_kernel_class(const ConvParams& p);      // 0..4, see conv_igemm.hip
 bool vpd_conv_takes_bn_sums(const ConvParams& p);
 // pixels per tile when `p` runs on conv3x3_pws_kernel with its XCD-affine tile order (pixel tile t on XCD t % 8), else 0

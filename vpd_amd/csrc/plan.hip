@@ -1781,6 +1781,28 @@ extern "C" int vpd_op_conv2d(const void* x, const void* w, void* y, double* stat
     return 0;
 }
 
+extern "C" int vpd_op_conv2d_ep(const void* x, const void* w, void* y, int n, int xHp, int xWp, int xC, int yHp, int yWp,
+                                int yC, int ypad, int Hs, int Ws, int istr, int Kc, int Co, const int* tapset9,
+                                const float* ep_scale, const float* ep_shift, const void* res_padded, int ep_relu,
+                                int accumulate, const unsigned char* acc_mask, void* stream) {
+    if ((ep_scale == nullptr) != (ep_shift == nullptr)) return fail("ep_scale and ep_shift come together");
+    if (ep_scale && accumulate) return fail("eval epilogue or accumulate, not both");
+    if (res_padded && !ep_scale) return fail("a residual needs the eval epilogue");
+    if (acc_mask && (!accumulate || ypad != 0 || yC != Co || yHp != Hs || yWp != Ws)) return fail("acc_mask: accumulate onto a dense y");
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)x; q.xHp = xHp; q.xWp = xWp; q.xC = xC; q.w = (const bf16_t*)w;
+    q.y = (bf16_t*)y; q.yHp = yHp; q.yWp = yWp; q.yC = yC; q.ypad = ypad;
+    q.N = n; q.Hs = Hs; q.Ws = Ws; q.osub = 1; q.istr = istr;
+    q.Kc = Kc; q.Co = Co; q.M = n * Hs * Ws; q.accumulate = accumulate; q.acc_mask = acc_mask;
+    q.ep_scale = ep_scale; q.ep_shift = ep_shift; q.ep_relu = ep_relu;
+    if (res_padded) { q.res = (const bf16_t*)res_padded; q.rHp = Hs + 2; q.rWp = Ws + 2; q.rC = Co; q.rpad = 1; }
+    q.taps = tapset_from(tapset9);
+    if (q.taps.nr < 1 || q.taps.nc < 1) return fail("empty tap set");
+    LCHECK(vpd_launch_conv(q, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int vpd_op_conv2d_bnsums(const void* x, const void* w, void* y, const void* bst_z, const unsigned char* bst_mask,
                                     double* rows, int n, int xHp, int xWp, int xC, int Hs, int Ws, int Kc, int Co,
                                     const int* tapset9, int accumulate, void* stream) {
