@@ -1032,22 +1032,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const BnBwdParams p,
             for (int j = 0; j < 8; ++j) { a1[j] += __shfl_xor(a1[j], o, 64); a2[j] += __shfl_xor(a2[j], o, 64); }
         }
     }
+    // waves that hold the same channel groups: all 16 when cv <= 64, every (cv/64)-th otherwise (waves j, j + wstep, ...: their
+    // sums go to rows 0, 1, ... of `red`, [16 / wstep][2][C] floats -- 64 KB at most, also for 2,048 channels)
+    const int wstep = cv <= 64 ? 1 : cv / 64;
     if (lane < cv) {                                        // (cv >= 64: every lane; its channel group is c8)
+        const int rrow = wave / wstep;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            red[(size_t)(wave * 2 + 0) * C + c + j] = a1[j];
-            red[(size_t)(wave * 2 + 1) * C + c + j] = a2[j];
+            red[(size_t)(rrow * 2 + 0) * C + c + j] = a1[j];
+            red[(size_t)(rrow * 2 + 1) * C + c + j] = a2[j];
         }
     }
     __syncthreads();
-    // waves that hold the same channel groups: all 16 when cv <= 64, every (cv/64)-th otherwise
-    const int wstep = cv <= 64 ? 1 : cv / 64;
     for (int t = tid; t < 2 * C; t += T) {
         const int which = t / C;
         const int ch = t - which * C;
-        const int w0 = cv <= 64 ? 0 : (ch >> 3) / 64;
         float tot = 0.f;
-        for (int w = w0; w < 16; w += wstep) tot += red[(size_t)(w * 2 + which) * C + ch];
+        for (int k = 0; k < 16 / wstep; ++k) tot += red[(size_t)(k * 2 + which) * C + ch];
         atomicAdd(&f.rows[((size_t)(blockIdx.x & (VPD_FUSED_ROWS - 1)) * 2 + which) * C + ch], (double)tot);
     }
     vpd_grid_barrier(f.sync, false, f.err, blockIdx.x, gridDim.x);
@@ -1442,7 +1443,7 @@ hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p0, const BnFusedBwd& fA,
 // false: this shape has to take the three-launch path (vpd_launch_bn_bwd)
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g) {
     static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
-    if (off || C % 8 || C < 64 || C > 1024 || 1024 % (C / 8)) return false;
+    if (off || C % 8 || C < 64 || C > 2048 || 1024 % (C / 8)) return false;
     if (mask_act && !write_g) return false;             // (no caller: the masked g could not be recovered in phase 2)
     return M >= 1;
 }
@@ -1467,7 +1468,7 @@ hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, 
     f.rows = f0.rows; f.sync = reinterpret_cast<GridSync*>(f0.sync); f.err = f0.err; f.gamma = f0.gamma; f.dgamma = f0.dgamma; f.dbeta = f0.dbeta;
     f.count = f0.count;
     f.iters = ppb / ppi;
-    const size_t red_bytes = (size_t)16 * 2 * p.C * sizeof(float);
+    const size_t red_bytes = (size_t)(cv <= 64 ? 16 : 16 / (cv / 64)) * 2 * p.C * sizeof(float);
     const size_t tile = (size_t)f.iters * 1024 * 16;    // bytes of one resident tensor slice
     const size_t cap = 160 * 1024;
     const int mask = p.mask_bits ? 3 : (p.act ? 1 : (p.mscale ? 2 : 0));
