@@ -1120,23 +1120,6 @@ struct BnBwdApplyArgs {
     const bf16_t* z2; bf16_t* dz2;
     int xcd_r;                                 // vpd_bn_virtual_block
 };
-static __device__ __forceinline__ void bn_bwd_apply_coef(const double* rows, int C, int ch, float count, float gamma, float mean,
-                                                         float rstd, float* A, float* B, float* D, float* dgamma, float* dbeta,
-                                                         bool write) {
-    double s1 = 0.0, sz = 0.0;
-#pragma unroll
-    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
-        s1 += rows[((size_t)t * 2) * C + ch];
-        sz += rows[((size_t)t * 2 + 1) * C + ch];
-    }
-    const double mu = (double)mean, rs = (double)rstd;
-    const double sx = (sz - mu * s1) * rs;                         // sum g * xhat
-    const double a = (double)gamma * rs;
-    const double b = -a * rs * (sx / (double)count);
-    A[ch] = (float)a; B[ch] = (float)b;
-    D[ch] = (float)(-a * (s1 / (double)count) - b * mu);
-    if (write) { dbeta[ch] = (float)s1; dgamma[ch] = (float)sx; }
-}
 template <bool PAIR>
 __global__ __launch_bounds__(1024) void bn_bwd_apply_fused_kernel(const BnBwdParams p, const BnBwdApplyArgs f) {
     extern __shared__ float sm[];                      // A[C] B[C] D[C] (A2[C] B2[C] D2[C])

@@ -179,6 +179,27 @@ static __device__ __forceinline__ void bn_finalize_channel(const double* rows, i
     *mu_o = (float)mu; *r_o = r; *sc_o = sc; *sh_o = beta - (float)mu * sc; *var_o = var;
 }
 
+// One channel of a BatchNorm backward whose sums (sum g, sum g * z; g = dy * ReLU mask) sit in its fp64 rows [VPD_FUSED_ROWS][2][C]:
+// dz = A g + B z + D with A = gamma rstd, B = -A rstd mean(g xhat), D = -A mean(g) - B mean; dgamma = sum g xhat, dbeta = sum g
+// (bn_bwd_apply_fused_kernel, conv1x1_bn_stream_kernel).
+static __device__ __forceinline__ void bn_bwd_apply_coef(const double* rows, int C, int ch, float count, float gamma, float mean,
+                                                         float rstd, float* A, float* B, float* D, float* dgamma, float* dbeta,
+                                                         bool write, int oi = -1) {
+    if (oi < 0) oi = ch;                                           // A / B / D are indexed by oi (default: the channel)
+    double s1 = 0.0, sz = 0.0;
+#pragma unroll
+    for (int t = 0; t < VPD_FUSED_ROWS; ++t) {
+        s1 += rows[((size_t)t * 2) * C + ch];
+        sz += rows[((size_t)t * 2 + 1) * C + ch];
+    }
+    const double mu = (double)mean, rs = (double)rstd;
+    const double sx = (sz - mu * s1) * rs;                         // sum g * xhat
+    const double a = (double)gamma * rs;
+    const double b = -a * rs * (sx / (double)count);
+    A[oi] = (float)a; B[oi] = (float)b;
+    D[oi] = (float)(-a * (s1 / (double)count) - b * mu);
+    if (write) { dbeta[ch] = (float)s1; dgamma[ch] = (float)sx; }
+}
 // Pixel-chunk split of the halo weight-gradient kernel (64-pixel chunks): shared by the launcher and by the
 // bucket-level reduce so both agree on the number of slabs without a host->device hand-off.
 static __host__ __device__ __forceinline__ int vpd_wgrad_split(int M, int Co, int Kc, int* cpb_out) {

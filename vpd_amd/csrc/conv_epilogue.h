@@ -12,6 +12,8 @@
 //   0 plain store, 1 store + per-channel statistics (train forward), 2 accumulate onto y (data gradient on top of
 //   the identity path), 3 eval epilogue (scale/shift, residual, ReLU); -1 decides at run time (legacy kernels).
 //   6 / 7 = 0 / 2 + the sums of the consuming BatchNorm's backward (ConvParams::bst_z); 8 = 7 + a second BatchNorm (bst_z2).
+//   4 = the statistics of mode 1 WITHOUT the store (conv_stream.hip: a Bottleneck's closing 1x1 conv is computed twice instead of
+//   written and read back; never returned by conv_ep_mode).
 static __host__ __device__ __forceinline__ int conv_ep_mode(const ConvParams& p) {
     if (p.bst_z) return p.accumulate ? (p.bst_z2 ? 8 : 7) : 6;
     return p.ep_scale ? 3 : (p.accumulate ? 2 : (p.stats ? 1 : 0));
@@ -258,7 +260,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
     const PixSplit ps = pix_split_init(p, geo);
     const bool do_eval = EPM < 0 ? (p.ep_scale != nullptr) : (EPM == 3);
     const bool do_acc = EPM < 0 ? (p.accumulate != 0) : (EPM == 2 || EPM == 7 || EPM == 8);
-    const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1);
+    const bool do_stats = EPM < 0 ? (p.stats != nullptr) : (EPM == 1 || EPM == 4);
+    constexpr bool do_store = EPM != 4;
     constexpr bool do_bst = EPM == 6 || EPM == 7 || EPM == 8;
     constexpr bool do_pair = EPM == 8;
     // acc[a][b][j] = out[channel n0 + wn*WTN + a*16 + 4*fq + j][pixel m0 + wm*WTM + b*16 + fr]
@@ -401,7 +404,8 @@ static __device__ __forceinline__ void conv_epilogue_impl(const ConvParams& p, f
                 }
             }
             // the pair leaves 16 bytes wide (64 contiguous bytes per pixel and instruction); a trailing odd group 8 bytes wide
-            if (pair) {
+            if (!do_store) {
+            } else if (pair) {
                 frag_pair_swap(ovs[0], ovs[1]);
                 if (valid) vpd_store16<VPD_CP_EPI>(dpix + frag_pair_chan(a0, fq), uint4{ovs[0].x, ovs[0].y, ovs[1].x, ovs[1].y});
             } else if (valid) {

@@ -122,6 +122,11 @@ struct BnFusedBwd {
 };
 #define VPD_GRID_SYNC_BYTES (18 * 128)
 hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f, hipStream_t s);
+// conv_stream.hip: a Bottleneck's closing 1x1 convolution with its train-mode BatchNorm, the convolution recomputed instead of
+// written and read back (modes: 0 statistics only, 1 forward apply, 2 backward sums, 3 backward apply)
+bool vpd_conv1x1_bn_eligible(const ConvParams& p);
+hipError_t vpd_launch_conv1x1_bn(const ConvParams& p, const BnFusedFwd* fwd, const BnFusedBwd* bwd, const float* mean,
+                                 const float* rstd, unsigned char* mask_out, bf16_t* dz, int dzpad, int mode, hipStream_t stream);
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p, const BnFusedBwd& f, hipStream_t s);
 // BatchNorm backward whose sums (sum g, sum g * z) the producing data gradient's epilogue has already added to `f.rows`

@@ -1019,6 +1019,67 @@ hipError_t run_bn_bwd_apply(const Ctx& c, const ConvInfo& cv, const bf16_t* dy, 
     return vpd_launch_bn_bwd_apply_fused(b, f, c.s);
 }
 
+// ---- a Bottleneck identity block's closing 1x1 convolution together with its BatchNorm, the convolution recomputed instead of
+// written and read back (conv_stream.hip, conv1x1_bn_stream_kernel; VPD_BNECK_RECOMPUTE=0: conv + BatchNorm launches) ----
+ConvParams conv3_params(const Ctx& c, const ConvInfo& cv, const bf16_t* x) {
+    ConvParams q;
+    memset(&q, 0, sizeof q);
+    q.x = x; q.xHp = cv.Hin + 2; q.xWp = cv.Win + 2; q.xC = cv.Ci;
+    q.w = c.b16(c.p->arena_off) + cv.fwd_off;
+    q.yHp = cv.Hout; q.yWp = cv.Wout; q.yC = cv.Co; q.ypad = 0;
+    q.N = c.n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.osub = 1; q.istr = cv.stride;
+    q.Kc = cv.Kc; q.Co = cv.Co; q.M = c.n * cv.Hout * cv.Wout;
+    q.taps = conv_taps_fwd(cv);
+    return q;
+}
+bool bneck_recompute_ok(const Ctx& c, const BlockInfo& B) {
+    if (!c.p->bottleneck || B.ds || !c.p->train || !c.fused(B.c3) || !relu_bits_ok(c, B.c3)) return false;
+    if (B.c3.k != 1 || B.c3.stride != 1) return false;
+    return vpd_conv1x1_bn_eligible(conv3_params(c, B.c3, c.b16(B.a2_off)));
+}
+// forward: statistics pass, then relu(BatchNorm(conv(x)) + res) -> out (padded) + the ReLU bit map
+hipError_t run_conv3_bn_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, const bf16_t* res, bf16_t* out,
+                            unsigned char* mask_out, float* bn_running) {
+    ConvParams q = conv3_params(c, cv, x);
+    q.stats = c.bn_rows(cv.bn); q.stat_rows = VPD_FUSED_ROWS;
+    hipError_t e;
+    {
+        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        e = vpd_launch_conv1x1_bn(q, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, c.s);
+    }
+    if (e != hipSuccess) return e;
+    q.stats = nullptr; q.stat_rows = 0;
+    q.y = out; q.yHp = cv.Hout + 2; q.yWp = cv.Wout + 2; q.ypad = 1;
+    q.res = res; q.rHp = cv.Hout + 2; q.rWp = cv.Wout + 2; q.rC = cv.Co; q.rpad = 1;
+    BnFusedFwd f;
+    memset(&f, 0, sizeof f);
+    f.rows = c.bn_rows(cv.bn); f.count = (float)q.M;
+    f.gamma = c.params + cv.bn.w_off; f.beta = c.params + cv.bn.b_off;
+    f.rm = bn_running ? bn_running + cv.bn.rm_off : nullptr; f.rv = bn_running ? bn_running + cv.bn.rv_off : nullptr;
+    f.mean = c.bn_mean(cv.bn); f.rstd = c.bn_rstd(cv.bn); f.scale = c.bn_scale(cv.bn); f.shift = c.bn_shift(cv.bn);
+    f.momentum = kBnMomentum; f.eps = kBnEps;
+    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+    return vpd_launch_conv1x1_bn(q, &f, nullptr, nullptr, nullptr, mask_out, nullptr, 0, 1, c.s);
+}
+// backward: the sums of g = dout * mask and g * z, then dz = A g + B z + D -> dz (padded by 1), dgamma, dbeta
+hipError_t run_conv3_bn_bwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, bf16_t* dout, const unsigned char* mask_bits,
+                            bf16_t* dz, float* grads) {
+    ConvParams q = conv3_params(c, cv, x);
+    q.y = dout; q.acc_mask = mask_bits;
+    BnFusedBwd f;
+    memset(&f, 0, sizeof f);
+    f.rows = c.bn_rows(cv.bn); f.count = (float)q.M;
+    f.gamma = c.params + cv.bn.w_off; f.dgamma = grads + cv.bn.w_off; f.dbeta = grads + cv.bn.b_off;
+    hipError_t e;
+    {
+        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        e = vpd_launch_conv1x1_bn(q, nullptr, &f, nullptr, nullptr, nullptr, nullptr, 0, 2, c.s);
+    }
+    if (e != hipSuccess) return e;
+    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+    return vpd_launch_conv1x1_bn(q, nullptr, &f, c.bn_mean(cv.bn), c.bn_rstd(cv.bn), nullptr, dz, 1, 3, c.s);
+}
+
 #define LCHECK(expr)                                   \
     do {                                               \
         hipError_t _e = (expr);                        \
@@ -1199,8 +1260,13 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1,
                               nullptr));
-            LCHECK(run_conv_train(c, B.c3, a2, bn_running));
             unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
+            if (bneck_recompute_ok(c, B)) {      // conv3 + bn3 + identity + ReLU: z3 is never stored
+                LCHECK(run_conv3_bn_fwd(c, B.c3, a2, cur, outp, mb3, bn_running));
+                cur = outp;
+                continue;
+            }
+            LCHECK(run_conv_train(c, B.c3, a2, bn_running));
             if (B.ds) {
                 LCHECK(run_conv_train(c, B.cd, cur, bn_running));
                 LCHECK(run_bn_fwd(c, B.c3, bn_running, 2, c.b16(B.cd.z_off), &B.cd, outp, 1, mb3));
@@ -1454,7 +1520,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             if (B.ds)
                 if (bn_bwd_pair(B.c3, B.cd, dout, c.b16(B.out_off), dz3,
                                 c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn3_pair)) return -1;
-            if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
+            if (bneck_recompute_ok(c, B)) LCHECK(run_conv3_bn_bwd(c, B.c3, c.b16(B.a2_off), dout, mb3, dz3, grads));
+            else if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
             // (the BatchNorm sums are not taken in a Bottleneck student's data gradients: vpd_plan_create, dgrad_sums)
             LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
