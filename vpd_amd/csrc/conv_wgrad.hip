@@ -940,7 +940,7 @@ struct Wg2Group {
     const int* blk_begin;                      // device: [grid + 1] first task of each block
     int stage_elems;                           // bf16 elements of the whole ring (the launch's dynamic LDS)
     int skew;                                  // see wg2_task
-    int kind[WG2_MAX];                         // 0: 3x3 (wg2_task); 1 / 2: 1x1 on 128 x 64 / 128 x 128 tiles (wg2_task_1x1)
+    int kind[WG2_MAX];                         // 0: 3x3 (wg2_task); 1 / 2 / 4: 1x1 on 128 x 64 / 128 x 128 / 128 x 256 tiles (wg2_task_1x1)
     WgradParams p[WG2_MAX];
     WgHaloGeom g[WG2_MAX];
 };
@@ -1158,26 +1158,31 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
 }
 
 // 1x1 convolutions (pad 0; stride 1 or 2) as tasks of the same persistent launch: dW[Co][Ci] = sum_m dz[m][Co]^T x[pix(m)][Ci],
-// a plain tall-K GEMM.  Tile 128(co) x TCI(ci), TCI = 64 or 128; per 64-pixel chunk the dz tile (two [64][64] halves) and the x
+// a plain tall-K GEMM.  Tile TCO(co) x TCI(ci), TCO = 128, TCI = 64, 128 or 256; per 64-pixel chunk the dz tile (two [64][64] halves) and the x
 // tile (TCI / 64 blocks of [64 px][64 ci], gathered pixel by pixel from the padded activation: (S*y + 1, S*x + 1)) come in by
 // LDS-DMA into a 4-stage ring; wave (ctile, cohalf) owns co 64*cohalf .. +63 and ci 16*ctile (+ 64 for the second block):
 // 8 or 16 MFMAs per chunk against 24-32 KB of operands -- these tasks are bound by the stream (51-65 FLOP per staged byte),
 // like the operator itself at small channel counts; what the launch buys over conv_wgrad_kernel is no atomics (fixed-order
 // slab sums), no launch of its own, and tiles that stream 2-4x fewer bytes per FLOP than its 64 x 64 ones.
-template <int TCI>
+#ifndef WG2_NS256
+#define WG2_NS256 2
+#endif
+template <int TCI, int TCO = 128>
 static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const WgHaloGeom& g, int tile, int split, bf16_t* ring,
                                                     int skew) {
     constexpr int NB = TCI / 64;
-    constexpr int NS = 4;
-    constexpr int STAGE = (128 + 64 * NB) * 64;                       // bf16 elements
-    constexpr int PER = 2 + NB;                                       // LDS-DMA instructions per wave and chunk
+    constexpr int NZ = TCO / 64;                                      // dz blocks of [64 px][64 co]; a wave owns NZ / 2 of them
+    constexpr int NA = NZ * 2;                                        // 16-channel co groups per wave
+    constexpr int NS = TCI == 256 ? WG2_NS256 : 4;                    // (48 / 64 KB stages: two of them; three measured equal)
+    constexpr int STAGE = (TCO + 64 * NB) * 64;                       // bf16 elements
+    constexpr int PER = NZ + NB;                                      // LDS-DMA instructions per wave and chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctile = wave & 3, cohalf = wave >> 2;
     const int W = p.Ws, H = p.Hs, S = p.istr;
     const int kct = p.Kc / TCI;
-    const int co0 = (tile / kct) * 128;
+    const int co0 = (tile / kct) * TCO;
     const int ci0 = (tile % kct) * TCI;
     const int nchunks_total = (p.M + WG_CH - 1) / WG_CH;
     const int chunk_begin = split * g.cpb;
@@ -1189,15 +1194,15 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
     const int TR = g.TR;
     const int cpi = g.multi ? 1 : H / TR;
     const int ipc = g.multi ? TR / H : 1;
-    int zlane[2], zrow[2], xlane[NB];
+    int zlane[NZ], zrow[NZ], xlane[NB];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = wave * 2 + k;
+    for (int k = 0; k < NZ; ++k) {
+        const int i = wave * NZ + k;                                  // dz instruction: block i >> 3, rows (i & 7) * 8 ..
         const int row = (i & 7) * 8 + lrow;
         const int lr = row / W, xx = row - lr * W;
         const int cpc = (((piece >> 1) ^ wg_f(row)) << 1) | (piece & 1);
         const int img = g.multi ? lr / H : 0, yy = g.multi ? lr % H : lr;
-        zlane[k] = ((img * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + cohalf * 64 + cpc * 8;
+        zlane[k] = ((img * p.dzHp + yy + p.dzpad) * p.dzWp + xx + p.dzpad) * p.dzC + co0 + (i >> 3) * 64 + cpc * 8;
         zrow[k] = row;
     }
 #pragma unroll
@@ -1218,12 +1223,12 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
     const unsigned ring_lds = (unsigned)(size_t)(wg_lptr_t)ring;
     auto issue = [&]() __attribute__((always_inline)) {
         const int ch = chunk_begin + is_c;
-        const unsigned st_lds = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((is_c & (NS - 1)) * STAGE * 2));
+        const unsigned st_lds = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((is_c % NS) * STAGE * 2));
         const bf16_t* zb = p.dz + ((size_t)is_b * p.dzHp + is_y) * p.dzWp * p.dzC;
         const bf16_t* xb = p.x + ((size_t)is_b * p.xHp + S * is_y) * p.xWp * p.xC;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = wave * 2 + k;
+        for (int k = 0; k < NZ; ++k) {
+            const int i = wave * NZ + k;
             const bf16_t* src = (ch * WG_CH + zrow[k] < p.M) ? zb + zlane[k] : p.dz + (zlane[k] & 63);      // zero border pixel
             wg2_lds_dma16(src, st_lds + (unsigned)(i * 8 * 64 * 2));
         }
@@ -1232,7 +1237,7 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
             const int j = wave * NB + k;
             // rows past the end of a ragged last chunk meet zero dz rows: any finite x will do (the first pixels of the tensor)
             const bf16_t* src = (ch * WG_CH + (j & 7) * 8 + lrow < p.M) ? xb + xlane[k] : p.x + (xlane[k] & 63);
-            wg2_lds_dma16(src, st_lds + (unsigned)((128 + j * 8) * 64 * 2));
+            wg2_lds_dma16(src, st_lds + (unsigned)((TCO + j * 8) * 64 * 2));
         }
         ++is_c;
         if (g.multi) is_b += ipc;
@@ -1246,8 +1251,8 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = ra + 4 * h;
-            offA0[h] = 2 * (cohalf * 64 * 64 + r * 64 + ((wg_f(r) << 4) | (4 * pp)));
-            offB0[h] = 2 * (128 * 64 + r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));
+            offA0[h] = 2 * (cohalf * (TCO / 2) * 64 + r * 64 + ((wg_f(r) << 4) | (4 * pp)));
+            offB0[h] = 2 * (TCO * 64 + r * 64 + (((ctile ^ wg_f(r)) << 4) | (4 * pp)));
         }
     }
     typedef s16x4 __attribute__((address_space(3))) * lds_p;
@@ -1260,11 +1265,11 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return __builtin_bit_cast(bf16x8, v);
     };
-    f32x4 acc[NB][4];
+    f32x4 acc[NB][NA];
 #pragma unroll
     for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[u][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < NA; ++a) acc[u][a] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     __builtin_amdgcn_s_barrier();                                     // the previous task is done with the ring
 #pragma unroll
@@ -1277,33 +1282,38 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
         __builtin_amdgcn_s_barrier();
         const bool do_issue = is_c < nch;
         if (do_issue && !(skew && cohalf)) issue();
-        const lds_cp sb = (lds_cp)(const char*)(ring + (c & (NS - 1)) * STAGE);
+        const lds_cp sb = (lds_cp)(const char*)(ring + (c % NS) * STAGE);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks == 1 && do_issue && skew && cohalf) issue();
-            bf16x8 az[4], bx[NB];
+            bf16x8 bx[NB];
             const lds_cp a0 = sb + ks * 32 * 128 + offA0[0], a1 = sb + ks * 32 * 128 + offA0[1];
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-                az[a] = frag2((lds_cp)((unsigned)(size_t)a0 ^ (unsigned)(a << 5)), (lds_cp)((unsigned)(size_t)a1 ^ (unsigned)(a << 5)));
 #pragma unroll
             for (int u = 0; u < NB; ++u)
                 bx[u] = frag2(sb + u * 64 * 128 + ks * 32 * 128 + offB0[0], sb + u * 64 * 128 + ks * 32 * 128 + offB0[1]);
 #pragma unroll
-            for (int u = 0; u < NB; ++u)
+            for (int zb = 0; zb < NZ / 2; ++zb) {      // this wave's dz blocks, one at a time (four co groups of fragments live)
+                bf16x8 az[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    acc[u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[u][a], 0, 0, 0);
+                for (int a = 0; a < 4; ++a)      // (16-channel group a of the block by the XOR)
+                    az[a] = frag2((lds_cp)(((unsigned)(size_t)a0 ^ (unsigned)(a << 5)) + zb * 64 * 128),
+                                  (lds_cp)(((unsigned)(size_t)a1 ^ (unsigned)(a << 5)) + zb * 64 * 128));
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[u][zb * 4 + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[u][zb * 4 + a], 0, 0, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // acc[u][a][j] = partial dW[co0 + 64*cohalf + a*16 + 4*gq + j][ci0 + 64*u + 16*ctile + i16]
+    // acc[u][a][j] = partial dW[co0 + (TCO/2)*cohalf + a*16 + 4*gq + j][ci0 + 64*u + 16*ctile + i16]
     float* out = g.ksplit > 1 ? p.slab + (size_t)split * p.Co * p.Kc : p.dw;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        float* o = out + (size_t)(co0 + cohalf * 64) * p.Kc + ci0 + 64 * u + 16 * ctile + i16;
+        float* o = out + (size_t)(co0 + cohalf * (TCO / 2)) * p.Kc + ci0 + 64 * u + 16 * ctile + i16;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[(size_t)(a * 16 + 4 * gq + j) * p.Kc] = acc[u][a][j];
     }
@@ -1320,7 +1330,8 @@ __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2
         const int kind = grp.kind[pi];
         if (kind == 0) wg2_task(grp.p[pi], grp.g[pi], tile, split, ring, grp.stage_elems, grp.skew);
         else if (kind == 1) wg2_task_1x1<64>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
-        else wg2_task_1x1<128>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else if (kind == 2) wg2_task_1x1<128>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else wg2_task_1x1<256>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
     }
 }
 
@@ -1336,6 +1347,10 @@ static int wg2_kind_1x1(const WgradParams& p) {
     if (W <= 0 || WG_CH % W) return -1;
     const int TR = WG_CH / W;
     if (TR <= H ? H % TR != 0 : TR % H != 0) return -1;
+    // 128 x 256 tiles: a dz chunk serves four ci blocks.  These tasks are bound by the bytes they stream (the tiles of a pixel range
+    // do not run close enough in time to meet in an XCD's 4 MB L2): ResNet-50's grouped launches 1,240 -> 955 us per step, same
+    // box.  256 x 256 tiles (64 KB stages, 128 accumulator registers) were slower again, 976 vs 925 us: fewer tiles, more splits
+    if (p.Kc % 256 == 0) return 4;
     return p.Kc % 128 == 0 ? 2 : 1;
 }
 static void wg2_geom_1x1(const WgradParams& p, WgHaloGeom* g) {
@@ -1396,7 +1411,7 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     for (int i = 0; i < n; ++i) {
         const int kind = kinds ? kinds[i] : 0;
         nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
-        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / (kind == 2 ? 128 : 64));
+        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / (kind > 1 ? 64 * kind : 64));
         ntap[i] = kind ? 1 : 9;
         cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc, ntap[i]);
         if (cap[i] > nch[i]) cap[i] = nch[i];
@@ -1539,17 +1554,6 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     if (!same) {
         wg2_build(ps, grp.g, n, ncu, &c->sch, kinds);
         c->n = n;
-        if (getenv("VPD_WG2_DEBUG")) {
-            int mx = 0, mn = 1 << 30;
-            for (int b = 0; b < c->sch.grid; ++b) {
-                const int k = c->sch.blk_begin[b + 1] - c->sch.blk_begin[b];
-                mx = k > mx ? k : mx; mn = k < mn ? k : mn;
-            }
-            fprintf(stderr, "wg2 schedule: %d problems, %d tasks on %d blocks (%d..%d per block), est %.1f us; splits:", n,
-                    (int)c->sch.tasks.size() / 4, c->sch.grid, mn, mx, c->sch.est_us);
-            for (int i = 0; i < n; ++i) fprintf(stderr, " %d", c->sch.ksplit[i]);
-            fprintf(stderr, "\n");
-        }
         for (int i = 0; i < n; ++i) { c->sig[i][0] = ps[i].M; c->sig[i][1] = ps[i].Co; c->sig[i][2] = ps[i].Kc; c->sig[i][3] = grp.g[i].NHP + 1000 * kinds[i]; }
         const size_t tb = c->sch.tasks.size() * sizeof(int), bb = c->sch.blk_begin.size() * sizeof(int);
         if (tb + bb + 64 > vpd_wgrad128_table_bytes()) return hipErrorInvalidValue;
@@ -1567,14 +1571,13 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
         size_t need = 0;      // every problem's ring: 4 stages (stride 1, and every 1x1) or 2 (3x3 stride 2)
         for (int i = 0; i < n; ++i) {
             const size_t st = kinds[i] ? (size_t)(128 + 64 * kinds[i]) * 64 : (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
-            const size_t want = (kinds[i] || ps[i].istr == 1 ? 4 : 2) * st;
+            const size_t want = (kinds[i] >= 4 ? WG2_NS256 : (kinds[i] || ps[i].istr == 1 ? 4 : 2)) * st;
             need = want > need ? want : need;
         }
         grp.stage_elems = (int)need;
     }
     // skew on: same-box A/B 490 -> 458 us per step for the class (profiles/r02_negative_results.txt has the variants)
-    static const int skew = getenv("VPD_WG2_SKEW") ? atoi(getenv("VPD_WG2_SKEW")) : 1;
-    grp.skew = skew;
+    grp.skew = 1;
     int max_ks = 1;
     long max_n4 = 0;
     for (int i = 0; i < n; ++i) {
