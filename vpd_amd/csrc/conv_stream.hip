@@ -47,7 +47,9 @@ struct StreamGeo {
 // The loader waves' part of a block (the four waves behind the MFMA waves, lw = 0..3): the resident weight tile, then the block's pixel tiles through
 // the ring.  PRE: extra workgroup barriers the MFMA waves run before their first tile (a coefficient prologue), matched here
 // once the first AHEAD tiles are on their way.  Returns in front of the END barrier.
-template <int KC, int BM, int BN, int NSA, int PRE = 0>
+// DUAL: two convolutions of 64 input channels each on the same pixels (same padded geometry): chunk 0 = (p.x, p.w), chunk 1 =
+// (p.x2, p.w2) -- a down-sampling Bottleneck's closing 1x1 and its 1x1 branch (conv1x1_bn2_stream_kernel)
+template <int KC, int BM, int BN, int NSA, int PRE = 0, bool DUAL = false>
 static __device__ __forceinline__ void stream_loader(const ConvParams& p, const StreamGeo& sg, bf16_t* sW, bf16_t* ring, int n0,
                                                      int first, int lanes, int ntile, int lw, int lane) {
     constexpr int KCH = KC / 64;
@@ -60,12 +62,14 @@ static __device__ __forceinline__ void stream_loader(const ConvParams& p, const 
     const int lrow = lane >> 3;
     // weights: [BN][Kc] rows n0 .. of the one tap, chunk by chunk
     const bf16_t* const wsrc = p.w + (size_t)p.taps.w0 * p.Co * p.Kc;
+    static_assert(!DUAL || KC == 128, "DUAL: two chunks of 64 channels");
 #pragma unroll
     for (int cc = 0; cc < KCH; ++cc)
 #pragma unroll
         for (int i = 0; i < W_PER; ++i) {
             const int n = (lw + 4 * i) * 8 + lrow;
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (size_t)(n0 + n) * p.Kc + cc * 64 + ((piece ^ (n & 7)) << 3)),
+            const bf16_t* const ws = DUAL ? (cc ? p.w2 : p.w) + (size_t)(n0 + n) * 64 : wsrc + (size_t)(n0 + n) * p.Kc + cc * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ws + ((piece ^ (n & 7)) << 3)),
                                              (lptr_t)(sW + (cc * BN + (lw + 4 * i) * 8) * 64), 16, 0, 0);
         }
     // this lane's pixel rows of a tile: offsets from the tile's first pixel (same in every tile)
@@ -82,13 +86,14 @@ static __device__ __forceinline__ void stream_loader(const ConvParams& p, const 
         const int t = first + it * lanes;
         const int b = t / sg.tiles_per_img;
         const int r0 = (t - b * sg.tiles_per_img) * sg.rows_per_tile;
-        const bf16_t* const src = p.x + (size_t)((b * p.xHp + r0 * p.istr) * p.xWp) * p.xC + tap_off;
+        const size_t toff = (size_t)((b * p.xHp + r0 * p.istr) * p.xWp) * p.xC + tap_off;
+        const bf16_t* const src = p.x + toff;
         bf16_t* const st = ring + (it % NSA) * ASTAGE;
 #pragma unroll
         for (int cc = 0; cc < KCH; ++cc)
 #pragma unroll
             for (int i = 0; i < A_PER; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[i] + cc * 64),
+                __builtin_amdgcn_global_load_lds((gptr_t)(DUAL ? (cc ? p.x2 : p.x) + toff + aoff[i] : src + aoff[i] + cc * 64),
                                                  (lptr_t)(st + (cc * BM + (lw + 4 * i) * 8) * 64), 16, 0, 0);
     };
 #pragma unroll
@@ -424,6 +429,237 @@ __global__ __launch_bounds__(768) void conv1x1_bn_stream_kernel(const ConvParams
     if (MODE == 2) stream_stats_flush<BN, WM, WN>(bn.rows_out, VPD_FUSED_ROWS, p.Co, n0, st1, st2, smem);
 }
 
+// ---------------------------------------------------------------------------
+// The same for a DOWN-SAMPLING Bottleneck whose two 1x1 convolutions have 64 input channels each and stride 1 (layer1's first
+// block): out = relu(BatchNorm3(conv3(a2)) + BatchNormD(convD(x))).  Both weight tiles are resident, a ring stage holds the
+// a2 tile and the x tile of the same pixels, two accumulator sets per wave.  Neither z3 nor zd is ever stored.
+//   MODE 1: both BatchNorms finalized in the prologue; out + ReLU bit map
+//   MODE 2: g = d(out) * mask; sum g, sum g z3 -> BatchNorm3's rows; sum g, sum g zd -> BatchNormD's rows
+//   MODE 3: dz3 = A3 g + B3 z3 + D3, dzd = Ad g + Bd zd + Dd -> two padded tensors; dgamma / dbeta of both
+// (the statistics passes are two launches of conv1x1_stream_kernel<.., 4>, one per convolution)
+// ---------------------------------------------------------------------------
+struct StreamBnB {                                          // the branch's BatchNorm (fields as in StreamBn)
+    const double* rows; const float* gamma; const float* beta;
+    float* mean; float* rstd; float* scale; float* shift; float* rm; float* rv;
+    double* rows_out; float* dgamma; float* dbeta; bf16_t* dz;
+};
+
+template <int NSA, int MODE>
+__global__ __launch_bounds__(768) void conv1x1_bn2_stream_kernel(const ConvParams p, const StreamGeo sg, const StreamBn bn,
+                                                                 const StreamBnB bb) {
+    constexpr int BM = 64, BN = 256, WM = 2, WN = 4, NMW = 8;
+    constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
+    constexpr int WELEMS = 2 * BN * 64, ASTAGE = 2 * BM * 64;
+    static_assert((size_t)(WELEMS + NSA * ASTAGE) * 2 + 6 * BN * 4 <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* const sW = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* const ring = sW + WELEMS;
+    float* const coef = reinterpret_cast<float*>(ring + NSA * ASTAGE);      // [6][BN]
+    const ConvGeo geo = {p.Hs, p.Ws, p.M, p.oph, p.opw};
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.y * BN;
+    const int lanes = gridDim.x;
+    const int first = blockIdx.x;
+    const int ntile = first < sg.mtiles ? (sg.mtiles - first + lanes - 1) / lanes : 0;
+    constexpr int PRE = (MODE == 1 || MODE == 3) ? 1 : 0;
+    if (wave >= NMW) {
+        stream_loader<128, BM, BN, NSA, PRE, true>(p, sg, sW, ring, n0, first, lanes, ntile, wave - NMW, lane);
+        __builtin_amdgcn_s_barrier();                             // END
+        if (MODE == 2) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+        return;
+    }
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int fr = lane & 15;
+    const int fq = lane >> 4;
+    const int nw = n0 + wn * WTN;
+    if (MODE == 1 && tid < BN) {
+        const int ch = n0 + tid;
+        float mu, r, sc, sh; double var;
+        bn_finalize_channel(bn.rows, p.Co, ch, bn.count, bn.eps, bn.gamma[ch], bn.beta[ch], &mu, &r, &sc, &sh, &var);
+        coef[tid] = sc; coef[BN + tid] = sh;
+        if (blockIdx.x == 0) {
+            bn.mean[ch] = mu; bn.rstd[ch] = r; bn.scale[ch] = sc; bn.shift[ch] = sh;
+            if (bn.rm) {
+                const double unb = bn.count > 1.f ? var * (double)bn.count / ((double)bn.count - 1.0) : var;
+                bn.rm[ch] = (1.f - bn.momentum) * bn.rm[ch] + bn.momentum * mu;
+                bn.rv[ch] = (1.f - bn.momentum) * bn.rv[ch] + bn.momentum * (float)unb;
+            }
+        }
+        bn_finalize_channel(bb.rows, p.Co, ch, bn.count, bn.eps, bb.gamma[ch], bb.beta[ch], &mu, &r, &sc, &sh, &var);
+        coef[2 * BN + tid] = sc; coef[3 * BN + tid] = sh;
+        if (blockIdx.x == 0) {
+            bb.mean[ch] = mu; bb.rstd[ch] = r; bb.scale[ch] = sc; bb.shift[ch] = sh;
+            if (bb.rm) {
+                const double unb = bn.count > 1.f ? var * (double)bn.count / ((double)bn.count - 1.0) : var;
+                bb.rm[ch] = (1.f - bn.momentum) * bb.rm[ch] + bn.momentum * mu;
+                bb.rv[ch] = (1.f - bn.momentum) * bb.rv[ch] + bn.momentum * (float)unb;
+            }
+        }
+    } else if (MODE == 3 && tid < BN) {
+        const int ch = n0 + tid;
+        bn_bwd_apply_coef(bn.rows, p.Co, ch, bn.count, bn.gamma[ch], bn.mean[ch], bn.rstd[ch], coef, coef + BN, coef + 2 * BN,
+                          bn.dgamma, bn.dbeta, blockIdx.x == 0, tid);
+        bn_bwd_apply_coef(bb.rows, p.Co, ch, bn.count, bb.gamma[ch], bb.mean[ch], bb.rstd[ch], coef + 3 * BN, coef + 4 * BN,
+                          coef + 5 * BN, bb.dgamma, bb.dbeta, blockIdx.x == 0, tid);
+    }
+    if (PRE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    float st1[NI][4], st2[NI][4], st3[NI][4];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st1[a][j] = 0.f; st2[a][j] = 0.f; st3[a][j] = 0.f; }
+    const PixSplit ps = pix_split_init(p, geo);
+    auto rounded = [](const f32x4& v, float (&z)[4]) __attribute__((always_inline)) {      // as the unfused path stores it
+        const unsigned z01 = pack2bf(v[0], v[1]), z23 = pack2bf(v[2], v[3]);
+        z[0] = bf2f((unsigned short)(z01 & 0xffff)); z[1] = bf2f((unsigned short)(z01 >> 16));
+        z[2] = bf2f((unsigned short)(z23 & 0xffff)); z[3] = bf2f((unsigned short)(z23 >> 16));
+    };
+    auto cf = [&](int k, int a) __attribute__((always_inline)) {      // coefficient row k, this lane's four channels of group a
+        return *reinterpret_cast<const float4*>(coef + k * BN + wn * WTN + a * 16 + 4 * fq);
+    };
+    for (int it = 0; it < ntile; ++it) {
+        const int mtile = first + it * lanes;
+        AccFrag<NI, MI> accf;      // MODE 2 / 3: d(out) (dense) and its ReLU bits
+        if (MODE != 1) conv_acc_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, accf);
+        f32x4 acc3[NI][MI], accd[NI][MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) { acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; accd[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        __builtin_amdgcn_s_barrier();                             // READY_it
+        const bf16_t* const stg = ring + (it % NSA) * ASTAGE;
+        if (MODE == 2) {
+            // one accumulator set at a time (three sum sets of 16 registers beside it): conv3's sums, then the branch's
+            auto sums = [&](f32x4 (&acc)[NI][MI], bool with_g, float (&sz)[NI][4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+#pragma unroll
+                    for (int a0 = 0; a0 < NI; a0 += 2) {
+                        uint2 dv[2];
+                        dv[0] = uint2{accf.old[b].q[a0 / 2].x, accf.old[b].q[a0 / 2].y};
+                        dv[1] = uint2{accf.old[b].q[a0 / 2].z, accf.old[b].q[a0 / 2].w};
+                        frag_pair_swap(dv[0], dv[1]);
+#pragma unroll
+                        for (int ai = 0; ai < 2; ++ai) {
+                            const int a = a0 + ai;
+                            float z[4];
+                            rounded(acc[a][b], z);
+                            const float d[4] = {bf2f((unsigned short)(dv[ai].x & 0xffff)), bf2f((unsigned short)(dv[ai].x >> 16)),
+                                                bf2f((unsigned short)(dv[ai].y & 0xffff)), bf2f((unsigned short)(dv[ai].y >> 16))};
+                            const unsigned bits = (unsigned)(accf.bits[b] >> (a * 16 + 4 * fq));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float g = ((bits >> j) & 1u) ? d[j] : 0.f;
+                                if (with_g) st1[a][j] += g;
+                                sz[a][j] += g * z[j];
+                            }
+                        }
+                    }
+            };
+            stream_mma<64, BM, BN, WM, WN>(sW, stg, acc3, wm, wn, fr, fq);
+            sums(acc3, true, st2);
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            stream_mma<64, BM, BN, WM, WN>(sW + BN * 64, stg + BM * 64, acc3, wm, wn, fr, fq);
+            sums(acc3, false, st3);
+            continue;
+        }
+        stream_mma<64, BM, BN, WM, WN>(sW, stg, acc3, wm, wn, fr, fq);
+        stream_mma<64, BM, BN, WM, WN>(sW + BN * 64, stg + BM * 64, accd, wm, wn, fr, fq);
+        size_t poff[MI];           // this lane's pixels in the padded outputs (out, or dz3 / dzd: same geometry)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) {
+            const int m = mtile * BM + wm * WTM + b * 16 + fr;
+            int bi, yy, xx;
+            pix_split(ps, m, bi, yy, xx);
+            if (MODE == 1) poff[b] = ((size_t)(bi * p.yHp + yy + p.ypad) * p.yWp + (xx + p.ypad)) * p.yC + nw;
+            else poff[b] = ((size_t)(bi * bn.dzHp + yy + bn.dzpad) * bn.dzWp + (xx + bn.dzpad)) * p.Co + nw;
+        }
+#pragma unroll
+        for (int a0 = 0; a0 < NI; a0 += 2) {
+            float4 k[2][6];
+            if (MODE == 1) {
+#pragma unroll
+                for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) k[ai][q] = cf(q, a0 + ai);
+            } else if (MODE == 3) {
+#pragma unroll
+                for (int ai = 0; ai < 2; ++ai)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) k[ai][q] = cf(q, a0 + ai);
+            }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) {
+                const int m = mtile * BM + wm * WTM + b * 16 + fr;
+                uint2 dv[2], o3[2], od[2];
+                if (MODE != 1) {
+                    dv[0] = uint2{accf.old[b].q[a0 / 2].x, accf.old[b].q[a0 / 2].y};
+                    dv[1] = uint2{accf.old[b].q[a0 / 2].z, accf.old[b].q[a0 / 2].w};
+                    frag_pair_swap(dv[0], dv[1]);
+                }
+#pragma unroll
+                for (int ai = 0; ai < 2; ++ai) {
+                    const int a = a0 + ai;
+                    float z3[4], zd[4], v[4], w[4];
+                    rounded(acc3[a][b], z3);
+                    rounded(accd[a][b], zd);
+                    if (MODE == 1) {
+                        const float s3[4] = {k[ai][0].x, k[ai][0].y, k[ai][0].z, k[ai][0].w}, h3[4] = {k[ai][1].x, k[ai][1].y, k[ai][1].z, k[ai][1].w};
+                        const float sd[4] = {k[ai][2].x, k[ai][2].y, k[ai][2].z, k[ai][2].w}, hd[4] = {k[ai][3].x, k[ai][3].y, k[ai][3].z, k[ai][3].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = __builtin_fmaf(z3[j], s3[j], h3[j]) + __builtin_fmaf(zd[j], sd[j], hd[j]);
+                            v[j] = v[j] > 0.f ? v[j] : 0.f;
+                        }
+                        o3[ai] = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                    } else {
+                        const float d[4] = {bf2f((unsigned short)(dv[ai].x & 0xffff)), bf2f((unsigned short)(dv[ai].x >> 16)),
+                                            bf2f((unsigned short)(dv[ai].y & 0xffff)), bf2f((unsigned short)(dv[ai].y >> 16))};
+                        const unsigned bits = (unsigned)(accf.bits[b] >> (a * 16 + 4 * fq));
+                        const float A3[4] = {k[ai][0].x, k[ai][0].y, k[ai][0].z, k[ai][0].w}, B3[4] = {k[ai][1].x, k[ai][1].y, k[ai][1].z, k[ai][1].w};
+                        const float D3[4] = {k[ai][2].x, k[ai][2].y, k[ai][2].z, k[ai][2].w}, Ad[4] = {k[ai][3].x, k[ai][3].y, k[ai][3].z, k[ai][3].w};
+                        const float Bd[4] = {k[ai][4].x, k[ai][4].y, k[ai][4].z, k[ai][4].w}, Dd[4] = {k[ai][5].x, k[ai][5].y, k[ai][5].z, k[ai][5].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float g = ((bits >> j) & 1u) ? d[j] : 0.f;
+                            v[j] = __builtin_fmaf(A3[j], g, __builtin_fmaf(B3[j], z3[j], D3[j]));
+                            w[j] = __builtin_fmaf(Ad[j], g, __builtin_fmaf(Bd[j], zd[j], Dd[j]));
+                        }
+                        o3[ai] = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                        od[ai] = uint2{pack2bf(w[0], w[1]), pack2bf(w[2], w[3])};
+                    }
+                }
+                const int chan = frag_pair_chan(a0, fq);
+                frag_pair_swap(o3[0], o3[1]);
+                const uint4 ov = uint4{o3[0].x, o3[0].y, o3[1].x, o3[1].y};
+                if (MODE == 1) {
+                    vpd_store16<VPD_CP_EPI>(p.y + poff[b] + chan, ov);
+                    if (bn.mask_out) bn.mask_out[(size_t)m * (p.Co >> 3) + ((nw + chan) >> 3)] = (unsigned char)stream_relu_bits(ov);
+                } else {
+                    vpd_store16<VPD_CP_EPI>(bn.dz + poff[b] + chan, ov);
+                    frag_pair_swap(od[0], od[1]);
+                    vpd_store16<VPD_CP_EPI>(bb.dz + poff[b] + chan, uint4{od[0].x, od[0].y, od[1].x, od[1].y});
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_barrier();                                 // END
+    if (MODE == 2) {
+        stream_stats_flush<BN, WM, WN>(bn.rows_out, VPD_FUSED_ROWS, p.Co, n0, st1, st2, smem);
+        __syncthreads();
+        stream_stats_flush<BN, WM, WN>(bb.rows_out, VPD_FUSED_ROWS, p.Co, n0, st1, st3, smem);
+    }
+}
+
 int stream_cu_count() {
     static const int n = [] {
         int dev = 0, cu = 256;
@@ -574,4 +810,60 @@ hipError_t vpd_launch_conv1x1_bn(const ConvParams& p, const BnFusedFwd* fwd, con
     }
     if (p.Kc == 64) return launch_bn_stream<64, 8>(p, bn, mode, stream);
     return launch_bn_stream<128, 5>(p, bn, mode, stream);
+}
+
+// ---- ... of a down-sampling Bottleneck with two 64-channel stride-1 1x1 convolutions (conv1x1_bn2_stream_kernel): p.x / p.w =
+// the closing convolution, p.x2 / p.w2 = the branch (same padded input geometry).  fwd: rows / ... = BatchNorm3, rows2 / ... = the
+// branch's; bwd3 / bwdD likewise.  Modes 1..3 as vpd_launch_conv1x1_bn (the statistics passes are two mode-0 launches of that).
+bool vpd_conv1x1_bn2_eligible(const ConvParams& p) {
+    if (!(p.x2 && p.w2 && p.Kc == 64 && p.Kc2 == 64 && p.Co == 256)) return false;
+    ConvParams q = p;
+    q.x2 = nullptr; q.w2 = nullptr; q.Kc2 = 0;
+    return vpd_conv1x1_bn_eligible(q);
+}
+hipError_t vpd_launch_conv1x1_bn2(const ConvParams& p, const BnFusedFwd* fwd, const BnFusedBwd* bwd3, const BnFusedBwd* bwdD,
+                                  const float* mean3, const float* rstd3, const float* meanD, const float* rstdD,
+                                  unsigned char* mask_out, bf16_t* dz3, bf16_t* dzD, int dzpad, int mode, hipStream_t stream) {
+    if (!vpd_conv1x1_bn2_eligible(p)) return hipErrorInvalidValue;
+    StreamBn bn;
+    StreamBnB bb;
+    memset(&bn, 0, sizeof bn);
+    memset(&bb, 0, sizeof bb);
+    if (mode == 1) {
+        if (!fwd || !fwd->rows2 || !p.y || p.ypad != 1 || p.yC != p.Co) return hipErrorInvalidValue;
+        bn.rows = fwd->rows; bn.count = fwd->count; bn.gamma = fwd->gamma; bn.beta = fwd->beta;
+        bn.mean = fwd->mean; bn.rstd = fwd->rstd; bn.scale = fwd->scale; bn.shift = fwd->shift;
+        bn.rm = fwd->rm; bn.rv = fwd->rv; bn.momentum = fwd->momentum; bn.eps = fwd->eps; bn.mask_out = mask_out;
+        bb.rows = fwd->rows2; bb.gamma = fwd->gamma2; bb.beta = fwd->beta2;
+        bb.mean = fwd->mean2; bb.rstd = fwd->rstd2; bb.scale = fwd->scale2; bb.shift = fwd->shift2; bb.rm = fwd->rm2; bb.rv = fwd->rv2;
+    } else if (mode == 2 || mode == 3) {
+        if (!bwd3 || !bwdD || !p.y || !p.acc_mask || p.ypad != 0 || p.yC != p.Co || p.yHp != p.Hs || p.yWp != p.Ws) return hipErrorInvalidValue;
+        bn.count = bwd3->count;
+        if (mode == 2) { bn.rows_out = bwd3->rows; bb.rows_out = bwdD->rows; }
+        else {
+            if (!dz3 || !dzD || !mean3 || !rstd3 || !meanD || !rstdD) return hipErrorInvalidValue;
+            bn.rows = bwd3->rows; bn.gamma = bwd3->gamma; bn.dgamma = bwd3->dgamma; bn.dbeta = bwd3->dbeta;
+            bn.mean = const_cast<float*>(mean3); bn.rstd = const_cast<float*>(rstd3);
+            bn.dz = dz3; bn.dzHp = p.Hs + 2 * dzpad; bn.dzWp = p.Ws + 2 * dzpad; bn.dzpad = dzpad;
+            bb.rows = bwdD->rows; bb.gamma = bwdD->gamma; bb.dgamma = bwdD->dgamma; bb.dbeta = bwdD->dbeta;
+            bb.mean = const_cast<float*>(meanD); bb.rstd = const_cast<float*>(rstdD); bb.dz = dzD;
+        }
+    } else return hipErrorInvalidValue;
+    constexpr int BM = 64, BN = 256, NSA = 5;
+    StreamGeo sg;
+    sg.mtiles = p.M / BM;
+    sg.tiles_per_img = (p.Hs * p.Ws) / BM;
+    sg.rows_per_tile = BM / p.Ws;
+    int lanes = stream_cu_count();
+    lanes -= lanes % 8;
+    if (lanes < 8) lanes = 8;
+    if (lanes > sg.mtiles) lanes = sg.mtiles;
+    const dim3 grid(lanes, 1);
+    const size_t lds = (size_t)2 * 64 * (BN + NSA * BM) * sizeof(bf16_t) + 6 * BN * sizeof(float);
+    switch (mode) {
+        case 1: VPD_LAUNCH((conv1x1_bn2_stream_kernel<NSA, 1>), grid, dim3(768), lds, stream, p, sg, bn, bb); break;
+        case 2: VPD_LAUNCH((conv1x1_bn2_stream_kernel<NSA, 2>), grid, dim3(768), lds, stream, p, sg, bn, bb); break;
+        default: VPD_LAUNCH((conv1x1_bn2_stream_kernel<NSA, 3>), grid, dim3(768), lds, stream, p, sg, bn, bb); break;
+    }
+    return hipGetLastError();
 }

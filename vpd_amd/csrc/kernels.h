@@ -125,6 +125,11 @@ hipError_t vpd_launch_bn_fwd_fused(const BnApplyParams& p, const BnFusedFwd& f, 
 // conv_stream.hip: a Bottleneck's closing 1x1 convolution with its train-mode BatchNorm, the convolution recomputed instead of
 // written and read back (modes: 0 statistics only, 1 forward apply, 2 backward sums, 3 backward apply)
 bool vpd_conv1x1_bn_eligible(const ConvParams& p);
+// ... of a down-sampling Bottleneck whose closing 1x1 conv (p.x, p.w) and 1x1 branch (p.x2, p.w2) both have 64 input channels, stride 1
+bool vpd_conv1x1_bn2_eligible(const ConvParams& p);
+hipError_t vpd_launch_conv1x1_bn2(const ConvParams& p, const BnFusedFwd* fwd, const BnFusedBwd* bwd3, const BnFusedBwd* bwdD,
+                                  const float* mean3, const float* rstd3, const float* meanD, const float* rstdD,
+                                  unsigned char* mask_out, bf16_t* dz3, bf16_t* dzD, int dzpad, int mode, hipStream_t stream);
 hipError_t vpd_launch_conv1x1_bn(const ConvParams& p, const BnFusedFwd* fwd, const BnFusedBwd* bwd, const float* mean,
                                  const float* rstd, unsigned char* mask_out, bf16_t* dz, int dzpad, int mode, hipStream_t stream);
 bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g);

@@ -1037,6 +1037,68 @@ bool bneck_recompute_ok(const Ctx& c, const BlockInfo& B) {
     if (B.c3.k != 1 || B.c3.stride != 1) return false;
     return vpd_conv1x1_bn_eligible(conv3_params(c, B.c3, c.b16(B.a2_off)));
 }
+// ... and a DOWN-SAMPLING block whose closing 1x1 conv and 1x1 branch both have 64 input channels and stride 1 (layer1's first
+// block): both convolutions and both BatchNorms in the same launches (conv1x1_bn2_stream_kernel)
+ConvParams conv3d_params(const Ctx& c, const BlockInfo& B, const bf16_t* xin) {
+    ConvParams q = conv3_params(c, B.c3, c.b16(B.a2_off));
+    q.x2 = xin; q.w2 = c.b16(c.p->arena_off) + B.cd.fwd_off; q.Kc2 = B.cd.Kc;
+    return q;
+}
+bool bneck_recompute2_ok(const Ctx& c, const BlockInfo& B) {
+    if (!c.p->bottleneck || !B.ds || !c.p->train || !c.fused(B.c3) || !c.fused(B.cd) || !relu_bits_ok(c, B.c3)) return false;
+    if (B.c3.k != 1 || B.cd.k != 1 || B.c3.stride != 1 || B.cd.stride != 1 || B.c3.Ci != B.cd.Ci || B.c3.Co != B.cd.Co) return false;
+    if (B.c3.Hin != B.cd.Hin || B.c3.Win != B.cd.Win) return false;
+    return vpd_conv1x1_bn2_eligible(conv3d_params(c, B, c.b16(B.a2_off)));
+}
+void fill_bn_fwd(const Ctx& c, const ConvInfo& k, float* bn_running, int M, double** rows, float* count, const float** gamma,
+                 const float** beta, float** rm, float** rv, float** mean, float** rstd, float** scale, float** shift) {
+    *rows = c.bn_rows(k.bn); *count = (float)M;
+    *gamma = c.params + k.bn.w_off; *beta = c.params + k.bn.b_off;
+    *rm = bn_running ? bn_running + k.bn.rm_off : nullptr; *rv = bn_running ? bn_running + k.bn.rv_off : nullptr;
+    *mean = c.bn_mean(k.bn); *rstd = c.bn_rstd(k.bn); *scale = c.bn_scale(k.bn); *shift = c.bn_shift(k.bn);
+}
+hipError_t run_conv3d_bn_fwd(const Ctx& c, const BlockInfo& B, const bf16_t* xin, bf16_t* out, unsigned char* mask_out,
+                             float* bn_running) {
+    hipError_t e;
+    for (int k = 0; k < 2; ++k) {      // the two statistics passes
+        const ConvInfo& cv = k ? B.cd : B.c3;
+        ConvParams q = conv3_params(c, cv, k ? xin : c.b16(B.a2_off));
+        q.stats = c.bn_rows(cv.bn); q.stat_rows = VPD_FUSED_ROWS;
+        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        e = vpd_launch_conv1x1_bn(q, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, c.s);
+        if (e != hipSuccess) return e;
+    }
+    ConvParams q = conv3d_params(c, B, xin);
+    q.y = out; q.yHp = B.c3.Hout + 2; q.yWp = B.c3.Wout + 2; q.ypad = 1;
+    BnFusedFwd f;
+    memset(&f, 0, sizeof f);
+    fill_bn_fwd(c, B.c3, bn_running, q.M, &f.rows, &f.count, &f.gamma, &f.beta, &f.rm, &f.rv, &f.mean, &f.rstd, &f.scale, &f.shift);
+    fill_bn_fwd(c, B.cd, bn_running, q.M, &f.rows2, &f.count2, &f.gamma2, &f.beta2, &f.rm2, &f.rv2, &f.mean2, &f.rstd2, &f.scale2, &f.shift2);
+    f.momentum = kBnMomentum; f.eps = kBnEps;
+    TimeScope ts(c.p, c.s, 4, conv_flops(B.c3, c.n) + conv_flops(B.cd, c.n));
+    return vpd_launch_conv1x1_bn2(q, &f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mask_out, nullptr, nullptr, 0, 1, c.s);
+}
+hipError_t run_conv3d_bn_bwd(const Ctx& c, const BlockInfo& B, const bf16_t* xin, bf16_t* dout, const unsigned char* mask_bits,
+                             bf16_t* dz3, bf16_t* dzd, float* grads) {
+    ConvParams q = conv3d_params(c, B, xin);
+    q.y = dout; q.acc_mask = mask_bits;
+    BnFusedBwd f3, fd;
+    memset(&f3, 0, sizeof f3);
+    memset(&fd, 0, sizeof fd);
+    f3.rows = c.bn_rows(B.c3.bn); f3.count = (float)q.M;
+    f3.gamma = c.params + B.c3.bn.w_off; f3.dgamma = grads + B.c3.bn.w_off; f3.dbeta = grads + B.c3.bn.b_off;
+    fd.rows = c.bn_rows(B.cd.bn); fd.count = (float)q.M;
+    fd.gamma = c.params + B.cd.bn.w_off; fd.dgamma = grads + B.cd.bn.w_off; fd.dbeta = grads + B.cd.bn.b_off;
+    hipError_t e;
+    {
+        TimeScope ts(c.p, c.s, 4, conv_flops(B.c3, c.n) + conv_flops(B.cd, c.n));
+        e = vpd_launch_conv1x1_bn2(q, nullptr, &f3, &fd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, c.s);
+    }
+    if (e != hipSuccess) return e;
+    TimeScope ts(c.p, c.s, 4, conv_flops(B.c3, c.n) + conv_flops(B.cd, c.n));
+    return vpd_launch_conv1x1_bn2(q, nullptr, &f3, &fd, c.bn_mean(B.c3.bn), c.bn_rstd(B.c3.bn), c.bn_mean(B.cd.bn), c.bn_rstd(B.cd.bn),
+                                  nullptr, dz3, dzd, 1, 3, c.s);
+}
 // forward: statistics pass, then relu(BatchNorm(conv(x)) + res) -> out (padded) + the ReLU bit map
 hipError_t run_conv3_bn_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, const bf16_t* res, bf16_t* out,
                             unsigned char* mask_out, float* bn_running) {
@@ -1263,6 +1325,11 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
             if (bneck_recompute_ok(c, B)) {      // conv3 + bn3 + identity + ReLU: z3 is never stored
                 LCHECK(run_conv3_bn_fwd(c, B.c3, a2, cur, outp, mb3, bn_running));
+                cur = outp;
+                continue;
+            }
+            if (bneck_recompute2_ok(c, B)) {     // ... + the 1x1 branch and its BatchNorm: neither z3 nor zd is stored
+                LCHECK(run_conv3d_bn_fwd(c, B, cur, outp, mb3, bn_running));
                 cur = outp;
                 continue;
             }
@@ -1517,7 +1584,11 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             // leaves dout alone: conv1's data gradient masks it when it adds the identity path (as in the BasicBlock path)
             const unsigned char* mb3 = (!B.ds && relu_bits_ok(c, B.c3)) ? reinterpret_cast<const unsigned char*>(ws + B.mask_off) : nullptr;
             bool bn3_pair = false;      // down-sampling block: bn3 and the 1x1 branch's BatchNorm in one launch
-            if (B.ds)
+            if (B.ds && bneck_recompute2_ok(c, B)) {
+                LCHECK(run_conv3d_bn_bwd(c, B, xin, dout, reinterpret_cast<const unsigned char*>(ws + B.mask_off), dz3,
+                                         c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), grads));
+                bn3_pair = true;
+            } else if (B.ds)
                 if (bn_bwd_pair(B.c3, B.cd, dout, c.b16(B.out_off), dz3,
                                 c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off), &bn3_pair)) return -1;
             if (bneck_recompute_ok(c, B)) LCHECK(run_conv3_bn_bwd(c, B.c3, c.b16(B.a2_off), dout, mb3, dz3, grads));
