@@ -940,7 +940,7 @@ struct Wg2Group {
     const int* blk_begin;                      // device: [grid + 1] first task of each block
     int stage_elems;                           // bf16 elements of the whole ring (the launch's dynamic LDS)
     int skew;                                  // see wg2_task
-    int kind[WG2_MAX];                         // 0: 3x3 (wg2_task); 1 / 2 / 4: 1x1 on 128 x 64 / 128 x 128 / 128 x 256 tiles (wg2_task_1x1)
+    int kind[WG2_MAX];                         // 0: 3x3 (wg2_task); 1 / 2 / 4: 1x1 on 128 x 64 / 128 x 128 / 128 x 256 tiles (wg2_task_1x1); + 16: 256 output channels per tile
     WgradParams p[WG2_MAX];
     WgHaloGeom g[WG2_MAX];
 };
@@ -1173,7 +1173,7 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
     constexpr int NB = TCI / 64;
     constexpr int NZ = TCO / 64;                                      // dz blocks of [64 px][64 co]; a wave owns NZ / 2 of them
     constexpr int NA = NZ * 2;                                        // 16-channel co groups per wave
-    constexpr int NS = TCI == 256 ? WG2_NS256 : 4;                    // (48 / 64 KB stages: two of them; three measured equal)
+    constexpr int NS = (TCI == 256 || TCO == 256) ? WG2_NS256 : 4;    // (40-48 KB stages: two of them; three measured equal)
     constexpr int STAGE = (TCO + 64 * NB) * 64;                       // bf16 elements
     constexpr int PER = NZ + NB;                                      // LDS-DMA instructions per wave and chunk
     const int tid = threadIdx.x;
@@ -1331,7 +1331,9 @@ __global__ __launch_bounds__(512) void conv_wgrad128_persistent_kernel(const Wg2
         if (kind == 0) wg2_task(grp.p[pi], grp.g[pi], tile, split, ring, grp.stage_elems, grp.skew);
         else if (kind == 1) wg2_task_1x1<64>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
         else if (kind == 2) wg2_task_1x1<128>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
-        else wg2_task_1x1<256>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else if (kind == 4) wg2_task_1x1<256>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else if (kind == 17) wg2_task_1x1<64, 256>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
+        else wg2_task_1x1<128, 256>(grp.p[pi], grp.g[pi], tile, split, ring, grp.skew);
     }
 }
 
@@ -1351,8 +1353,13 @@ static int wg2_kind_1x1(const WgradParams& p) {
     // do not run close enough in time to meet in an XCD's 4 MB L2): ResNet-50's grouped launches 1,240 -> 955 us per step, same
     // box.  256 x 256 tiles (64 KB stages, 128 accumulator registers) were slower again, 976 vs 925 us: fewer tiles, more splits
     if (p.Kc % 256 == 0) return 4;
-    return p.Kc % 128 == 0 ? 2 : 1;
+    // few input channels, many output channels (a Bottleneck's closing conv): 256 x 64 / 256 x 128 tiles -- the x chunk serves twice
+    // the output channels
+    static const int tco = getenv("VPD_WG2_TCO256") ? atoi(getenv("VPD_WG2_TCO256")) : 1;
+    return (p.Kc % 128 == 0 ? 2 : 1) + (tco && p.Co % 256 == 0 ? 16 : 0);
 }
+static inline int wg2_nb(int kind) { return kind & 15; }                     // 64-channel ci blocks per tile
+static inline int wg2_tco(int kind) { return kind >= 16 ? 256 : 128; }       // output channels per tile
 static void wg2_geom_1x1(const WgradParams& p, WgHaloGeom* g) {
     memset(g, 0, sizeof *g);
     const int TR = WG_CH / p.Ws;
@@ -1411,7 +1418,7 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     for (int i = 0; i < n; ++i) {
         const int kind = kinds ? kinds[i] : 0;
         nch[i] = (ps[i].M + WG_CH - 1) / WG_CH;
-        tiles[i] = (ps[i].Co / 128) * (ps[i].Kc / (kind > 1 ? 64 * kind : 64));
+        tiles[i] = kind ? (ps[i].Co / wg2_tco(kind)) * (ps[i].Kc / (64 * wg2_nb(kind))) : (ps[i].Co / 128) * (ps[i].Kc / 64);
         ntap[i] = kind ? 1 : 9;
         cap[i] = vpd_wgrad_group_max_splits(ps[i].Co, ps[i].Kc, ntap[i]);
         if (cap[i] > nch[i]) cap[i] = nch[i];
@@ -1424,7 +1431,7 @@ static void wg2_build(const WgradParams* ps, const WgHaloGeom* gs, int n, int G,
     int best_ks[WG2_MAX];
     auto tchunk = [&](int i) {
         const int kind = kinds ? kinds[i] : 0;
-        if (kind) return (16.0 + 8.0 * kind) / 21.0;      // 1x1: the stream alone (8 or 16 MFMAs per chunk and wave)
+        if (kind) return (wg2_tco(kind) / 8.0 + 8.0 * wg2_nb(kind)) / 21.0;      // 1x1: the stream alone
         const double st = (16.0 + (gs[i].NHP + 7) / 8) / 21.0;
         return st > 1.15 ? st : 1.15;
     };
@@ -1570,8 +1577,8 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     {
         size_t need = 0;      // every problem's ring: 4 stages (stride 1, and every 1x1) or 2 (3x3 stride 2)
         for (int i = 0; i < n; ++i) {
-            const size_t st = kinds[i] ? (size_t)(128 + 64 * kinds[i]) * 64 : (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
-            const size_t want = (kinds[i] >= 4 ? WG2_NS256 : (kinds[i] || ps[i].istr == 1 ? 4 : 2)) * st;
+            const size_t st = kinds[i] ? (size_t)(wg2_tco(kinds[i]) + 64 * wg2_nb(kinds[i])) * 64 : (size_t)(128 + 8 * ((grp.g[i].NHP + 7) / 8)) * 64;
+            const size_t want = (kinds[i] >= 4 ? WG2_NS256 : (kinds[i] || ps[i].istr == 1 ? 4 : 2)) * st;      // (kind 4, or + 16)
             need = want > need ? want : need;
         }
         grp.stage_elems = (int)need;
