@@ -439,7 +439,7 @@ STREAM_CASES = [
     ("k128_n128", 256, 128, 128, 16, 16, 1),
     ("k128_n512", 128, 128, 512, 16, 16, 1),
     ("k256_n128_and_k128_n256", 128, 256, 128, 16, 16, 1),
-    ("k256_n512_s2", 128, 256, 512, 32, 32, 2),
+    ("k256_n512_s2", 64, 256, 512, 32, 32, 2),
 ]
 
 
@@ -487,10 +487,10 @@ def _pack_mask_bits(keep):
 
 STREAM_EP_CASES = [
     # name, N, Ci, Co, H, W
-    ("k64_n256", 64, 64, 256, 32, 32),       # a Bottleneck's closing 1x1 (eval: BatchNorm + identity + ReLU in the epilogue)
+    ("k64_n256", 32, 64, 256, 32, 32),       # a Bottleneck's closing 1x1 (eval: BatchNorm + identity + ReLU in the epilogue)
     ("k256_n64", 64, 256, 64, 32, 32),       # its opening 1x1; as data gradient 64 -> 256 it adds onto the masked identity path
     ("k128_n512", 128, 128, 512, 16, 16),
-    ("k256_n128", 64, 256, 128, 32, 32),
+    ("k256_n128", 16, 256, 128, 32, 32),
 ]
 
 

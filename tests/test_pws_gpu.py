@@ -75,8 +75,12 @@ def _run(case, env_extra):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("case", list(CASES), ids=list(CASES))
-@pytest.mark.parametrize("blocks", ["24", "0"], ids=["few_blocks", "device_blocks"])
+# every tile class with few blocks (many tiles per block: ring and halo wrap-around); one block per CU for the two classes of
+# the BASELINE step's layer2 / layer3 launches (the full-size tests run the rest that way)
+_PWS_RUNS = [(c, "24") for c in CASES] + [("c1_256x128_layer2", "0"), ("c6_256x64_layer3_ragged", "0")]
+
+
+@pytest.mark.parametrize("case,blocks", _PWS_RUNS, ids=["%s-%s" % (c, "few_blocks" if b == "24" else "device_blocks") for c, b in _PWS_RUNS])
 def test_pws_conv_matches_reference_and_old_kernel(case, blocks):
     new = _run(case, {"VPD_PWS": "1", "VPD_PWS_BLOCKS": blocks})
     assert new["fwd"] < 4e-3 and new["dgrad"] < 4e-3 and new["acc"] < 8e-3, new

@@ -27,4 +27,7 @@ bash tools/ab_env.sh "merged:" "unmerged:VPD_WG_MERGE=0" > $OUT/r05_ab_wg_unmerg
 ( echo "digest tree:"; python3 tools/step_digest.py 2>/dev/null; echo "digest r04:"; VPD_LIB_PATH=$R/tools/probe/ab/libr04.so python3 tools/step_digest.py 2>/dev/null ) > $OUT/r05_vs_r04_same_box.txt 2>&1
 bash tools/ab_env.sh "r05:" "r04:VPD_LIB_PATH=$R/tools/probe/ab/libr04.so" >> $OUT/r05_vs_r04_same_box.txt 2>&1
 AB_EXTRA="--batch 512" bash tools/ab_env.sh "r05_512:" "r04_512:VPD_LIB_PATH=$R/tools/probe/ab/libr04.so" >> $OUT/r05_vs_r04_same_box.txt 2>&1
+# the ResNet-50 step: kernel summary + timeline, and its round-5 paths against the launches they replace
+bash tools/jobs/r05_trace50.sh r05_resnet50 > /dev/null 2>&1
+AB_EXTRA="--arch resnet50" bash tools/ab_env.sh "default:" "no_stream_no_recompute:VPD_CONV1X1_STREAM=0,VPD_BNECK_RECOMPUTE=0" "no_recompute:VPD_BNECK_RECOMPUTE=0" 2>&1 | cut -c1-330 > $OUT/r05_ab_r50_paths.txt
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $OUT/r05_gputests.log 2>&1; tail -2 $OUT/r05_gputests.log
