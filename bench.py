@@ -446,6 +446,7 @@ def main():
         multi["ms_per_step_overlap_off"] = 1e3 * float(t_off.item()) / args.steps
         multi["lazy_gradients"] = os.environ.get("VPD_DDP_LAZY", "1") != "0"
         multi["early_bucket0"] = bool(pl.early_bucket0)      # layer4's weight gradients at layer4's end: bucket 0 handed over early
+        multi["wire_dtype"] = os.environ.get("VPD_DDP_WIRE", "fp32")      # bf16: gradient messages travel and are summed in bf16
         # replicas: every rank must hold the same bits after the timed steps (same initial weights, same all-reduced gradients)
         chk = torch.stack([eng.params.double().sum(), (eng.params.double() ** 2).sum()])
         lo, hi = chk.clone(), chk.clone()

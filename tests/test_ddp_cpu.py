@@ -211,3 +211,53 @@ def test_eight_ranks_ragged_final_batch_and_lazy_exchange():
         assert np.array_equal(ws[1024:2048], o[3][1024:2048]) and np.array_equal(ws[4000:], o[3][4000:])
         assert np.allclose(flat[mask], flat_sum[mask], rtol=0, atol=1e-5) and np.array_equal(flat[~mask], o[4][~mask])
         assert o[7][1] == 3616 and o[7][0] == 452 * sum(range(1, 9))
+
+
+def _wire_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["VPD_DDP_WIRE"] = "bf16"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vpd_amd.ddp import all_reduce_lazy, average_running_stats
+    g = torch.Generator().manual_seed(10 + rank)
+    flat = torch.randn(5000, generator=g)
+    exact = flat.clone()
+    dist.all_reduce(exact)                                        # fp32 sums, for reference
+    ref16 = flat.to(torch.bfloat16)
+    dist.all_reduce(ref16)                                        # what a bf16 collective gives
+    a = flat.clone()
+    all_reduce_buckets(a, [(3000, 2000), (0, 3000)])
+    scratch = [flat[:1000].clone(), flat[1000:1000].clone(), flat[1000:4000].clone()]
+    b = flat.clone()
+    idx = torch.arange(4000, 5000)
+    works, finish = all_reduce_lazy(scratch, b, idx, async_op=True)
+    for w in works:
+        w.wait()
+    finish()
+    bn = torch.full((6,), float(rank + 1))
+    average_running_stats(bn)
+    if rank == 0:
+        q.put((a.numpy(), ref16.float().numpy(), exact.numpy(), torch.cat(scratch + [b[4000:]]).numpy(), bn.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_format_and_running_stat_average():
+    """SURVEY 8e's two optional items, both opt-in: VPD_DDP_WIRE=bf16 -- the bucket / lazy messages are converted to bf16, summed by
+    the collective in bf16 and copied back (every rank gets the same values: what a bf16 all-reduce of the same tensor gives,
+    within bf16 rounding of the fp32 sums), also through the asynchronous works of the overlapped path; VPD_DDP_AVG_BN=1 --
+    average_running_stats leaves the mean over ranks on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 37
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    a, ref16, exact, lazy, bn = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(a, ref16)
+    assert np.abs(a - exact).max() <= 2.0 ** -7 * np.abs(exact).max() and not np.array_equal(a, exact)
+    assert np.array_equal(lazy, ref16)
+    assert np.array_equal(bn, np.full(6, 1.5, np.float32))

@@ -161,6 +161,9 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     best_val_loss = float('inf')
     for epoch in range(1, num_epochs + 1):
         train_loss = trainer.epoch(train_loader, optimizer=optimizer, scaler=scaler)
+        if world > 1 and os.environ.get('VPD_DDP_AVG_BN', '0') == '1':      # per-rank BatchNorm statistics -> their mean over ranks
+            from vpd_amd.ddp import average_running_stats
+            average_running_stats(encoder.engine.bn_running)
         val_loss = trainer.epoch(val_loader)
         losses.append({'epoch': epoch, 'train': train_loss, 'val': val_loss,
                        'dataset_train': [(dataset, train_loss)], 'dataset_val': [(dataset, val_loss)]})

@@ -26,16 +26,54 @@ def shard_slice(n, rank, world):
     return slice(start, start + sizes[rank])
 
 
+def wire_dtype():
+    """VPD_DDP_WIRE=bf16 (optional): gradient messages travel -- and are summed by the collective -- in bf16, half the
+    bytes on a per-link-bound xGMI ring; every rank receives the same sums, so replicas stay identical.  Default fp32."""
+    w = os.environ.get("VPD_DDP_WIRE", "fp32")
+    if w not in ("fp32", "bf16"):
+        raise ValueError("VPD_DDP_WIRE must be fp32 or bf16, not %r" % w)
+    return torch.bfloat16 if w == "bf16" else torch.float32
+
+
+class _WireWork:
+    """An all-reduce of `view` through a buffer of the wire dtype: wait(), then the summed values are copied back."""
+
+    def __init__(self, view, group, async_op, dtype):
+        self.view = view
+        self.buf = view if dtype == view.dtype else view.to(dtype)
+        self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if not async_op:
+            self._back()
+
+    def _back(self):
+        if self.buf is not self.view:
+            self.view.copy_(self.buf)
+
+    def wait(self):
+        self.work.wait()
+        self._back()
+
+
 def all_reduce_buckets(flat, ranges, group=None, async_op=False):
     """SUM all-reduce of flat[off:off+numel] for every bucket, in the given order."""
     works = []
+    dt = wire_dtype()
     for off, numel in ranges:
         if numel == 0:
             continue
-        w = dist.all_reduce(flat[off:off + numel], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        w = _WireWork(flat[off:off + numel], group, async_op, dt)
         if async_op:
             works.append(w)
     return works
+
+
+def average_running_stats(bn_running, group=None):
+    """VPD_DDP_AVG_BN=1 (optional): BatchNorm statistics are per rank (no SyncBN); at the end of an epoch every replica
+    takes the mean over ranks of the running means / variances, so the checkpoint rank 0 writes -- and the validation pass -- see
+    all shards.  In place; a collective: every rank calls it."""
+    dist.all_reduce(bn_running, op=dist.ReduceOp.SUM, group=group)
+    bn_running.div_(dist.get_world_size(group))
+    return bn_running
 
 
 def all_reduce_lazy(scratch_views, flat, small_idx, group=None, async_op=False):
@@ -44,13 +82,14 @@ def all_reduce_lazy(scratch_views, flat, small_idx, group=None, async_op=False):
     stem: ~150 k of the 21.4 M elements).  Returns (works, finish): call finish() once the works are done to scatter the
     small message back."""
     works = []
+    dt = wire_dtype()
     for v in scratch_views:
         if v.numel():
-            w = dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            w = _WireWork(v, group, async_op, dt)
             if async_op:
                 works.append(w)
     small = flat.index_select(0, small_idx)
-    w = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    w = _WireWork(small, group, async_op, dt)
     if async_op:
         works.append(w)
     return works, (lambda: flat.index_copy_(0, small_idx, small))
@@ -110,7 +149,7 @@ class GradBucketReducer:
                 if lazy:
                     v = plan.scratch_views[b]
                     if v.numel():
-                        works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        works.append(_WireWork(v, self.group, True, wire_dtype()))
                     if b == len(plan.buckets) - 1:      # everything else, once the whole backward is done
                         w2, finish = all_reduce_lazy([], flat, plan.small_idx, self.group, async_op=True)
                         works += w2
