@@ -900,11 +900,11 @@ sys.path.insert(0, {repo!r})
 from oracle import vpd_oracle as O
 from vpd_amd.models.rgb import RGBF_EmbeddingModel
 from vpd_amd.trainer import ModelTrainer
-sd = O.reference_init_state_dict("resnet50", 5, 32, 3)
+sd = O.reference_init_state_dict({arch!r}, 5, 32, 3)
 for k in sd:
     if k.endswith(".bn3.weight"):
         sd[k] = sd[k] * 0.1                      # the well-conditioned regime of the wc_grads goldens
-enc = RGBF_EmbeddingModel("resnet50", 32, True, "cuda")
+enc = RGBF_EmbeddingModel({arch!r}, 32, True, "cuda")
 enc.load_state_dict(sd)
 tr = ModelTrainer(enc, False)
 g = torch.Generator(device="cuda").manual_seed(4)
@@ -922,7 +922,8 @@ print("LOSS", loss.item())
 """
 
 
-def test_bottleneck_tail_recomputed_instead_of_stored(tmp_path):
+@pytest.mark.parametrize("arch", ["resnet50", "wide_resnet50_2"])
+def test_bottleneck_tail_recomputed_instead_of_stored(tmp_path, arch):
     """Default path from 64 crops per step up (layer1 of a ResNet-50; layer2 from 256): an identity Bottleneck's closing 1x1
     convolution and its BatchNorm run as conv1x1_bn_stream_kernel -- z3 is computed twice (statistics pass, apply pass) and never
     stored, in the backward twice more (sums, apply).  VPD_BNECK_RECOMPUTE=0 is conv + BatchNorm launches with z3 in memory, which
@@ -930,7 +931,8 @@ def test_bottleneck_tail_recomputed_instead_of_stored(tmp_path):
     bn_bwd_apply_fused_kernel's arithmetic (sum g z in fp64 -> A g + B z + D) instead of bn_bwd_fused_kernel's: same gradient to
     rounding -- whole gradient: cosine > 0.999, norm within 1 %; EVERY parameter tensor: rel-L2 <= 2e-2 (measured <= 0.8e-2; a
     coefficient of one recomputed BatchNorm 2 % off shows as >= 2e-2 in that block's and every earlier tensor) -- in the
-    well-conditioned regime of the wc_grads goldens."""
+    well-conditioned regime of the wc_grads goldens.  resnet50: layer1's three blocks at 64 crops (K = 64 kernels, the down-sampling
+    block's two-convolution launches); wide_resnet50_2: K = 128 kernels (layer1's closing convs are 128 -> 256)."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -938,7 +940,7 @@ def test_bottleneck_tail_recomputed_instead_of_stored(tmp_path):
     for flag in ("0", "1"):
         out = str(tmp_path / ("g%s.npy" % flag))
         env = dict(os.environ, VPD_BNECK_RECOMPUTE=flag)
-        r = subprocess.run([sys.executable, "-c", _R50_STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
+        r = subprocess.run([sys.executable, "-c", _R50_STEP_SCRIPT.format(repo=repo, out=out, arch=arch)], env=env, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         outs.append((np.load(out), np.load(out + ".bn.npy"), float(r.stdout.split("LOSS")[1].split()[0]), dict(np.load(out + ".t.npz"))))

@@ -1310,22 +1310,22 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused2_kernel(const BnBwdParams p
             }
         }
     }
+    const int wstep = cv <= 64 ? 1 : cv / 64;      // (rows of `red` by the waves that share a channel group: as bn_bwd_fused_kernel)
     if (lane < cv) {
+        const int rrow = wave / wstep;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            red[(size_t)(wave * 3 + 0) * C + c + j] = a1[j];
-            red[(size_t)(wave * 3 + 1) * C + c + j] = a2[j];
-            red[(size_t)(wave * 3 + 2) * C + c + j] = a3[j];
+            red[(size_t)(rrow * 3 + 0) * C + c + j] = a1[j];
+            red[(size_t)(rrow * 3 + 1) * C + c + j] = a2[j];
+            red[(size_t)(rrow * 3 + 2) * C + c + j] = a3[j];
         }
     }
     __syncthreads();
-    const int wstep = cv <= 64 ? 1 : cv / 64;
     for (int t = tid; t < 3 * C; t += T) {
         const int which = t / C;
         const int ch = t - which * C;
-        const int w0 = cv <= 64 ? 0 : (ch >> 3) / 64;
         float tot = 0.f;
-        for (int w = w0; w < 16; w += wstep) tot += red[(size_t)(w * 3 + which) * C + ch];
+        for (int k = 0; k < 16 / wstep; ++k) tot += red[(size_t)(k * 3 + which) * C + ch];
         double* rows = which == 2 ? f.rowsB : f.rowsA;
         const int slot = which == 2 ? 1 : which;
         atomicAdd(&rows[((size_t)(blockIdx.x & (VPD_FUSED_ROWS - 1)) * 2 + slot) * C + ch], (double)tot);
@@ -1383,8 +1383,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused2_kernel(const BnBwdParams p
 bool vpd_bn_bwd_fused2_ok(int M, int C) {
     static const int off = getenv("VPD_FUSED_BN") ? !atoi(getenv("VPD_FUSED_BN")) : 0;
     static const int off2 = getenv("VPD_BN_PAIR") ? !atoi(getenv("VPD_BN_PAIR")) : 0;
-    // (three per-wave sum rows of C floats for 16 waves must leave LDS for the resident slices: C <= 512)
-    return !(off || off2 || C % 8 || C < 64 || C > 512 || 1024 % (C / 8)) && M >= 1;
+    return !(off || off2 || C % 8 || C < 64 || C > 2048 || 1024 % (C / 8)) && M >= 1;
 }
 
 // p: BatchNorm A as for vpd_launch_bn_bwd_fused (dy, act, z, mean, rstd, dz + geometry); fA / fB: rows, gamma, dgamma, dbeta
@@ -1412,7 +1411,7 @@ hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p0, const BnFusedBwd& fA,
     f.gammaB = fB.gamma; f.dgammaB = fB.dgamma; f.dbetaB = fB.dbeta;
     f.dzB = dzB; f.count = fA.count;
     f.iters = ppb / ppi;
-    const size_t red_bytes = (size_t)16 * 3 * p.C * sizeof(float);
+    const size_t red_bytes = (size_t)(cv <= 64 ? 16 : 16 / (cv / 64)) * 3 * p.C * sizeof(float);
     const size_t tile = (size_t)f.iters * 1024 * 16;
     const size_t cap = 160 * 1024;
     f.keep_g = red_bytes + tile <= cap;
