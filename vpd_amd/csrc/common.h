@@ -280,6 +280,10 @@ struct WgradParams {
     // holds the 3x3 geometry, only tap 4 is accumulated and dw / the slab have ONE slice
     int one_by_one;
     int prefer_halo_1x1;                        // caller's wish for a 1x1 conv: the halo kernel (no atomics) instead of conv_wgrad_kernel
+    // 1x1 tasks of conv_wgrad128_persistent_kernel only: the problem is stated with the operands SWAPPED (dz := the convolution's
+    // input activation, x := its dz; Co := input channels, Kc := output channels) because the convolution has fewer than 128 output
+    // channels but >= 128 input channels; the tile is stored transposed, dw[Kc][Co] = the convolution's own [Co][Ci] layout
+    int transposed;
 };
 
 // ---------------------------------------------------------------------------

@@ -1311,6 +1311,12 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
     float* out = g.ksplit > 1 ? p.slab + (size_t)split * p.Co * p.Kc : p.dw;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
+        if (p.transposed) {      // out[ci][co]: this lane's four consecutive co of one ci are 16 contiguous bytes
+            float* o = out + (size_t)(ci0 + 64 * u + 16 * ctile + i16) * p.Co + co0 + cohalf * (TCO / 2) + 4 * gq;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) *reinterpret_cast<f32x4*>(o + a * 16) = acc[u][a];
+            continue;
+        }
         float* o = out + (size_t)(co0 + cohalf * (TCO / 2)) * p.Kc + ci0 + 64 * u + 16 * ctile + i16;
 #pragma unroll
         for (int a = 0; a < NA; ++a)

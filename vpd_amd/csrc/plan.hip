@@ -503,6 +503,12 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                 q.M = NB * cv.Hout * cv.Wout; q.taps = conv_taps_fwd(cv);
                 return q;
             };
+            auto wq_swapped = [&](const ConvInfo& cv) {      // dz := the input activation, x := dz (WgradParams::transposed)
+                WgradParams q = wq(cv);
+                if (cv.k != 1 || cv.stride != 1 || cv.Co % 128 == 0) { q.Co = 0; return q; }      // (Co = 0: never eligible)
+                q.dzC = cv.Ci; q.xC = cv.Co; q.Co = cv.Ci; q.Kc = cv.Co; q.transposed = 1;
+                return q;
+            };
             for (auto& B : p->blocks) {
                 std::vector<ConvInfo*> cvs = {&B.c1, &B.c2};
                 if (bottleneck) cvs.push_back(&B.c3);
@@ -514,7 +520,8 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                         // Bottleneck students: ResNet-50 step 9.32 -> 8.74 ms (36 launches of the atomics kernel at 47 us each
                         // become tasks; no atomics left).  BasicBlock students keep their three down-sampling convs on
                         // launches of their own (same-box: 3.945 vs 3.951 ms grouped).
-                        if (!bottleneck || !vpd_wgrad128_eligible(wq(*cv))) continue;
+                        // (a conv with < 128 output but >= 128 input channels -- layer1's 256 -> 64 -- joins with its operands swapped)
+                        if (!bottleneck || !(vpd_wgrad128_eligible(wq(*cv)) || vpd_wgrad128_eligible(wq_swapped(*cv)))) continue;
                     } else if (cv->k != 3) {
                         continue;
                     } else if (cv->stride != 1) {
@@ -1438,6 +1445,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         q.N = n; q.Hs = cv.Hout; q.Ws = cv.Wout; q.istr = cv.stride; q.Kc = cv.Kc; q.Co = cv.Co;
         q.M = n * cv.Hout * cv.Wout;
         q.taps = conv_taps_fwd(cv);
+        if (cv.k == 1 && cv.stride == 1 && cv.Co % 128 != 0 && cv.Ci % 128 == 0) {      // operands swapped, result stored transposed
+            q.dz = pd.x; q.dzC = cv.Ci; q.x = pd.dz; q.xC = cv.Co; q.Co = cv.Ci; q.Kc = cv.Co; q.transposed = 1;
+        }
         return q;
     };
     // `slot`: the stage whose table / schedule cache the 128 x 64 launch uses
