@@ -1534,7 +1534,10 @@ static bool conv1x1_ws_eligible(const ConvParams& p) {
     if (p.ncls > 1 || p.x2 || p.osub != 1)
         return dgon && p.ncls == 4 && p.osub == 2 && p.istr == 1 && !p.alt_w && !p.accumulate && !p.ep_scale && p.Kc >= dgk &&
                p.Co % 128 == 0 && (!p.x2 || p.Kc2 == p.Kc) && (!p.bst_z || (p.yC == p.Co && p.ypad == 0));
-    if (p.bst_z || p.oph != 0 || p.opw != 0) return false;
+    if (p.oph != 0 || p.opw != 0) return false;
+    // BatchNorm sums in the epilogue (mode 6): a deep stride-1 1x1 data gradient writing a dense tensor (Bottleneck students, layer3 / 4)
+    if (p.bst_z && !(p.istr == 1 && p.taps.nr == 1 && p.taps.nc == 1 && !p.alt_w && !p.bst_z2 && !p.accumulate && p.yC == p.Co && p.ypad == 0))
+        return false;
     // the stride-2 convs at the ResNet stage boundaries (3x3 forward, with the BasicBlock's 1x1 branch as second convolution):
     // 9-36 K-steps, one round of blocks with the tile choice below
     static const int s2on = getenv("VPD_CONV_S2_WS") ? atoi(getenv("VPD_CONV_S2_WS")) : 1;

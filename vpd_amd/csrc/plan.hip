@@ -68,6 +68,7 @@ struct BlockInfo {
     size_t a1_off = 0, a2_off = 0, out_off = 0;      // padded bf16 activations (a2: Bottleneck only)
     size_t mask_off = 0;                             // train, BasicBlock: [M][C/8] ReLU mask bits of the block output
     size_t mask1_off = 0;                            // train with dgrad_sums: ReLU mask bits of a1 (0: none)
+    size_t mask2_off = 0;                            // ... of a2 (Bottleneck students, layer3 / layer4)
 };
 struct StageInfo {
     int H = 0, W = 0, C = 0;
@@ -546,13 +547,16 @@ extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w,
                 const ConvInfo& last = bottleneck ? B.c3 : B.c2;      // the conv whose BatchNorm feeds the block-output ReLU
                 B.mask_off = bp.take((size_t)NB * last.Hout * last.Wout * last.Co / 8 + 16);
             }
-        // BasicBlock students only: a Bottleneck student's BatchNorm tensors are 4x wider, its backward launches run at the
-        // memory system's rate rather than on the barrier's latency chain, and the second read of z in the 1x1 data gradients'
-        // epilogues costs what the shorter BatchNorm launch saves (ResNet-50 8.73 -> 8.76 ms, rounds 2 and 4)
-        p->dgrad_sums = p->relu_bits && p->fused_bn && !bottleneck && !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS")));
+        // BasicBlock students: every block.  Bottleneck students: layer3 / layer4 only, the BatchNorms of conv1 / conv2 -- there the
+        // backward launches sit on the grid barrier's latency chain (14-16 us for 2-8 MB) like a BasicBlock student's; in layer1 /
+        // layer2 the tensors are 4-16x larger, the launches run at the memory system's rate, and the second read of z in the data
+        // gradients' epilogues costs what the shorter BatchNorm launch saves (ResNet-50 8.73 -> 8.76 ms with all stages, rounds 2 / 4)
+        p->dgrad_sums = p->relu_bits && p->fused_bn && !(getenv("VPD_DGRAD_SUMS") && !atoi(getenv("VPD_DGRAD_SUMS")));
         if (p->dgrad_sums)
             for (auto& B : p->blocks) {
+                if (bottleneck && B.stage < 2) continue;
                 B.mask1_off = bp.take((size_t)NB * B.c1.Hout * B.c1.Wout * B.c1.Co / 8 + 16);
+                if (bottleneck) B.mask2_off = bp.take((size_t)NB * B.c2.Hout * B.c2.Wout * B.c2.Co / 8 + 16);
             }
         for (int i = 0; i < 3; ++i) p->G_off[i] = bp.take(maxact * 2);
         p->slab_off = bp.take((size_t)(p->slab_elems > 0 ? p->slab_elems : 1) * 4);
@@ -1328,7 +1332,7 @@ extern "C" int vpd_forward_train(vpd_plan_t* p, const float* params, float* bn_r
             bf16_t* a2 = c.b16(B.a2_off);
             LCHECK(run_conv_train(c, B.c2, a1, bn_running));
             LCHECK(run_bn_fwd(c, B.c2, bn_running, 0, nullptr, nullptr, a2, 1,
-                              nullptr));
+                              B.mask2_off ? reinterpret_cast<unsigned char*>(ws + B.mask2_off) : nullptr));
             unsigned char* mb3 = p->relu_bits ? reinterpret_cast<unsigned char*>(ws + B.mask_off) : nullptr;
             if (bneck_recompute_ok(c, B)) {      // conv3 + bn3 + identity + ReLU: z3 is never stored
                 LCHECK(run_conv3_bn_fwd(c, B.c3, a2, cur, outp, mb3, bn_running));
@@ -1604,12 +1608,26 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
             if (bneck_recompute_ok(c, B)) LCHECK(run_conv3_bn_bwd(c, B.c3, c.b16(B.a2_off), dout, mb3, dz3, grads));
             else if (!bn3_pair) LCHECK(run_bn_bwd(c, B.c3, dout, c.b16(B.out_off), dz3, 1, 1, grads, false, false, mb3));
             LCHECK(queue_wgrad(B.c3, dz3, 1, c.b16(B.a2_off)));
-            // (the BatchNorm sums are not taken in a Bottleneck student's data gradients: vpd_plan_create, dgrad_sums)
-            LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
-            LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
+            // layer3 / layer4 (vpd_plan_create, dgrad_sums): the sums of bn2 / bn1 ride in the data gradients that produce their dy
+            if (B.mask2_off && dgrad_takes_sums(c, B.c3, 0)) {
+                const unsigned char* m2 = reinterpret_cast<const unsigned char*>(ws + B.mask2_off);
+                const BnSums sm{c.b16(B.c2.z_off), m2, c.bn_rows(B.c2.bn), nullptr, nullptr};
+                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0, nullptr, nullptr, nullptr, &sm));
+                LCHECK(run_bn_bwd_apply(c, B.c2, da2, dz2, 1, grads, m2));
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c3, dz3, da2, 0));
+                LCHECK(run_bn_bwd(c, B.c2, da2, nullptr, dz2, 1, 0, grads, true));
+            }
             LCHECK(queue_wgrad(B.c2, dz2, 1, c.b16(B.a1_off)));
-            LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
-            LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
+            if (B.mask1_off && dgrad_takes_sums(c, B.c2, 0)) {
+                const unsigned char* m1 = reinterpret_cast<const unsigned char*>(ws + B.mask1_off);
+                const BnSums sm{c.b16(B.c1.z_off), m1, c.bn_rows(B.c1.bn), nullptr, nullptr};
+                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0, nullptr, nullptr, nullptr, &sm));
+                LCHECK(run_bn_bwd_apply(c, B.c1, da1b, dz1, 1, grads, m1));
+            } else {
+                LCHECK(run_conv_dgrad(c, B.c2, dz2, da1b, 0));
+                LCHECK(run_bn_bwd(c, B.c1, da1b, nullptr, dz1, 1, 0, grads, true));
+            }
             LCHECK(queue_wgrad(B.c1, dz1, 1, xin));
             if (B.ds) {
                 bf16_t* dzd = c.b16(grouped && B.cd.dz_own_off ? B.cd.dz_own_off : S.dzd_off);
