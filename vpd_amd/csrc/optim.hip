@@ -72,6 +72,41 @@ __global__ __launch_bounds__(256) void pack_input_px_kernel(const float* x, int 
         *reinterpret_cast<uint4*>(out + ((size_t)(b * Hp + y + pad) * Wp + xx + pad) * Cp) = pack8(v);
     }
 }
+// Rows of a multiple of 64 pixels (the 128 x 128 crops of every BASELINE config): a wave takes 256 consecutive pixels of an image --
+// one float4 per lane and channel plane in (1 KB per instruction), through its own 8 KB of LDS ([plane][256 pixels]: written four
+// pixels per lane, read one pixel per lane), one 16-byte pixel per lane out: every store instruction covers 1 KB of one padded row.
+// (pack_input_kernel's lanes write 64-byte pieces 64 bytes apart with four instructions that each touch 64 different lines.)
+template <int CT>
+__global__ __launch_bounds__(256) void pack_input_rows_kernel(const float* x, int N, int H, int W, bf16_t* out, int Hp, int Wp,
+                                                              int pad) {
+    __shared__ float lds[4][CT][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long plane = (long)H * W;
+    const long nwork = (long)N * plane / 256;                          // (H * W % 256 == 0: checked by the launcher)
+    const int per_img = (int)(plane / 256);
+    float (*my)[256] = lds[wave];
+    for (long it = (long)blockIdx.x * 4 + wave; it < nwork; it += (long)gridDim.x * 4) {
+        const int b = (int)(it / per_img);
+        const int p0 = (int)(it - (long)b * per_img) * 256;            // first pixel of the image
+        const float* src = x + (size_t)b * CT * plane + p0 + 4 * lane;
+        float4 f[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) f[c] = *reinterpret_cast<const float4*>(src + (size_t)c * plane);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *reinterpret_cast<float4*>(&my[c][4 * lane]) = f[c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = p0 + q * 64 + lane;
+            const int y = p / W, xx = p - y * W;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = c < CT ? my[c][q * 64 + lane] : 0.f;
+            *reinterpret_cast<uint4*>(out + ((size_t)(b * Hp + y + pad) * Wp + xx + pad) * 8) = pack8(v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf16_t* out, int Hp, int Wp, int pad,
                                  int Cp, hipStream_t s) {
     if (Cp != 8 || C > 8) return hipErrorInvalidValue;
@@ -81,6 +116,15 @@ hipError_t vpd_launch_pack_input(const float* x, int N, int C, int H, int W, bf1
     if (g > 8192) g = 8192;
     if (!quad) {
         hipLaunchKernelGGL(pack_input_px_kernel, dim3(g < 1 ? 1 : (int)g), dim3(256), 0, s, x, N, C, H, W, out, Hp, Wp, pad, Cp);
+        return hipGetLastError();
+    }
+    if ((W & 63) == 0 && ((long)H * W) % 256 == 0 && (C == 5 || C == 3 || C == 6)) {
+        long gb = ((long)N * H * W / 256 + 3) / 4;
+        if (gb > 4096) gb = 4096;
+        const dim3 gr((unsigned)(gb < 1 ? 1 : gb));
+        if (C == 5) hipLaunchKernelGGL(pack_input_rows_kernel<5>, gr, dim3(256), 0, s, x, N, H, W, out, Hp, Wp, pad);
+        else if (C == 3) hipLaunchKernelGGL(pack_input_rows_kernel<3>, gr, dim3(256), 0, s, x, N, H, W, out, Hp, Wp, pad);
+        else hipLaunchKernelGGL(pack_input_rows_kernel<6>, gr, dim3(256), 0, s, x, N, H, W, out, Hp, Wp, pad);
         return hipGetLastError();
     }
     const dim3 grid(g < 1 ? 1 : (int)g);
