@@ -12,7 +12,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "pack_input_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "pack_input" in r["Kernel_Name"]]
 if len(starts) < skip + 3:
     sys.exit("need more steps in the trace (%d found)" % len(starts))
 per_step, gaps_all, by_pred = [], [], {}

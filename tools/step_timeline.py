@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the zero_ranges launch that precedes pack_input
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("pack_input") or "pack_input_kernel" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "pack_input" in r["Kernel_Name"]]
 if len(starts) < 2:
     sys.exit("need at least two steps in the trace")
 # the step with the smallest sum of inter-dispatch gaps among the last ten complete ones (one host hiccup under the profiler

@@ -259,7 +259,8 @@ __global__ __launch_bounds__((NMW + 4) * 64) void conv1x1_stream_kernel(const Co
 //             [MODE 3]      z3 tile again; dz3 = A g + B z3 + D (bn_bwd_apply_coef in the prologue, dgamma / dbeta from the first
 //                           lane) -> padded dz3 for the weight- and data-gradient launches.
 // z3 is rounded to bf16 in registers exactly where the unfused path stores it: the forward is bit-identical to conv + bn_fwd_fused,
-// the backward has bn_bwd_apply_fused_kernel's arithmetic.  64 x 256 tiles (four MFMA waves x 64 channels), Kc = 64 / 128.
+// the backward has bn_bwd_apply_fused_kernel's arithmetic.  64 x 256 tiles (eight MFMA waves x 32 pixels x 64 channels; the statistics
+// pass keeps the storing launch's four), Kc = 64 / 128.
 // ---------------------------------------------------------------------------
 struct StreamBn {
     const double* rows; float count;                       // MODE 1 / 3: the sums to finalize ([VPD_FUSED_ROWS][2][Co])
