@@ -1075,7 +1075,7 @@ hipError_t run_conv3d_bn_fwd(const Ctx& c, const BlockInfo& B, const bf16_t* xin
         const ConvInfo& cv = k ? B.cd : B.c3;
         ConvParams q = conv3_params(c, cv, k ? xin : c.b16(B.a2_off));
         q.stats = c.bn_rows(cv.bn); q.stat_rows = VPD_FUSED_ROWS;
-        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, 4, 0.0);      // (a recomputation: its time counts, its FLOPs are not algorithmic work)
         e = vpd_launch_conv1x1_bn(q, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, c.s);
         if (e != hipSuccess) return e;
     }
@@ -1102,11 +1102,11 @@ hipError_t run_conv3d_bn_bwd(const Ctx& c, const BlockInfo& B, const bf16_t* xin
     fd.gamma = c.params + B.cd.bn.w_off; fd.dgamma = grads + B.cd.bn.w_off; fd.dbeta = grads + B.cd.bn.b_off;
     hipError_t e;
     {
-        TimeScope ts(c.p, c.s, 4, conv_flops(B.c3, c.n) + conv_flops(B.cd, c.n));
+        TimeScope ts(c.p, c.s, 4, 0.0);      // (BatchNorm backwards: no algorithmic matrix FLOPs)
         e = vpd_launch_conv1x1_bn2(q, nullptr, &f3, &fd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 2, c.s);
     }
     if (e != hipSuccess) return e;
-    TimeScope ts(c.p, c.s, 4, conv_flops(B.c3, c.n) + conv_flops(B.cd, c.n));
+    TimeScope ts(c.p, c.s, 4, 0.0);
     return vpd_launch_conv1x1_bn2(q, nullptr, &f3, &fd, c.bn_mean(B.c3.bn), c.bn_rstd(B.c3.bn), c.bn_mean(B.cd.bn), c.bn_rstd(B.cd.bn),
                                   nullptr, dz3, dzd, 1, 3, c.s);
 }
@@ -1117,7 +1117,7 @@ hipError_t run_conv3_bn_fwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, c
     q.stats = c.bn_rows(cv.bn); q.stat_rows = VPD_FUSED_ROWS;
     hipError_t e;
     {
-        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, 4, 0.0);      // (the statistics pass is a recomputation: time counted, FLOPs not)
         e = vpd_launch_conv1x1_bn(q, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, c.s);
     }
     if (e != hipSuccess) return e;
@@ -1145,11 +1145,11 @@ hipError_t run_conv3_bn_bwd(const Ctx& c, const ConvInfo& cv, const bf16_t* x, b
     f.gamma = c.params + cv.bn.w_off; f.dgamma = grads + cv.bn.w_off; f.dbeta = grads + cv.bn.b_off;
     hipError_t e;
     {
-        TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+        TimeScope ts(c.p, c.s, 4, 0.0);      // (a BatchNorm backward: no algorithmic matrix FLOPs)
         e = vpd_launch_conv1x1_bn(q, nullptr, &f, nullptr, nullptr, nullptr, nullptr, 0, 2, c.s);
     }
     if (e != hipSuccess) return e;
-    TimeScope ts(c.p, c.s, 4, conv_flops(cv, c.n));
+    TimeScope ts(c.p, c.s, 4, 0.0);
     return vpd_launch_conv1x1_bn(q, nullptr, &f, c.bn_mean(cv.bn), c.bn_rstd(cv.bn), nullptr, dz, 1, 3, c.s);
 }
 

@@ -414,7 +414,7 @@ class StudentEngine:
         # (class 1 -> conv3x3_pws_kernel<256,128,352> only with > 1 tile per block, else the class-6 tile; the non-persistent
         #  conv3x3_ws_kernel twins of every class remain behind VPD_PWS=0)
         names = ["conv3x3_c64_persistent_kernel<224>", "conv3x3_pws_kernel<256,128,352>", "conv3x3_pws_kernel<256,64,416> | <128,128,288>",
-                 "conv3x3_pws_kernel<128,64,288>", "conv1x1_ws_kernel (stride-2 / 1x1 ring GEMM) + conv_igemm_kernel (gather)", "conv_wgrad128_persistent_kernel (layer2-4) + conv_wgrad_halo_grouped_kernel (layer1)",
+                 "conv3x3_pws_kernel<128,64,288>", "conv1x1_ws_kernel (stride-2 / 1x1 ring GEMM) + conv1x1_stream_kernel (Bottleneck 1x1, streaming / recompute) + conv_igemm_kernel (gather)", "conv_wgrad128_persistent_kernel (layer2-4) + conv_wgrad_halo_grouped_kernel (layer1)",
                  "conv_wgrad_halo_kernel<10|13> (stride 2) + conv_wgrad_kernel (1x1)",
                  "conv_stem_persistent_kernel<160> + conv_wgrad_stem_kernel"]
         return {names[i]: dict(launches=out[3 * i], ms=out[3 * i + 1], flops=out[3 * i + 2]) for i in range(8)}
