@@ -10,13 +10,13 @@ traffic = json.load(open(sys.argv[1]))["kernels"]
 min_mb = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
 dur = {}
 for r in csv.DictReader(open(sys.argv[2])):
-    n = r["Name"].split("(")[0].strip()
+    n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].strip()
     dur["adamw_pack_kernel" if n.startswith("_Z17adamw_pack_kernel") else n] = float(r["AverageNs"]) / 1e3
 print("# fabric-side bytes (2*FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) / rocprofv3 average duration")
 print("%-58s %10s %9s %8s" % ("kernel", "MB/launch", "avg us", "TB/s"))
 rows = []
 for name, t in traffic.items():
-    key = name.split("(")[0].strip()
+    key = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
     if key.startswith("_Z17adamw_pack_kernel"):
         key = "adamw_pack_kernel"
     if key not in dur:

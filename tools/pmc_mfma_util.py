@@ -22,7 +22,7 @@ def main():
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].strip()
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].strip()
             a = acc.setdefault(name, {})
             c = a.setdefault(r["Counter_Name"], [0, 0.0])
             c[0] += 1

@@ -30,7 +30,7 @@ def per_kernel(d, counter):
             if r.get("Counter_Name") != counter:
                 continue
             name = r["Kernel_Name"]
-            name = name.split("(")[0].strip() if not name.startswith("void ") else name.split("(")[0].strip()
+            name = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
             a = acc.setdefault(name, [0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
