@@ -215,6 +215,36 @@ def cpu_baseline(batch=64, warm=3, timed=10):
     return train, apply
 
 
+PARITY_FIXTURE = "tests/golden/c2_r34_c5_d128_m0_n256.npz"
+PARITY_TOL = 2e-2
+
+
+def parity_block(device):
+    """The metric's second half, "emb L2 vs ref" (BASELINE.json): embed() (models/rgb.py:72-86) of the 256 crops of the committed
+    fixture -- embeddings the REFERENCE produced on its CPU path for configs[1]'s student (oracle/gen_golden.py) -- through the HIP
+    eval forward, per-sample ||e - e_ref|| / ||e_ref||.  Inputs (weights, crops) are regenerated from the fixture's seeds by
+    tests/golden/recipe.py (numpy; nothing under oracle/ is imported).  Runs before the timed region, on its own model."""
+    import importlib.util
+    from vpd_amd.models.rgb import RGBF_EmbeddingModel
+    spec = importlib.util.spec_from_file_location("vpd_golden_recipe", os.path.join(REPO, "tests", "golden", "recipe.py"))
+    recipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(recipe)
+    g = np.load(os.path.join(REPO, PARITY_FIXTURE))
+    meta = json.loads(str(g["meta"]))
+    enc = RGBF_EmbeddingModel(meta["arch"], meta["emb_dim"], meta["c_in"] != 3, device)
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in recipe.procedural_weights(shapes, meta["seed"]).items()})
+    img = recipe.synthetic_crops(meta["n"], meta["c_in"], meta["hw"], meta["seed"] + 1)
+    e = np.asarray(enc.embed(img), np.float64)
+    ref = np.asarray(g["emb_eval"], np.float64)
+    ps = np.linalg.norm(e - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+    del enc
+    return {"emb_rel_l2_max": float(ps.max()), "emb_rel_l2_mean": float(ps.mean()), "crops": int(meta["n"]), "fixture": PARITY_FIXTURE,
+            "tol": PARITY_TOL, "ok": bool(ps.max() <= PARITY_TOL),
+            "what": "per-sample ||e - e_ref|| / ||e_ref|| of embed() (eval mode, bf16 operands / fp32 accumulation) against the "
+                    "reference's fp32 CPU embeddings of the same crops and weights (ResNet-34, 5x128x128, D=128)"}
+
+
 def visible_gpu_count():
     """GPUs this process tree may use, WITHOUT touching the HIP runtime (the parent of the ranks must not initialise it):
     the visibility variables if set, else the KFD topology nodes that have SIMDs."""
