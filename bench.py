@@ -358,6 +358,7 @@ def main():
                          "motion head, 256 crops per GPU), c4 = configs[3] (fs normalisation, motion head, 512 crops per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-apply", action="store_true", help="skip the inference-twin block")
+    ap.add_argument("--no-parity", action="store_true", help="skip the embedding-parity block (emb L2 vs the reference fixture)")
     ap.add_argument("--arch", default=ARCH, help="student architecture (default: the BASELINE config, resnet34)")
     ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
     args = ap.parse_args()
@@ -392,6 +393,12 @@ def main():
     from vpd_amd.trainer import ModelTrainer
 
     from vpd_amd.data import RGB_MEAN_STD
+    # "emb L2 vs ref": before anything is timed, on a model of its own (rank 0; every rank computes the same thing)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_block(device)
+        if not parity["ok"]:
+            raise SystemExit("bench.py: embeddings differ from the reference fixture: %s" % json.dumps(parity))
     torch.manual_seed(0)
     enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device, in_channels=c_in)
     enc.reset_parameters(seed=0)                 # reference init semantics, same weights on every rank
@@ -552,6 +559,8 @@ def main():
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "flop_per_crop": flop, "loss_last_step": loss_now},
                "roofline": roofline}
+        if parity is not None:
+            out["parity"] = parity
         if multi is not None:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_apply and args.arch == ARCH and args.config == "c2":

@@ -185,9 +185,10 @@ int vpd_graph_launch_eval(vpd_plan_t* plan, int n, void* stream);
 int vpd_plan_sync_errors(vpd_plan_t* plan, void* workspace, void* stream, unsigned* count_out);
 
 /* Per-kernel-class timing for the roofline report (bench.py): when enabled, every conv launch is
- * bracketed by HIP events on its own stream.  One class per kernel function: 0 conv3x3_c64_persistent_kernel<224>,
- * 1 conv3x3_ws_kernel<256,128,352>, 2 conv3x3_ws_kernel<128,128,288>, 3 conv3x3_ws_kernel<128,64,288>,
- * 4 conv_igemm_kernel (gather), 5 conv_wgrad_halo_grouped_kernel (stride-1 3x3, per stage, without its slab reduce),
+ * bracketed by HIP events on its own stream.  One class per kernel family: 0 conv3x3_c64_persistent_kernel<224>,
+ * 1 conv3x3_pws_kernel<256,128,352>, 2 conv3x3_pws_kernel<256,64,416> and <128,128,288>, 3 conv3x3_pws_kernel<128,64,288>
+ * (conv3x3_ws_kernel, their one-tile-per-block twin, with VPD_PWS=0), 4 conv_igemm_kernel (gather), the ring GEMM conv1x1_ws_kernel
+ * and the streaming 1x1 kernels, 5 conv_wgrad128_persistent_kernel / conv_wgrad_halo_grouped_kernel (stride-1 3x3, per stage, without the slab reduce),
  * 6 per-conv weight-gradient launches (stride-2 3x3 on conv_wgrad_halo_kernel, 1x1 on conv_wgrad_kernel),
  * 7 conv_stem_persistent_kernel.  vpd_plan_read_timing (nclasses >= 8) waits for the events, writes out[3*cls + {0,1,2}] = {launches, milliseconds, algorithmic FLOPs} and clears. */
 int vpd_plan_set_timing(vpd_plan_t* plan, int enable);

@@ -438,6 +438,8 @@ STREAM_CASES = [
     ("k128_n64", 256, 128, 64, 16, 16, 1),
     ("k128_n128", 256, 128, 128, 16, 16, 1),
     ("k128_n512", 128, 128, 512, 16, 16, 1),
+    ("k64_n192", 64, 64, 192, 32, 32, 1),       # Co = 192: 64-wide channel tiles (only 64 / 128 / 256 are instantiated)
+    ("k128_n192", 256, 128, 192, 16, 16, 1),
     ("k256_n128_and_k128_n256", 128, 256, 128, 16, 16, 1),
     ("k256_n512_s2", 64, 256, 512, 32, 32, 2),
 ]

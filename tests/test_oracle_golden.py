@@ -216,3 +216,25 @@ def test_oracle_gradients_match_the_reference_in_the_well_conditioned_regime(arc
         scale = float(g["gnorm/" + k]) / np.sqrt(mine.numel())          # RMS element of the tensor
         assert np.abs(samp - ref).max() <= 2e-3 * scale + 1e-7, (k, float(np.abs(samp - ref).max()), scale)
         assert abs(float(mine.norm()) - float(g["gnorm/" + k])) <= 2e-4 * float(g["gnorm/" + k]) + 1e-9, k
+
+
+def test_fixture_recipe_reproduces_the_oracle_generators():
+    """tests/golden/recipe.py (numpy only; what bench.py's parity block rebuilds a fixture's inputs with) == the oracle's
+    procedural_state_dict / synthetic_crops, bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vpd_golden_recipe", os.path.join(GOLDEN, "recipe.py"))
+    recipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(recipe)
+    for arch, c_in, d in (("resnet34", 5, 128), ("resnet18", 3, 32), ("resnet50", 6, 32)):
+        sch = O.encoder_schema(arch, c_in, d)
+        want = O.procedural_state_dict(sch, 11)
+        got = recipe.procedural_weights({k: v[0] for k, v in sch.items()}, 11)
+        assert list(got) == list(want)
+        for k in want:
+            assert np.array_equal(got[k], want[k].numpy()), k
+    dsch = O.decoder_schema(32)
+    want = O.procedural_state_dict(dsch, 5)
+    got = recipe.procedural_weights({k: v[0] for k, v in dsch.items()}, 5)
+    assert all(np.array_equal(got[k], want[k].numpy()) for k in want)
+    for c_in in (3, 5, 6):
+        assert np.array_equal(recipe.synthetic_crops(3, c_in, 32, 9), O.synthetic_crops(3, c_in, 32, 9).numpy())

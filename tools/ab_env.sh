@@ -2,7 +2,7 @@
 # Same-box A/B of environment switches: tools/ab_env.sh "<label>:<ENV=..,ENV=..>" ...   ("<label>:" alone = defaults)
 # Each configuration runs bench.py twice, alternating, and prints crops/s + the per-class table of each run.
 python3 -c "from vpd_amd.boxid import gpu_unique_id; print('gpu_unique_id', gpu_unique_id(0))" 2>/dev/null
-ARGS="--no-cpu-baseline --no-apply --repeats 3 --steps 100 --warmup 20 ${AB_EXTRA:-}"      # AB_EXTRA: e.g. "--arch resnet50" or "--batch 512"
+ARGS="--no-cpu-baseline --no-apply --no-parity --repeats 3 --steps 100 --warmup 20 ${AB_EXTRA:-}"      # AB_EXTRA: e.g. "--arch resnet50" or "--batch 512"
 for rep in 1 2; do
   for cfg in "$@"; do
     label=${cfg%%:*}; envs=${cfg#*:}

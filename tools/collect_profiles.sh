@@ -7,11 +7,11 @@ set -u
 TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out
-ARGS="--steps 20 --warmup 5 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
+ARGS="--steps 20 --warmup 5 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply --no-parity"
 cd /tmp && export TMPDIR=/tmp
 export VPD_PROFILE_TAG=$TAG
 # 1. counters first: the default bench run below then reads the traffic figure collected on THIS box (roofline.traffic_source)
-PARGS="--steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
+PARGS="--steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply --no-parity"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o pmc --output-format csv -- python3 $R/bench.py $PARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o pmc --output-format csv -- python3 $R/bench.py $PARGS > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.txt

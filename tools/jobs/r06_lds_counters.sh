@@ -7,7 +7,7 @@ python3 -c "from vpd_amd.boxid import gpu_unique_id; print('gpu_unique_id', gpu_
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $OUT/r06_counter_list.txt 2>&1
 grep -o 'SQ_LDS[A-Z_0-9]*\|SQ_WAIT[A-Z_0-9]*\|SQ_ACTIVE_INST[A-Z_0-9]*\|SQ_INSTS_[A-Z_0-9]*\|SQ_VALU_MFMA[A-Z_0-9]*\|SQ_INST_CYCLES[A-Z_0-9]*' $OUT/r06_counter_list.txt | sort -u > $OUT/r06_counter_names.txt
-PARGS="--steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
+PARGS="--steps 4 --warmup 2 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply --no-parity"
 pass() {   # pass <name> <counters...>
   local n=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" -d $D/$n -o pmc --output-format csv -- python3 $R/bench.py $PARGS > $D/$n.log 2>&1

@@ -4,7 +4,7 @@
 set -u
 TAG=$1; shift
 R=$PWD; OUT=$R/gpurun_out
-ARGS="--steps 20 --warmup 5 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply"
+ARGS="--steps 20 --warmup 5 --repeats 1 --profile-steps 0 --no-cpu-baseline --no-apply --no-parity"
 cd /tmp && export TMPDIR=/tmp
 for cfg in "$@"; do
   label=${cfg%%:*}; envs=${cfg#*:}

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPD_LIB_PATH: A/B another build of the same ABI on the same GPU (devices differ by several % in clocks)
 LIB_PATH = os.environ.get("VPD_LIB_PATH") or os.path.join(_HERE, "libvpdhip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_int_p = C.POINTER(C.c_int)
 c_ll_p = C.POINTER(C.c_longlong)

@@ -378,11 +378,14 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
         if (g.multi) prow0 = (gr0 / H) * (H + 2);
         else { const int b = gr0 / H; prow0 = b * (H + 2) + (gr0 - b * H); }
         const int gp0 = prow0 * Wp;
+        // chunk rotation (HaloGeom::rot, as conv3x3_pws_kernel: bit-identical results): logical chunk cc is chunk (cc + tile) % nchunks
+        const int crot = g.rot ? mtile % nchunks : 0;
         auto halo_instr = [&](int cc, int k) __attribute__((always_inline)) {      // pass k of chunk cc
             const int hp = (lw + 4 * k) * 8 + lrow;
             int gp = gp0 + hp;
             gp = gp < g.total_pix ? gp : g.total_pix - 1;
-            const bf16_t* src = p.x + (size_t)gp * Ci + cc * 64 + ((piece ^ (hp & 7)) << 3);
+            const int cce = cc + crot >= nchunks ? cc + crot - nchunks : cc + crot;
+            const bf16_t* src = p.x + (size_t)gp * Ci + cce * 64 + ((piece ^ (hp & 7)) << 3);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (cc & (HB - 1)) * HBUF + (lw + 4 * k) * 8 * 64), 16, 0, 0);
         };
         auto issue_w = [&](int step, int stage) __attribute__((always_inline)) {
@@ -390,7 +393,8 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
             const int tap = step - cc * 9;
             const int ir = tap / 3, ic = tap - ir * 3;
             const int wsl = p.taps.w0 + ir * p.taps.wrs + ic * p.taps.wcs;
-            const bf16_t* wbp = p.w + ((size_t)wsl * p.Co + n0) * Ci + cc * 64;
+            const int cce = cc + crot >= nchunks ? cc + crot - nchunks : cc + crot;
+            const bf16_t* wbp = p.w + ((size_t)wsl * p.Co + n0) * Ci + cce * 64;
 #pragma unroll
             for (int i = 0; i < W_PER; ++i) {
                 const int n = (lw + 4 * i) * 8 + lrow;
@@ -861,6 +865,7 @@ static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
     g->TR = TR;
     g->NHP = g->HR * (W + 2);
     g->total_pix = p.N * (H + 2) * (W + 2);
+    g->rot = 0; g->rnch = 1.0f;
     return g->NHP <= C64X2_HPIX && p.M >= 256 * 256;      // at least one 256-pixel tile per CU (256 crops of 32 x 32: 1024 tiles)
 }
 static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
@@ -1298,7 +1303,12 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
         fprintf(stderr, "%llu cycles\n", emax - lo);
     } };
 #endif
-    switch (conv_ep_mode(q)) {
+    bool geo_launched = false;
+    if (PIPE && NMW == 4) {
+        static const int geo_on = getenv("VPD_PWS_GEO") ? atoi(getenv("VPD_PWS_GEO")) : 1;
+        geo_launched = geo_on && vpd_launch_pws_geo(BM, BN, HROWS, NS, q, g, sg, grid, block, lds, stream);
+    }
+    if (!geo_launched) switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
         case 1: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 1, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
         case 2: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 2, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;
@@ -1600,6 +1610,9 @@ static bool halo_geom(const ConvParams& p, int BM, int hrows_max, HaloGeom* g) {
     if (W >= 8) { g->kmask = 7; g->kshift = 0; g->rowmask = 0; }
     else { g->kmask = 3; g->kshift = 2; g->rowmask = 1; }
     g->rH = 1.0f / (float)H; g->rW = 1.0f / (float)W; g->rWp = 1.0f / (float)(W + 2);
+    static const int rot = getenv("VPD_PWS_ROT") ? atoi(getenv("VPD_PWS_ROT")) : 1;
+    g->rot = rot && p.Kc > 64;
+    g->rnch = 1.0f / (float)(p.Kc / 64);
     return g->NHP <= hrows_max;
 }
 
@@ -1728,7 +1741,11 @@ hipError_t vpd_launch_conv(const ConvParams& p0, hipStream_t stream) {
     if (p0.bst_z && (!p0.stats || !p0.bst_mask)) return hipErrorInvalidValue;
     if (p0.bst_z2 && !p0.stats2) return hipErrorInvalidValue;
     ConvParams p = p0;
+#ifdef VPD_ENABLE_ABLATE
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+#else
+    constexpr int ablate = 0;
+#endif
     p.ablate = ablate;
     HaloGeom g;
     switch (vpd_conv_kernel_class(p, &g)) {

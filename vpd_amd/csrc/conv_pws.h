@@ -44,6 +44,14 @@ struct HaloGeom {
     // conv3x3_pws_kernel only: swizzle key of halo pixel (row hr, column xp of the padded tile) = (xp & kmask) ^ ((hr & rowmask) << kshift)
     int kmask, kshift, rowmask;
     float rH, rW, rWp;   // correctly rounded 1 / H, 1 / W, 1 / (W + 2) from the host (vpd_fdiv)
+    // Chunk rotation (round 6; conv3x3_pws_kernel and conv3x3_ws_kernel): pixel tile t walks the 64-channel chunks of the K
+    // dimension starting at chunk t % nchunks instead of 0.  Every block of a launch reads chunk cc of 512-byte (layer3) or
+    // 1-KB (layer4) pixels and weight rows at the same time -- a quarter / an eighth of the 128-byte lines; staggered, the
+    // launch's requests cover all of them (layer3 / layer4 launches 4-6 % shorter, +1.3 % on the step:
+    // profiles/r06_ab_chunk_rotation.txt).  The order is a function of the tile index alone, so results do not depend on
+    // the grid; each accumulator's fp32 summation order over chunks is rotated accordingly.
+    int rot;             // 1: on (VPD_PWS_ROT=0 turns it off)
+    float rnch;          // 1 / nchunks
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -207,7 +215,9 @@ struct PwsSched {
     static constexpr int max_inflight() { int m = 0; for (int t = 0; t < 9; ++t) m = inflight(t) > m ? inflight(t) : m; return m; }
 };
 
-template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
+// WC > 0 (round 6): the image width is a compile-time constant (WC = W; FLIP: the data gradient's mirrored taps), so a pixel
+// fragment's LDS address is a per-lane register of the launch + an IMMEDIATE per tap -- see "compile-time geometry" below
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE, int WC = 0, bool FLIP = false>
 static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloGeom& g, const PwsGrid& sg) {
     constexpr int WN = BN / 64;
     constexpr int WM = NMW / WN;
@@ -223,6 +233,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     using SC = PwsSched<W_PER, HPASS, HT, A>;
     static_assert(HROWS % 8 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
     static_assert(EPM == 0 || EPM == 1 || EPM == 2 || EPM == 3 || EPM == 6 || EPM == 7 || EPM == 8, "epilogue mode");
+    static_assert(WC == 0 || (PIPE && NMW == 4), "compile-time geometry: four pipelined MFMA waves only");
     constexpr unsigned OFF_W = 2u * HBUF * 2u;                       // bytes
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
     constexpr unsigned OFF_RED = OFF_DUMP + 1024u;
@@ -283,7 +294,14 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             const int prow0 = g.multi ? b * (H + 2) : b * (H + 2) + (gr0 - b * H);
             return __builtin_amdgcn_readfirstlane(prow0 * Wp);
         };
-        auto halo_instr = [&](int gp0, int cc, int buf, int k) __attribute__((always_inline)) {
+        // chunk rotation (HaloGeom::rot): tile t starts at chunk t % nchunks; the chunk a loader instruction fetches = eff(logical
+        // chunk, its tile's rotation) -- the MFMA waves only ever see "the next chunk"
+        auto tile_rot = [&](int mtile) __attribute__((always_inline)) {
+            if (!g.rot) return 0;
+            return __builtin_amdgcn_readfirstlane(mtile - vpd_fdiv(mtile, g.rnch) * nchunks);
+        };
+        auto effcc = [&](int cc, int r) __attribute__((always_inline)) { const int e = cc + r; return e >= nchunks ? e - nchunks : e; };
+        auto halo_instr = [&](int gp0, int cc, int buf, int k) __attribute__((always_inline)) {      // (cc: effective chunk)
             if (HINSTR % 4 != 0 && lw + 4 * k >= HINSTR) { pws_dma16(p.w, lds0 + OFF_DUMP); return; }      // filler: keeps the counts
             const unsigned dst = lds0 + (unsigned)buf * (HBUF * 2u) + (unsigned)(lw + 4 * k) * 1024u;
             if (gp0 + HINSTR * 8 <= g.total_pix) {               // (wave-uniform) the whole halo lies inside the tensor
@@ -302,7 +320,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             const int n = (lw + 4 * i) * 8 + lrow;
             wrow[i] = (unsigned)(((n0 + n) * Ci + ((piece ^ (n & 7)) << 3)) * 2);
         }
-        auto issue_w = [&](int tap, int cc, unsigned stg) __attribute__((always_inline)) {
+        auto issue_w = [&](int tap, int cc, unsigned stg) __attribute__((always_inline)) {               // (cc: effective chunk)
             const int wsl = p.taps.w0 + (tap / 3) * p.taps.wrs + (tap % 3) * p.taps.wcs;
             const char* wbp = reinterpret_cast<const char*>(p.w) + ((size_t)wsl * p.Co * Ci + cc * 64) * 2;
 #pragma unroll
@@ -310,11 +328,12 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                 pws_dma16s(wbp, wrow[k], lds0 + OFF_W + stg * (WSTAGE * 2u) + (unsigned)(lw + 4 * k) * 1024u);
         };
         // prologue: the first tile's first halo, then the weights of steps 0 .. A (retired in this order)
+        int w_job = 0, wrot = tile_rot(lane0);                       // tile of the next weight bundle and its rotation
         {
             const int gp0 = tile_gp0(lane0);
             PWS_STAMP(12);                                           // first tile's origin known
 #pragma unroll
-            for (int k = 0; k < HPASS; ++k) { hoff[k] = halo_off(k); halo_instr(gp0, 0, 0, k); }
+            for (int k = 0; k < HPASS; ++k) { hoff[k] = halo_off(k); halo_instr(gp0, effcc(0, wrot), 0, k); }
         }
         PWS_STAMP(9);                                                // first halo issued
         int w_tap = 0, w_cc = 0;                                     // tap / chunk-in-tile of the next weight bundle
@@ -322,18 +341,20 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
         int w_step = 0;                                              // ... and its step index
 #pragma unroll
         for (int k = 0; k <= A; ++k) {
-            if (w_step < total && !VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
+            if (w_step < total && !VPD_ABL(p, 1)) issue_w(w_tap, effcc(w_cc, wrot), w_st);
             ++w_step;
-            if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
+            if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) { w_cc = 0; wrot = tile_rot(lane0 + ++w_job * sg.lanes); } }
             if (++w_st == NS) w_st = 0;
         }
         PWS_STAMP_RT(13);                                            // (100 MHz counter at the loader's start of streaming)
         const int total_chunks = njobs * nchunks;
         int h_job = nchunks > 1 ? 0 : 1, h_cc = nchunks > 1 ? 1 : 0; // the chunk whose halo is issued during this chunk
+        int hrot = tile_rot(lane0 + h_job * sg.lanes);
         for (int c = 0; c < total_chunks; ++c) {
             const bool has_next = c + 1 < total_chunks;
             const int h_gp0 = has_next ? tile_gp0(lane0 + h_job * sg.lanes) : 0;
             const int h_buf = (c + 1) & 1;
+            const int h_cce = effcc(h_cc, hrot);
             // one chunk = nine READY barriers, unrolled: every bundle's size is a constant of its tap
             auto step = [&](auto tc) __attribute__((always_inline)) {
                 constexpr int t = decltype(tc)::value;
@@ -343,22 +364,22 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                 if (c == 0 && t == 0) PWS_STAMP(10);                 // first two steps landed
                 if (!VPD_ABL(p, 16) || (c == 0 && t == 0)) __builtin_amdgcn_s_barrier();      // READY_s (ablation 16: one tile per block only)
                 if (w_step < total) {
-                    if (!VPD_ABL(p, 1)) issue_w(w_tap, w_cc, w_st);
+                    if (!VPD_ABL(p, 1)) issue_w(w_tap, effcc(w_cc, wrot), w_st);
                     ++w_step;
-                    if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) w_cc = 0; }
+                    if (++w_tap == 9) { w_tap = 0; if (++w_cc == nchunks) { w_cc = 0; wrot = tile_rot(lane0 + ++w_job * sg.lanes); } }
                     if (++w_st == NS) w_st = 0;
                 }
                 if constexpr (SC::cnt(t) > 0) {
                     if (has_next && !VPD_ABL(p, 4)) {
 #pragma unroll
-                        for (int u = 0; u < SC::cnt(t); ++u) halo_instr(h_gp0, h_cc, h_buf, SC::first(t) + u);
+                        for (int u = 0; u < SC::cnt(t); ++u) halo_instr(h_gp0, h_cce, h_buf, SC::first(t) + u);
                     }
                 }
             };
             step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
             step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
             step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
-            if (++h_cc == nchunks) { h_cc = 0; ++h_job; }
+            if (++h_cc == nchunks) { h_cc = 0; ++h_job; hrot = tile_rot(lane0 + h_job * sg.lanes); }
         }
         pws_vmwait<0>();
         PWS_STAMP(11);                                               // loader done
@@ -438,6 +459,17 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
 #endif
     unsigned stage = 0;                                              // ring stage of the step being consumed
     int gch = 0;                                                     // global chunk index: halo buffer gch & 1
+    // compile-time geometry: per-lane fragment bases (see the K loop); pb starts in halo buffer 0
+    unsigned pb[WC > 0 ? 3 : 1][2][MI];
+    unsigned wv0 = 0, wv1 = 0, hbsel = 0;
+    if constexpr (WC > 0) {
+#pragma unroll
+        for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) { pb[ic][0][b] = lds0 + lo[ic][b]; pb[ic][1][b] = (lds0 + lo[ic][b]) ^ 64u; }
+        wv0 = lds0 + OFF_W + wa0;
+        wv1 = wv0 ^ 64u;
+    }
     for (int job = 0; job < njobs; ++job) {
         const int mtile = lane0 + job * sg.lanes;
         f32x4 acc[NI][MI];
@@ -486,6 +518,125 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             __builtin_amdgcn_sched_group_barrier(0x008, NI * MI - (NI + MI), 0);
         };
 
+        // modes 6 / 7: the epilogue's z fragments and mask bits; eval with a residual (mode 3): its fragments -- requested at the start of
+        // the tile's LAST chunk where the registers are there (see the generic loop below)
+        BstFrag<NI, VPD_BST_MB(MI)> bst;
+        constexpr bool RES_EARLY = PIPE && EPM == 3 && PWS_RES_EARLY;
+        ResFrag<NI, MI> resf;
+        const bool res_pre = RES_EARLY && p.res != nullptr;
+        // ---- compile-time geometry (WC > 0) -------------------------------------------------------------------------------
+        // What bounds the generic K loop below is INSTRUCTION ISSUE, not the LDS array (profiles/r06_lds_counters.txt: no bank
+        // conflicts, the array 15-30 % busy): one wave per SIMD issues in order, a 16x16x32 MFMA holds the vector issue port for
+        // 8 of its 16 cycles, and hipcc placed the ~45 address / bookkeeping / read instructions of a K-step in blocks of up to
+        // 22 between two MFMAs -- the matrix pipe idles behind each block.  With W known at compile time a K-step needs 16
+        // ds_read_b128 with immediate offsets + 2 VALU + ~4 SALU, and they are pinned two MFMAs apart:
+        //   pb[ic][k][b] = halo buffer + pixel base of fragment b for tap COLUMN ic (the swizzle key depends on the column
+        //                  read), K-half k (address bit 6); the tap's row / column shift (tdy * (W + 2) + tdx) * 128 is the
+        //                  instruction's offset field; where the key has a row-parity bit (W < 8) it IS address bit 6, so an odd
+        //                  tap row swaps the two K-half registers (compile time)
+        //   wv[k]        = weight ring base + this lane's row / piece, K-half k; + stage * 8 KB (one v_add per K-half)
+        // pb follows the halo double buffer by +- HBUF * 2 per chunk, column ic switched right after its last read of the chunk.
+        if constexpr (WC > 0) {
+            constexpr int Wpc = WC + 2;
+            constexpr bool PAR = WC < 8;
+            constexpr unsigned HB2 = HBUF * 2u;
+            const int nchunks_ = nchunks;
+            auto rd_a = [&](bf16x8 (&af)[NI], unsigned base) __attribute__((always_inline)) {
+#pragma unroll
+                for (int a = 0; a < NI; ++a) af[a] = *(frag_t)(size_t)(base + a * 2048u);
+            };
+            auto rd_b = [&](bf16x8 (&bfm)[MI], auto icc, auto kc, auto immc) __attribute__((always_inline)) {
+                constexpr int ic = decltype(icc)::value, k = decltype(kc)::value;
+                constexpr unsigned imm = decltype(immc)::value;
+#pragma unroll
+                for (int b = 0; b < MI; ++b) bfm[b] = *(frag_t)(size_t)(pb[ic][k][b] + imm);
+            };
+            // one region: Q = NI * MI MFMAs with R = NI + MI reads (and NV vector-ALU instructions) spread between them
+            auto pin = [&](auto nvc) __attribute__((always_inline)) {
+                constexpr int NV = decltype(nvc)::value;
+                constexpr int Q = NI * MI, R = NI + MI, PER = Q / R;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                    if (k < NV) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if constexpr (Q - PER * R > 0) __builtin_amdgcn_sched_group_barrier(0x008, Q - PER * R, 0);
+            };
+            // pixel-fragment-major MFMA order: the reads of a region are issued weights first, pixels last, so the first MFMAs of
+            // the next region must not be the ones that need the youngest read (each accumulator still sees the same K order)
+            auto mfma_set_b = [&](bf16x8 (&af)[NI], bf16x8 (&bfm)[MI]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int b = 0; b < MI; ++b)
+#pragma unroll
+                    for (int a = 0; a < NI; ++a)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+            };
+            auto tap_imm = [](int t) constexpr { const int ir = t / 3, ic = t % 3; return (unsigned)((((FLIP ? 2 - ir : ir)) * Wpc + (FLIP ? 2 - ic : ic)) * 128); };
+            auto tap_par = [](int t) constexpr { const int ir = t / 3; return PAR ? ((FLIP ? 2 - ir : ir) & 1) : 0; };
+            if (job == 0) PWS_STAMP(1);
+            __builtin_amdgcn_s_barrier();                            // the tile's first READY
+            if (job == 0) PWS_STAMP(2);
+#ifdef PWS_GEO_DUMMY
+            bf16x8 afd[NI], bfd[MI];
+            rd_a(afd, wv0); 
+#pragma unroll
+            for (int b = 0; b < MI; ++b) bfd[b] = afd[b % NI];
+#endif
+            rd_a(af0, wv0 + stage * (WSTAGE * 2u));
+            rd_b(bf0, std::integral_constant<int, 0>{}, std::integral_constant<int, tap_par(0)>{}, std::integral_constant<unsigned, tap_imm(0)>{});
+#pragma nounroll
+            for (int cc = 0; cc < nchunks_; ++cc) {
+                if (BST_EARLY && cc == nchunks_ - 1) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
+                if (RES_EARLY && res_pre && cc == nchunks_ - 1) conv_res_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, resf);
+                const unsigned hdelta = hbsel ? 0u - HB2 : HB2;          // to the other halo buffer
+                auto tap = [&](auto tc) __attribute__((always_inline)) {
+                    constexpr int t = decltype(tc)::value, ic = t % 3;
+                    constexpr int nt = (t + 1) % 9, nic = nt % 3;
+                    if (t != 0 || cc != 0) __builtin_amdgcn_s_barrier();         // READY_s: this step and the next have landed
+                    // region 1: K-half 1 of this step is requested while K-half 0 multiplies
+                    rd_a(af1, wv1 + stage * (WSTAGE * 2u));
+                    rd_b(bf1, std::integral_constant<int, ic>{}, std::integral_constant<int, 1 ^ tap_par(t)>{}, std::integral_constant<unsigned, tap_imm(t)>{});
+#ifdef PWS_GEO_DUMMY      // diagnostic: the reads are issued, nothing waits for them (the MFMAs multiply registers no read targets)
+                    mfma_set_b(afd, bfd);
+#else
+                    mfma_set_b(af0, bf0);
+#endif
+                    pin(std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    // region 2: K-half 0 of the NEXT step while K-half 1 multiplies; behind the chunk's last read of tap column ic its
+                    // bases move to the other halo buffer (t = 6, 7, 8: columns 0, 1, 2; the next chunk's tap 0 reads column 0)
+                    const unsigned nstage = stage + 1 == NS ? 0u : stage + 1;
+                    if constexpr (t >= 6) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+#pragma unroll
+                            for (int b = 0; b < MI; ++b) pb[ic][k][b] += hdelta;
+                    }
+                    rd_a(af0, wv0 + nstage * (WSTAGE * 2u));
+                    rd_b(bf0, std::integral_constant<int, nic>{}, std::integral_constant<int, tap_par(nt)>{}, std::integral_constant<unsigned, tap_imm(nt)>{});
+#ifdef PWS_GEO_DUMMY
+                    mfma_set_b(afd, bfd);
+#else
+                    mfma_set_b(af1, bf1);
+#endif
+                    pin(std::integral_constant<int, (t >= 6 ? 2 * MI + 1 : 1)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage = nstage;
+                };
+                tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{}); tap(std::integral_constant<int, 2>{});
+                tap(std::integral_constant<int, 3>{}); tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
+                tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{}); tap(std::integral_constant<int, 8>{});
+                hbsel ^= 1u;
+            }
+            gch += nchunks_;
+#ifdef PWS_GEO_DUMMY
+#pragma unroll
+            for (int a = 0; a < NI; ++a) { asm volatile("" ::"v"(af0[a]), "v"(af1[a])); }
+#pragma unroll
+            for (int b = 0; b < MI; ++b) { asm volatile("" ::"v"(bf0[b]), "v"(bf1[b])); }
+#endif
+        } else {
         const unsigned hb0 = lds0, hb1 = lds0 + HBUF * 2u;           // the two halo buffers
         unsigned hb = (gch & 1) ? hb1 : hb0;
         // tap walk: one kernel ROW per iteration (rolled: fully unrolled, hipcc hoists the addresses of all nine taps out of the
@@ -511,11 +662,6 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
         // LAST chunk -- nine K-steps (~3 us) ahead of their use; requested behind the K loop (conv3x3_ws_kernel: its 256-pixel
         // tile has no registers for them) they cost the data gradients ~2 us of exposed memory latency per tile (in-step stamps:
         // 8,400 cycles of epilogue against 3,700 for the plain forward store).  Mode 8 has no registers left for it.
-        BstFrag<NI, VPD_BST_MB(MI)> bst;
-        // eval with a residual (mode 3): its fragments likewise, where the registers are there (not on the eight-wave tile)
-        constexpr bool RES_EARLY = PIPE && EPM == 3 && PWS_RES_EARLY;
-        ResFrag<NI, MI> resf;
-        const bool res_pre = RES_EARLY && p.res != nullptr;
 #pragma nounroll
         for (int row = 0; row < nrows; ++row) {
             if (BST_EARLY && row == nrows - (MI <= 2 ? 3 : PWS_BST_ROWS4)) conv_bst_prefetch<BM, BN, WM, WN>(p, mtile, n0, geo, bst);
@@ -565,6 +711,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             hb = nhb; tdy = ntdy; S0 = nS0; P = nP;
             if (wrap) { ir = 0; ++gch; } else ++ir;
         }
+        }      // (generic K loop)
         if (job == 0) PWS_STAMP(3);                                  // first tile's K loop done
         // ---- epilogue of the tile (the loaders are already filling the ring and the other halo buffer for the next one) ----
         if (VPD_ABL(p, 8)) continue;
@@ -635,8 +782,14 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
 #endif
 }
 
-template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE>
+template <int BM, int BN, int HROWS, int NS, int EPM, int NMW, bool PIPE, int WC = 0, bool FLIP = false>
 __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_kernel(const ConvParams p, const HaloGeom g,
                                                                                    const PwsGrid sg) {
-    pws_body<BM, BN, HROWS, NS, EPM, NMW, PIPE>(p, g, sg);
+    pws_body<BM, BN, HROWS, NS, EPM, NMW, PIPE, WC, FLIP>(p, g, sg);
 }
+
+// conv_pws_geo.hip: the compile-time-geometry instantiations (W = 16 / 8 on 256 x 64 tiles, W = 4 on 128 x 64 tiles; forward taps or
+// the data gradient's mirrored ones).  Returns false when (tile, W, taps, epilogue mode) has no such instantiation: the caller
+// launches the generic kernel.
+bool vpd_launch_pws_geo(int bm, int bn, int hrows, int ns, const ConvParams& q, const HaloGeom& g, const PwsGrid& sg, dim3 grid,
+                        dim3 block, size_t lds, hipStream_t stream);

@@ -675,7 +675,7 @@ int stream_cu_count() {
 
 // tile shape for (Kc, Co): wide channel tiles take 64-pixel tiles (64 accumulator registers beside the prefetched fragments)
 void stream_shape(int Kc, int Co, int* bm, int* bn) {
-    int n = Co >= 256 ? 256 : Co;
+    int n = Co % 256 == 0 ? 256 : Co % 128 == 0 ? 128 : 64;      // (only the instantiated widths: Co = 192 runs on 64-wide tiles)
     if (Kc == 256 && n > 128) n = 128;      // 64 KB of weights + the ring
     *bn = n;
     // 256 input channels: 32 KB per 64 pixels -- small tiles keep 96 KB per CU in flight (128-pixel tiles with two stages

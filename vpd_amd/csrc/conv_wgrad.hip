@@ -809,7 +809,11 @@ bool vpd_wgrad_group_eligible(const WgradParams& p) {
 // ps[i].slab must point to vpd_wgrad_group_slab_floats() floats of its own (ignored when that is 0)
 hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stream) {
     if (n < 1 || n > WG_GROUP_MAX) return hipErrorInvalidValue;
+#ifdef VPD_ENABLE_ABLATE
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+#else
+    constexpr int ablate = 0;
+#endif
     WgGroup grp = {};
     WgReduceGroup red = {};
     grp.nprob = n;
@@ -863,7 +867,11 @@ hipError_t vpd_launch_wgrad_group(const WgradParams* ps, int n, hipStream_t stre
 hipError_t vpd_launch_wgrad(const WgradParams& p0, hipStream_t stream) {
     if (p0.Kc % 64 != 0 || p0.Co % 64 != 0 || p0.M <= 0) return hipErrorInvalidValue;
     WgradParams p = p0;
+#ifdef VPD_ENABLE_ABLATE
     static const int ablate = getenv("VPD_ABLATE") ? atoi(getenv("VPD_ABLATE")) : 0;
+#else
+    constexpr int ablate = 0;
+#endif
     p.ablate = ablate;
     int tr_stem;
     if (wg_stem_eligible(p, &tr_stem)) {

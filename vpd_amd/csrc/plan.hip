@@ -1,5 +1,5 @@
-// Network plan: owns the static description of the student (ResNet-18/34
-// BasicBlock encoder + optional motion MLP), the workspace layout, and the
+// Network plan: owns the static description of the student (ResNet-18/34 BasicBlock or
+// ResNet-50/101 / wide Bottleneck encoder + optional motion MLP), the workspace layout, and the
 // launch sequences for eval forward, train forward+loss, backward, and the
 // weight re-pack.  Exposes the C ABI of include/vpd_hip.h.
 #include <hip/hip_runtime.h>
@@ -32,7 +32,7 @@ static int fail(const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 extern "C" const char* vpd_last_error(void) { return g_err.c_str(); }
-extern "C" int vpd_abi_version(void) { return 1; }
+extern "C" int vpd_abi_version(void) { return 2; }      // 2: round 5/6 entry points (vpd_op_conv2d_ep, train flag word, 8 timing classes)
 
 namespace {
 
@@ -1878,9 +1878,9 @@ extern "C" int vpd_plan_read_timing(vpd_plan_t* p, double* out, int nclasses) {
         float ms = 0.f;
         HCHECK(hipEventElapsedTime(&ms, t.a, t.b));
         const int cls = t.cls;
+        p->ev_pool.push_back(t.a); p->ev_pool.push_back(t.b);
         if (cls < 0 || cls >= nclasses) continue;
         out[3 * cls + 0] += 1.0; out[3 * cls + 1] += ms; out[3 * cls + 2] += t.flops;
-        p->ev_pool.push_back(t.a); p->ev_pool.push_back(t.b);
     }
     p->timed.clear();
     return 0;
