@@ -1392,12 +1392,7 @@ hipError_t vpd_launch_bn_bwd_fused2(const BnBwdParams& p0, const BnFusedBwd& fA,
                                     const float* meanB, const float* rstdB, bf16_t* dzB, hipStream_t s) {
     BnBwdParams p = p0;
     if (!p.act) return hipErrorInvalidValue;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
-    }
+    const int ncu = vpd_cu_budget();
     const int cv = p.C / 8, ppi = 1024 / cv;
     int G = ncu;
     int ppb = (p.M + G - 1) / G;
@@ -1432,12 +1427,7 @@ bool vpd_bn_bwd_fused_ok(int M, int C, bool mask_act, bool write_g) {
 
 hipError_t vpd_launch_bn_bwd_fused(const BnBwdParams& p0, const BnFusedBwd& f0, hipStream_t s) {
     BnBwdParams p = p0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
-    }
+    const int ncu = vpd_cu_budget();
     const int cv = p.C / 8, ppi = 1024 / cv;
     int G = ncu;                                        // one 1024-thread block per CU: the whole grid is resident
     {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -13,6 +14,27 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VPD_WAVE 64
+
+// CU budget of the persistent grids (round 6): the device's CU count minus VPD_RESERVE_CUS (default 0) -- every kernel that sizes its
+// grid by "one block per CU" (conv3x3_pws / c64 / stem / streaming 1x1 kernels, the persistent weight-gradient launch, the grid-barrier
+// BatchNorm launches) asks here, so that R CUs stay free of LDS-heavy blocks for whatever co-runs with the step (RCCL's kernels under
+// data parallelism).  vpd_cu_budget_override(): a launch sequence's own budget (the weight-gradient side stream).
+inline int& vpd_cu_budget_override() { static thread_local int v = 0; return v; }
+inline int vpd_cu_budget() {
+    if (vpd_cu_budget_override() > 0) return vpd_cu_budget_override();
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1) cu = 256;
+        const char* r = getenv("VPD_RESERVE_CUS");
+        int res = r ? atoi(r) : 0;
+        if (res < 0) res = 0;
+        res = (res + 7) & ~7;                       // whole octets: one CU of every XCD per 8
+        if (cu - res < 8) res = cu > 8 ? cu - 8 : 0;
+        return cu - res;
+    }();
+    return n;
+}
 // Diagnostics (tools/bench_conv.py, VPD_ABLATE env) are compiled in only with -DVPD_ENABLE_ABLATE: even never-taken
 // branches cost registers and issue slots in the hot loops.
 #ifdef VPD_ENABLE_ABLATE

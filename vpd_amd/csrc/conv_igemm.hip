@@ -870,7 +870,8 @@ static bool c64x2_geom(const ConvParams& p, HaloGeom* g) {
 }
 static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 255) / 256;
-    int grid = ntiles < 256 ? ntiles : 256;
+    const int ncu = vpd_cu_budget();
+    int grid = ntiles < ncu ? ntiles : ncu;
     static const int contig = getenv("VPD_C64_CONTIG") ? atoi(getenv("VPD_C64_CONTIG")) : 1;
     const int per = contig ? (ntiles + grid - 1) / grid : 0;
     if (per > 0) grid = (ntiles + per - 1) / per;
@@ -888,7 +889,8 @@ static hipError_t launch_c64x2(const ConvParams& p, const HaloGeom& g, hipStream
 template <int HROWS>
 static hipError_t launch_c64(const ConvParams& p, const HaloGeom& g, hipStream_t stream) {
     const int ntiles = (p.M + 127) / 128;
-    int grid = ntiles < 256 ? ntiles : 256;
+    const int ncu = vpd_cu_budget();
+    int grid = ntiles < ncu ? ntiles : ncu;
     // consecutive tiles per block (VPD_C64_CONTIG=0: strided); the grid shrinks to the blocks that get tiles
     static const int contig = getenv("VPD_C64_CONTIG") ? atoi(getenv("VPD_C64_CONTIG")) : 1;
     const int per = contig ? (ntiles + grid - 1) / grid : 0;
@@ -1201,7 +1203,8 @@ static bool stem_eligible(const ConvParams& p, int* TR) {
 
 static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
     const int ntiles = p.M / 128;
-    const int grid = p.pool_y ? (p.N < 256 ? p.N : 256) : (ntiles < 256 ? ntiles : 256);      // pooled: whole images per block
+    const int ncu = vpd_cu_budget();
+    const int grid = p.pool_y ? (p.N < ncu ? p.N : ncu) : (ntiles < ncu ? ntiles : ncu);      // pooled: whole images per block
     // statistics scratch (2 KiB) + the coalesced-store staging of the four MFMA waves (4 x 32 pixels x 136 B; pooled mode:
     // two parked tiles of 128 pixels x 144 B + two carried rows of 32 x 128 B)
     const size_t lds = ((size_t)7 * 64 + 2 * 160) * 64 * sizeof(bf16_t) + 2048 +
@@ -1234,15 +1237,9 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 #define PWS_NS_C6 5
 #endif
 int pws_cu_count() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 1;
-        // VPD_PWS_BLOCKS: pretend the device has this many CUs (tests: many tiles per block on small problems)
-        if (getenv("VPD_PWS_BLOCKS") && atoi(getenv("VPD_PWS_BLOCKS")) > 0) ncu = atoi(getenv("VPD_PWS_BLOCKS"));
-    }
-    return ncu;
+    // VPD_PWS_BLOCKS: pretend the device has this many CUs (tests: many tiles per block on small problems)
+    static const int forced = getenv("VPD_PWS_BLOCKS") && atoi(getenv("VPD_PWS_BLOCKS")) > 0 ? atoi(getenv("VPD_PWS_BLOCKS")) : 0;
+    return forced ? forced : vpd_cu_budget();
 }
 static bool pws_enabled(const ConvParams& p) {
     static const int on = getenv("VPD_PWS") ? atoi(getenv("VPD_PWS")) : 1;

@@ -661,17 +661,7 @@ __global__ __launch_bounds__(768) void conv1x1_bn2_stream_kernel(const ConvParam
     }
 }
 
-int stream_cu_count() {
-    static const int n = [] {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t pr;
-            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cu = pr.multiProcessorCount;
-        }
-        return cu;
-    }();
-    return n;
-}
+int stream_cu_count() { return vpd_cu_budget(); }
 
 // tile shape for (Kc, Co): wide channel tiles take 64-pixel tiles (64 accumulator registers beside the prefetched fragments)
 void stream_shape(int Kc, int Co, int* bm, int* bn) {

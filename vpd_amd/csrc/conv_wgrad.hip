@@ -1536,7 +1536,7 @@ size_t vpd_wgrad128_table_bytes() { return (size_t)1 << 17; }       // device ta
 // null) keeps the schedule between calls with the same shapes; `dev_table` is vpd_wgrad128_table_bytes() of device
 // memory owned by the caller for THIS group (re-uploaded, stream-ordered, only when the shapes change).
 struct Wg2Cache {
-    int n = 0;
+    int n = 0, ncu = 0;
     int sig[WG2_MAX][4];
     const void* uploaded_to = nullptr;
     Wg2Schedule sch;
@@ -1546,12 +1546,7 @@ void vpd_wgrad128_cache_free(void* c) { delete static_cast<Wg2Cache*>(c); }
 
 hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v, void* dev_table, hipStream_t stream) {
     if (n < 1 || n > WG2_MAX || !dev_table) return hipErrorInvalidValue;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 8) ncu = 256;
-    }
+    const int ncu = vpd_cu_budget();
     Wg2Group grp = {};
     WgReduceGroup red = {};
     grp.nprob = n;
@@ -1569,12 +1564,12 @@ hipError_t vpd_launch_wgrad128_group(const WgradParams* ps, int n, void* cache_v
     }
     Wg2Cache local;
     Wg2Cache* c = cache_v ? static_cast<Wg2Cache*>(cache_v) : &local;
-    bool same = c->n == n && c->uploaded_to == dev_table;
+    bool same = c->n == n && c->uploaded_to == dev_table && c->ncu == ncu;
     for (int i = 0; i < n && same; ++i)
         same = c->sig[i][0] == ps[i].M && c->sig[i][1] == ps[i].Co && c->sig[i][2] == ps[i].Kc && c->sig[i][3] == grp.g[i].NHP + 1000 * kinds[i];
     if (!same) {
         wg2_build(ps, grp.g, n, ncu, &c->sch, kinds);
-        c->n = n;
+        c->n = n; c->ncu = ncu;
         for (int i = 0; i < n; ++i) { c->sig[i][0] = ps[i].M; c->sig[i][1] = ps[i].Co; c->sig[i][2] = ps[i].Kc; c->sig[i][3] = grp.g[i].NHP + 1000 * kinds[i]; }
         const size_t tb = c->sch.tasks.size() * sizeof(int), bb = c->sch.blk_begin.size() * sizeof(int);
         if (tb + bb + 64 > vpd_wgrad128_table_bytes()) return hipErrorInvalidValue;

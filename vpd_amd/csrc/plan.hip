@@ -752,15 +752,7 @@ hipError_t run_bn_finalize(const Ctx& c, const ConvInfo& cv, float* bn_running) 
 }
 
 // data-gradient of a conv: dz (padded, border 1) -> dx (dense [n][Hin][Win][Ci])
-int device_cu_count() {
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 1;
-    }
-    return ncu;
-}
+int device_cu_count() { return vpd_cu_budget(); }
 
 // stride-1 data-gradient launch descriptor
 ConvParams conv_dgrad_s1_params(const Ctx& c, const ConvInfo& cv, const bf16_t* dz, bf16_t* dx, int accumulate) {
@@ -1434,7 +1426,9 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
         else LCHECK(vpd_launch_avgpool_bwd(c.f32(p->dpooled_off), S.H, S.W, p->feat, n, G[gi], s));
     }
     // grouped mode: eligible convs are queued and launched together when the stage's backward is done
-    // (running weight gradients or their slab sums on a second stream was measured 6 % slower: DESIGN.md)
+    // (running weight gradients or their slab sums on a second stream was measured 6 % slower in round 2 and, with the persistent
+    //  kernels, 1.4 % slower in round 6; confined to a CU partition 40-50 % slower: profiles/r06_ab_wgrad_overlap.txt,
+    //  tools/probe/wg_overlap.patch)
     const bool grouped = p->wg_group;
     struct Pending { const ConvInfo* cv; const bf16_t* dz; const bf16_t* x; };
     std::vector<Pending> pending;
