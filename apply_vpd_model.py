@@ -24,10 +24,13 @@ def get_args():
     parser.add_argument('--flow_img', type=str)
     parser.add_argument('--host_fp32', action='store_true',
                         help='(this build) hand fp32 views across like the reference instead of u8 frames + device-side views')
+    parser.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
+                        help='(this build) element type of the HIP forward: bf16 (default) or fp16 -- the precision the reference '
+                             'trains in on a GPU (fp16 autocast), same MFMA rate, 8x finer rounding')
     return parser.parse_args()
 
 
-def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip, host_fp32=False):
+def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip, host_fp32=False, dtype='bf16'):
     device = 'cuda'
     model_params = load_json(os.path.join(model_dir, 'config.json'))
     emb_dim = model_params['emb_dim']
@@ -58,7 +61,7 @@ def main(dataset, model_dir, out_dir, model_epoch, flow_img, jitter, no_flip, ho
 
     model_name = 'best_epoch' if model_epoch is None else 'epoch{:04d}'.format(model_epoch)
     print('Model name:', model_name)
-    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, use_flow, device)
+    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, use_flow, device, dtype=dtype)
     encoder.load_state_dict(torch.load(os.path.join(model_dir, '{}.encoder.pt'.format(model_name)),
                                        map_location=device))
     encoder.to(device)

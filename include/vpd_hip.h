@@ -31,6 +31,10 @@ typedef struct vpd_plan vpd_plan_t;
 
 const char* vpd_last_error(void);
 int vpd_abi_version(void);
+/* Element type of activations / packed weights / activation gradients this library was built with: "bf16" (libvpdhip.so: training and
+ * inference) or "fp16" (libvpdhip_f16.so, the same sources with -DVPD_ELEM_F16: inference only -- vpd_plan_create refuses train != 0).
+ * fp16 is the reference's own GPU precision (torch.cuda.amp.autocast + GradScaler: train_vpd_model.py:79,105; models/util.py:55-57). */
+const char* vpd_elem_dtype(void);
 
 /* Network + workspace description for one (arch, input, head) configuration.
  * Replaces the module construction of RGBF_EmbeddingModel.__init__ (models/rgb.py:46-66),

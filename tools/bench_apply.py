@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--crops", type=int, default=0, help="full job of this many crops (2 views per frame) with real pickles")
     ap.add_argument("--out_dir", default="/tmp/vpd_apply_out")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="element type of the HIP forward (apply_vpd_model.py --dtype)")
     args = ap.parse_args()
     from vpd_amd.apply import StreamingWriter, embed_dataset
     from vpd_amd.augment import CropAugmenter
@@ -43,7 +44,7 @@ def main():
 
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    enc = RGBF_EmbeddingModel(ARCH, EMB_DIM, True, dev)
+    enc = RGBF_EmbeddingModel(ARCH, EMB_DIM, True, dev, dtype=args.dtype)
     enc.reset_parameters(seed=0)
     enc.eval()
     eng = enc.engine

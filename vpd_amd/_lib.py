@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VPD_LIB_PATH: A/B another build of the same ABI on the same GPU (devices differ by several % in clocks)
 LIB_PATH = os.environ.get("VPD_LIB_PATH") or os.path.join(_HERE, "libvpdhip.so")
+# the same sources built with fp16 elements (vpd_amd/csrc/Makefile, common.h "Element type"): inference only
+LIB_PATH_F16 = os.environ.get("VPD_LIB_PATH_F16") or os.path.join(_HERE, "libvpdhip_f16.so")
 ABI_VERSION = 2
 
 c_int_p = C.POINTER(C.c_int)
@@ -19,6 +21,7 @@ vp = C.c_void_p
 SIGNATURES = {
     "vpd_last_error": (C.c_char_p, []),
     "vpd_abi_version": (C.c_int, []),
+    "vpd_elem_dtype": (C.c_char_p, []),
     "vpd_plan_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(vp)]),
     "vpd_plan_destroy": (None, [vp]),
@@ -70,42 +73,48 @@ SIGNATURES = {
                                            C.POINTER(C.c_double)]),
 }
 
-_lib = None
+_libs = {}
 
 
 class VpdHipError(RuntimeError):
     pass
 
 
-def lib():
-    """Load libvpdhip.so (once).  Raises -- never falls back -- when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
+def lib(dtype="bf16"):
+    """Load libvpdhip.so (dtype "bf16": training and inference) or libvpdhip_f16.so ("fp16": inference), once each.
+    Raises -- never falls back -- when the library is absent, lacks a symbol or was built for another element type."""
+    if dtype in _libs:
+        return _libs[dtype]
+    if dtype not in ("bf16", "fp16"):
+        raise VpdHipError("unknown element type %r (bf16 | fp16)" % (dtype,))
+    path = LIB_PATH if dtype == "bf16" else LIB_PATH_F16
+    name = os.path.basename(path)
+    if not os.path.isfile(path):
         raise VpdHipError(
-            "libvpdhip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C vpd_amd/csrc`.  vpd_amd has no PyTorch/CPU fallback." % LIB_PATH)
-    h = C.CDLL(LIB_PATH)
+            "%s not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C vpd_amd/csrc`.  vpd_amd has no PyTorch/CPU fallback." % (name, path))
+    h = C.CDLL(path)
     # VPD_LIB_PATH (same-box A/B against an OLDER build of the library, tools/build_head_lib.sh): the operator-level test entry
     # points that build does not have yet are skipped; the in-tree library must export every declared symbol
-    ab_build = "VPD_LIB_PATH" in os.environ
-    for name, (res, args) in SIGNATURES.items():
+    ab_build = "VPD_LIB_PATH" in os.environ and dtype == "bf16"
+    for sym, (res, args) in SIGNATURES.items():
         try:
-            fn = getattr(h, name)
+            fn = getattr(h, sym)
         except AttributeError as e:
-            if ab_build and name.startswith("vpd_op_"):
+            if ab_build and (sym.startswith("vpd_op_") or sym == "vpd_elem_dtype"):
                 continue
-            raise VpdHipError("libvpdhip.so lacks symbol %s declared in include/vpd_hip.h" % name) from e
+            raise VpdHipError("%s lacks symbol %s declared in include/vpd_hip.h" % (name, sym)) from e
         fn.restype = res
         fn.argtypes = args
     if h.vpd_abi_version() != ABI_VERSION:
-        raise VpdHipError("libvpdhip.so ABI version %d != expected %d" % (h.vpd_abi_version(), ABI_VERSION))
-    _lib = h
+        raise VpdHipError("%s ABI version %d != expected %d" % (name, h.vpd_abi_version(), ABI_VERSION))
+    if hasattr(h, "vpd_elem_dtype") and h.vpd_elem_dtype().decode() != dtype:
+        raise VpdHipError("%s was built with %s elements, %s asked for" % (path, h.vpd_elem_dtype().decode(), dtype))
+    _libs[dtype] = h
     return h
 
 
-def check(rc, what=""):
+def check(rc, what="", dtype="bf16"):
     if rc != 0:
-        msg = lib().vpd_last_error()
+        msg = lib(dtype).vpd_last_error()
         raise VpdHipError("%s failed: %s" % (what or "libvpdhip call", msg.decode() if msg else "unknown error"))

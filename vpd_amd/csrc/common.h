@@ -5,9 +5,24 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// Element type of activations / packed weights / activation gradients.  The library is built twice from these sources
+// (vpd_amd/csrc/Makefile): libvpdhip.so with bf16 elements (training and inference), libvpdhip_f16.so with -DVPD_ELEM_F16 = IEEE fp16
+// elements for INFERENCE (apply_vpd_model.py --dtype fp16): the reference's own GPU precision (fp16 autocast, train_vpd_model.py:79),
+// the same MFMA rate (v_mfma_f32_16x16x32_f16), 8x finer rounding (11 significant bits against 8).  The type NAMES stay bf16_t /
+// bf16x8 in both builds; every conversion goes through bf2f / f2bf / pack2bf below and every matrix instruction through VPD_MFMA16.
+#ifdef VPD_ELEM_F16
+typedef _Float16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+#define VPD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+#define VPD_ELEM_NAME "fp16"
+#else
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define VPD_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+#define VPD_ELEM_NAME "bf16"
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -48,14 +63,22 @@ inline int vpd_cu_budget() {
 #define VPD_FUSED_ROWS 4
 
 static __device__ __forceinline__ float bf2f(unsigned short u) {
+#ifdef VPD_ELEM_F16
+    return (float)__builtin_bit_cast(_Float16, u);
+#else
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
+#endif
 }
 static __device__ __forceinline__ unsigned short f2bf(float f) {
     // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
     return __builtin_bit_cast(unsigned short, (bf16_t)f);
 }
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef VPD_ELEM_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;      // (v_cvt_pk_f16_f32: RNE)
+#else
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#endif
 static __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     // ONE v_cvt_pk_bf16_f32 for the pair (RNE, NaN stays NaN).  Written as two scalar casts + shift + or, hipcc emitted two
     // half-empty conversions, a shift and an or per dword: four instructions where one does -- in every epilogue and BatchNorm pass

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p0)
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
         }
         if (s + 1 < nsteps) store_step(buf ^ 1);
         __syncthreads();
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvParams p, c
                 for (int a = 0; a < NI; ++a)
 #pragma unroll
                     for (int b = 0; b < MI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
             }
         }
         if (!HALO2 && cc + 1 < nchunks) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__((NMW + 4) * 64, WPS) void conv3x3_ws_kernel(const C
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
         }
     };
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_persistent_kernel(const ConvP
             for (int st = 0; st < 18; ++st) {
                 const int cur = st & 1, nxt = cur ^ 1;
                 const bool more = st + 1 < 18;
-#define C64_MFMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][a], bfm[cur][b], acc[a][b], 0, 0, 0)
+#define C64_MFMA(a, b) acc[a][b] = VPD_MFMA16(af[cur][a], bfm[cur][b], acc[a][b])
                 // source order pinned by scheduling barriers: the next step's reads leave in pairs behind the first three MFMAs
                 C64_MFMA(0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(768) void conv3x3_c64x2_persistent_kernel(const Con
                 for (int a = 0; a < NI; ++a)
 #pragma unroll
                     for (int b = 0; b < MI; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
             }
         }
         // this group's 128 pixels are output tile 2t + grp of the 128-pixel tiling
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(512) void conv_stem_persistent_kernel(const ConvPar
         for (int st = 0; st < 14; ++st) {
             const int cur = st & 1, nxt = cur ^ 1;
             const bool more = st + 1 < 14;
-#define STEM_MFMA(a, b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[cur][a], bfm[cur][b], acc[a][b], 0, 0, 0)
+#define STEM_MFMA(a, b) acc[a][b] = VPD_MFMA16(af[cur][a], bfm[cur][b], acc[a][b])
             STEM_MFMA(0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (more) { ldone(st + 1, nxt, 0); ldone(st + 1, nxt, 1); }
@@ -1512,7 +1512,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p0) {
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
         }
     }
     __builtin_amdgcn_s_barrier();                                 // END

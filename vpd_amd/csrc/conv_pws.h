@@ -503,7 +503,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
         };
         // Interleave of one half-step region: its MFMAs (NI * MI) with the address arithmetic and the NI + MI fragment reads of
         // the NEXT half-step, which the source places in front of them.  Left to itself hipcc issues address math, reads and
@@ -570,7 +570,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
                 for (int b = 0; b < MI; ++b)
 #pragma unroll
                     for (int a = 0; a < NI; ++a)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
             };
             auto tap_imm = [](int t) constexpr { const int ir = t / 3, ic = t % 3; return (unsigned)((((FLIP ? 2 - ir : ir)) * Wpc + (FLIP ? 2 - ic : ic)) * 128); };
             auto tap_par = [](int t) constexpr { const int ir = t / 3; return PAR ? ((FLIP ? 2 - ir : ir) & 1) : 0; };

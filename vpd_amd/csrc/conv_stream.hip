@@ -137,7 +137,7 @@ static __device__ __forceinline__ void stream_mma(const bf16_t* sW, const bf16_t
             for (int a = 0; a < NI; ++a)
 #pragma unroll
                 for (int b = 0; b < MI; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfm[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = VPD_MFMA16(af[a], bfm[b], acc[a][b]);
         }
 }
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradParams p)
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx8[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = VPD_MFMA16(az[a], bx8[b], acc[a][b]);
         if (ch + 1 < chunk_end) store_chunk(buf ^ 1);
         __syncthreads();
     }
@@ -281,7 +281,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[ks][a], bx[ks][t], acc[t][a], 0, 0, 0);
+                        acc[t][a] = VPD_MFMA16(az[ks][a], bx[ks][t], acc[t][a]);
             continue;
         }
 #pragma unroll
@@ -296,7 +296,7 @@ static __device__ __forceinline__ void wgrad_mfma_half(const WgradParams& p, con
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[t], acc[t][a], 0, 0, 0);
+                    acc[t][a] = VPD_MFMA16(az[a], bx[t], acc[t][a]);
         }
     }
 
@@ -555,7 +555,7 @@ static __device__ __forceinline__ void wgrad_stem_half(const WgradParams& p, con
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    acc[t][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[t], acc[t][a], 0, 0, 0);
+                    acc[t][a] = VPD_MFMA16(az[a], bx[t], acc[t][a]);
         }
     }
     // acc[t][a][j] = partial dW[row R0+t][co a*16 + 4*gq + j][16*ctile + i16]
@@ -1146,7 +1146,7 @@ static __device__ __forceinline__ void wg2_task(const WgradParams& p, const WgHa
                     for (int u = 0; u < 3; ++u)
 #pragma unroll
                         for (int a = 0; a < 4; ++a)
-                            acc[tg * 3 + u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[tg * 3 + u][a], 0, 0, 0);
+                            acc[tg * 3 + u][a] = VPD_MFMA16(az[a], bx[u], acc[tg * 3 + u][a]);
                 }
             }
         }
@@ -1310,7 +1310,7 @@ static __device__ __forceinline__ void wg2_task_1x1(const WgradParams& p, const 
                 for (int u = 0; u < NB; ++u)
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        acc[u][zb * 4 + a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(az[a], bx[u], acc[u][zb * 4 + a], 0, 0, 0);
+                        acc[u][zb * 4 + a] = VPD_MFMA16(az[a], bx[u], acc[u][zb * 4 + a]);
             }
         }
     }

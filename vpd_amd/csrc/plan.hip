@@ -32,6 +32,7 @@ static int fail(const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 extern "C" const char* vpd_last_error(void) { return g_err.c_str(); }
+extern "C" const char* vpd_elem_dtype(void) { return VPD_ELEM_NAME; }      // "bf16" (libvpdhip.so) or "fp16" (libvpdhip_f16.so)
 extern "C" int vpd_abi_version(void) { return 2; }      // 2: round 5/6 entry points (vpd_op_conv2d_ep, train flag word, 8 timing classes)
 
 namespace {
@@ -223,6 +224,11 @@ TapSet conv_taps_fwd(const ConvInfo& c) {
 // ---------------------------------------------------------------------------
 extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
                                int max_batch, int train, vpd_plan_t** out) {
+#ifdef VPD_ELEM_F16
+    // fp16 elements: inference only.  A train-mode fp16 path needs the reference's loss scaling (GradScaler, models/util.py:55-57):
+    // activation gradients of a sum-MSE over 256 crops reach 1e-7..1e-8 at the stem, below fp16's 6e-8 subnormal step
+    if (train) return fail("libvpdhip_f16.so is inference only (train plans need libvpdhip.so: bf16 elements)");
+#endif
     if (!arch || !out) return fail("null argument");
     std::vector<int> layers;
     int bottleneck = 0, base_width = 64;          // reference models/module.py:17-32 (ENCODER_ARCH)

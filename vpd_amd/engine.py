@@ -62,7 +62,8 @@ class _Plan:
     """One vpd_plan_t + its workspace for a fixed (H, W, max_batch, train, motion)."""
 
     def __init__(self, eng, h, w, max_batch, train, motion):
-        L = lib()
+        L = self.L = eng.L
+        check = self.check = eng.check
         self.h, self.w, self.max_batch, self.train, self.motion = h, w, max_batch, train, motion
         handle = C.c_void_p()
         # data parallel, VPD_DDP_EARLY_BUCKET0=1: bucket 0 (fc + layer4, 61 % of the gradient bytes) is handed to the reducer at the
@@ -114,7 +115,7 @@ class _Plan:
             self.small_idx = torch.cat([torch.arange(a, a + n_, dtype=torch.int64) for a, n_ in small]).to(eng.device)
 
     def bn_table(self):
-        L = lib()
+        L, check = self.L, self.check
         out = []
         ch, rm, rv = C.c_int(), C.c_longlong(), C.c_longlong()
         for i in range(L.vpd_plan_num_bn(self.handle)):
@@ -124,7 +125,7 @@ class _Plan:
 
     def close(self):
         if self.handle:
-            lib().vpd_plan_destroy(self.handle)
+            self.L.vpd_plan_destroy(self.handle)
             self.handle = None
         # whoever still holds this _Plan (apply's graph table, a reducer's last plan) must not pin its workspace
         self.workspace, self.scratch_views, self.small_idx = None, [], None
@@ -140,11 +141,15 @@ class StudentEngine:
     """Flat fp32 parameter / gradient / optimizer-state buffers in the
     reference's state_dict order and layout, plus lazily created plans."""
 
-    def __init__(self, arch, c_in, emb_dim, device="cuda"):
+    def __init__(self, arch, c_in, emb_dim, device="cuda", dtype="bf16"):
         if not torch.cuda.is_available():
             raise RuntimeError("vpd_amd needs a ROCm GPU (MI355X): torch.cuda.is_available() is False; "
                                "there is no CPU fallback for the student path")
-        lib()   # fail loudly right here if the HIP library is missing
+        # dtype: element type of activations / packed weights -- "bf16" (libvpdhip.so: training and inference) or "fp16"
+        # (libvpdhip_f16.so: inference only; the reference's own GPU precision, train_vpd_model.py:79)
+        self.dtype = dtype
+        self.L = lib(dtype)   # fail loudly right here if the HIP library is missing
+        self.check = lambda rc, what="": check(rc, what, dtype)
         self.arch, self.c_in, self.emb_dim = arch, int(c_in), int(emb_dim)
         self.device = torch.device(device)
         self.enc_names, self.bn_names = encoder_param_names(arch)
@@ -197,8 +202,8 @@ class StudentEngine:
 
     def materialize_grads(self):
         pl = self._step_plan
-        if pl is not None and pl.handle and lib().vpd_plan_grads_pending(pl.handle):
-            check(lib().vpd_plan_materialize_grads(pl.handle, _ptr(self._grads), _ptr(pl.workspace), self._stream()),
+        if pl is not None and pl.handle and self.L.vpd_plan_grads_pending(pl.handle):
+            self.check(self.L.vpd_plan_materialize_grads(pl.handle, _ptr(self._grads), _ptr(pl.workspace), self._stream()),
                   "vpd_plan_materialize_grads")
 
     def _stream(self):
@@ -238,7 +243,7 @@ class StudentEngine:
         v = self.weights_version()
         if pl.packed_version != v:
             # the eval-mode BN fold is only needed by eval plans
-            check(lib().vpd_pack_weights(pl.handle, _ptr(self.params), None if pl.train else _ptr(self.bn_running),
+            self.check(self.L.vpd_pack_weights(pl.handle, _ptr(self.params), None if pl.train else _ptr(self.bn_running),
                                          _ptr(pl.workspace), self._stream()), "vpd_pack_weights")
             pl.packed_version = v
 
@@ -258,7 +263,7 @@ class StudentEngine:
         pl = self.plan(h, w, n, False, motion)
         self._ensure_packed(pl)
         emb = out if out is not None else torch.empty((n, self.emb_dim), dtype=torch.float32, device=self.device)
-        check(lib().vpd_forward_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(emb), _ptr(target),
+        self.check(self.L.vpd_forward_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(emb), _ptr(target),
                                      _ptr(self.loss_step) if target is not None else None,
                                      _ptr(self.loss_accum) if (target is not None and accumulate_loss) else None,
                                      _ptr(pl.workspace), self._stream()), "vpd_forward_eval")
@@ -271,7 +276,7 @@ class StudentEngine:
         n, h, w, _ = rgb_u8.shape
         pl = self.plan(img_dim, img_dim, n, train, motion)
         ms = (C.c_float * 6)(*mean_std6)
-        check(lib().vpd_plan_stage_crops(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), _ptr(mask_u8), _ptr(noise),
+        self.check(self.L.vpd_plan_stage_crops(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), _ptr(mask_u8), _ptr(noise),
                                          _ptr(params_dev), n, h, w, ms, float(noise_sd), _ptr(scratch),
                                          _ptr(pl.workspace), self._stream()), "vpd_plan_stage_crops")
         return pl
@@ -282,7 +287,7 @@ class StudentEngine:
         n, h, w, _ = rgb_u8.shape
         pl = self.plan(h, w, n * k_views, False, False)
         ms = (C.c_float * 6)(*mean_std6)
-        check(lib().vpd_plan_stage_views(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), n, k_views, h, w, ms,
+        self.check(self.L.vpd_plan_stage_views(pl.handle, _ptr(rgb_u8), _ptr(flow_u8), n, k_views, h, w, ms,
                                          _ptr(pl.workspace), self._stream()), "vpd_plan_stage_views")
         return pl
 
@@ -300,7 +305,7 @@ class StudentEngine:
             want = (n, self.emb_dim * (2 if motion else 1))
             assert tuple(target.shape) == want and target.dtype == torch.float32 and target.is_contiguous(), \
                 "target must be f32 %s" % (want,)
-        check(lib().vpd_forward_train(pl.handle, _ptr(self.params), _ptr(self.bn_running), _ptr(x), _ptr(target), n,
+        self.check(self.L.vpd_forward_train(pl.handle, _ptr(self.params), _ptr(self.bn_running), _ptr(x), _ptr(target), n,
                                       _ptr(emb), _ptr(self.loss_step),
                                       _ptr(self.loss_accum) if accumulate_loss else None,
                                       _ptr(pl.workspace), self._stream()), "vpd_forward_train")
@@ -325,8 +330,8 @@ class StudentEngine:
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
         if lazy:      # (with bucket events the reducer sums the scratch ranges: GradBucketReducer.reduce(plan, lazy=True))
-            check(lib().vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
-        check(lib().vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
+            self.check(self.L.vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
+        self.check(self.L.vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
                                  self._stream()), "vpd_backward")
         return pl
 
@@ -353,14 +358,14 @@ class StudentEngine:
             pl = None
         if pl is not None and pl.packed_version == self.weights_version() and os.environ.get("VPD_FUSED_ADAMW", "1") != "0":
             # the train plan of the last backward: AdamW + refresh of its packed bf16 weights in one pass
-            check(lib().vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self._grads), _ptr(self.adam_m),
+            self.check(self.L.vpd_plan_adamw_step(pl.handle, _ptr(self.params), _ptr(self._grads), _ptr(self.adam_m),
                                             _ptr(self.adam_v), max(numel, pl.param_numel), lr, betas[0], betas[1], eps,
                                             weight_decay, self.adam_step, _ptr(pl.workspace), self._stream()),
                   "vpd_plan_adamw_step")
             self._hip_version += 1
             pl.packed_version = self.weights_version()
         else:
-            check(lib().vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+            self.check(self.L.vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                        numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
                                        self._stream()), "vpd_adamw_step")
             self._hip_version += 1
@@ -374,7 +379,7 @@ class StudentEngine:
         self._ensure_packed(pl)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        check(lib().vpd_graph_capture_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(out), _ptr(pl.workspace),
+        self.check(self.L.vpd_graph_capture_eval(pl.handle, _ptr(self.params), _ptr(x), n, _ptr(out), _ptr(pl.workspace),
                                            C.c_void_p(side.cuda_stream)), "vpd_graph_capture_eval")
         torch.cuda.current_stream(self.device).wait_stream(side)
         pl.graph_sizes.add(n)
@@ -387,7 +392,7 @@ class StudentEngine:
         self._ensure_packed(pl)
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        check(lib().vpd_graph_capture_eval(pl.handle, _ptr(self.params), None, n, _ptr(out), _ptr(pl.workspace),
+        self.check(self.L.vpd_graph_capture_eval(pl.handle, _ptr(self.params), None, n, _ptr(out), _ptr(pl.workspace),
                                            C.c_void_p(side.cuda_stream)), "vpd_graph_capture_eval")
         torch.cuda.current_stream(self.device).wait_stream(side)
         pl.graph_sizes.add(n)
@@ -400,17 +405,17 @@ class StudentEngine:
         out = C.c_uint(0)
         for pl in self._plans.values():
             if pl.train and pl.handle:
-                check(lib().vpd_plan_sync_errors(pl.handle, _ptr(pl.workspace), self._stream(), C.byref(out)),
+                self.check(self.L.vpd_plan_sync_errors(pl.handle, _ptr(pl.workspace), self._stream(), C.byref(out)),
                       "vpd_plan_sync_errors")
                 total += out.value
         return total
 
     def set_timing(self, pl, enable):
-        check(lib().vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
+        self.check(self.L.vpd_plan_set_timing(pl.handle, int(enable)), "vpd_plan_set_timing")
 
     def read_timing(self, pl):
         out = (C.c_double * 24)()
-        check(lib().vpd_plan_read_timing(pl.handle, out, 8), "vpd_plan_read_timing")
+        self.check(self.L.vpd_plan_read_timing(pl.handle, out, 8), "vpd_plan_read_timing")
         # (class 1 -> conv3x3_pws_kernel<256,128,352> only with > 1 tile per block, else the class-6 tile; the non-persistent
         #  conv3x3_ws_kernel twins of every class remain behind VPD_PWS=0)
         names = ["conv3x3_c64_persistent_kernel<224>", "conv3x3_pws_kernel<256,128,352>", "conv3x3_pws_kernel<256,64,416> | <128,128,288>",
@@ -421,4 +426,4 @@ class StudentEngine:
 
     def launch_eval_graph(self, pl, n):
         self._ensure_packed(pl)
-        check(lib().vpd_graph_launch_eval(pl.handle, n, self._stream()), "vpd_graph_launch_eval")
+        self.check(self.L.vpd_graph_launch_eval(pl.handle, n, self._stream()), "vpd_graph_launch_eval")

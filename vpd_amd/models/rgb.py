@@ -50,11 +50,13 @@ def find_imagenet_weights(model_arch):
 class RGBF_EmbeddingModel(nn.Module):
     """Basic embedding model with single frame features (HIP / MI355X)."""
 
-    def __init__(self, model_arch, emb_dim, use_flow, device, pretrained=False, in_channels=None):
+    def __init__(self, model_arch, emb_dim, use_flow, device, pretrained=False, in_channels=None, dtype="bf16"):
         """Reference signature (models/rgb.py:49-50) + in_channels: an explicit input-channel count (1..8) for the
         variants the reference's hard-coded 5 cannot express -- BASELINE configs[2] runs a 6-channel two-stream input.
         The stem is then initialised by the same recipe as add_flow_to_model (models/rgb.py:19-23): the channel mean of
-        a 3-channel kaiming kernel expanded to in_channels."""
+        a 3-channel kaiming kernel expanded to in_channels.
+        dtype: "bf16" (default; training and inference) or "fp16" -- the reference's own GPU precision (fp16 autocast,
+        train_vpd_model.py:79) for INFERENCE: embed() / the apply loop run on libvpdhip_f16.so, train mode raises."""
         super().__init__()
         if "effnet" in model_arch:
             raise NotImplementedError("EfficientNet students are out of scope (SURVEY.md 2.1 #3)")
@@ -73,7 +75,7 @@ class RGBF_EmbeddingModel(nn.Module):
             if not 1 <= c_in <= 8:
                 raise ValueError("in_channels must be in 1..8")
         self.in_channels = c_in
-        eng = StudentEngine(model_arch, c_in, emb_dim, device="cuda" if str(device) == "cuda" else device)
+        eng = StudentEngine(model_arch, c_in, emb_dim, device="cuda" if str(device) == "cuda" else device, dtype=dtype)
         self._engine_ref = [eng]
         attach_views(self, eng.enc_names, eng.view)
         for k in eng.enc_names:
