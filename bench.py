@@ -360,6 +360,9 @@ def main():
     ap.add_argument("--no-apply", action="store_true", help="skip the inference-twin block")
     ap.add_argument("--no-parity", action="store_true", help="skip the embedding-parity block (emb L2 vs the reference fixture)")
     ap.add_argument("--arch", default=ARCH, help="student architecture (default: the BASELINE config, resnet34)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"],
+                    help="element type of the HIP path: bf16 (BASELINE configs[1], default) or fp16 + static loss scale (the reference's own "
+                         "GPU precision: fp16 autocast + GradScaler)")
     ap.add_argument("--profile-steps", type=int, default=3, help="event-instrumented steps after the timed region")
     args = ap.parse_args()
 
@@ -400,7 +403,7 @@ def main():
         if not parity["ok"]:
             raise SystemExit("bench.py: embeddings differ from the reference fixture: %s" % json.dumps(parity))
     torch.manual_seed(0)
-    enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device, in_channels=c_in)
+    enc = RGBF_EmbeddingModel(args.arch, EMB_DIM, True, device, in_channels=c_in, dtype=args.dtype)
     enc.reset_parameters(seed=0)                 # reference init semantics, same weights on every rank
     trainer = ModelTrainer(enc, motion=motion)
     if world > 1 and motion:                     # the motion head is initialised in the trainer: rank 0's on every rank
@@ -553,7 +556,7 @@ def main():
         out = {"metric": "frame-crops/sec (VPD student train)", "value": value, "unit": "crops/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
                "repeats": {"n": len(region_s), "pick": "median", "crops_per_s": [args.batch * world * args.steps / t for t in region_s]},
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "gpu_unique_id": __import__("vpd_amd.boxid", fromlist=["gpu_unique_id"]).gpu_unique_id(local_rank),
                "config": {"workload": cfg["what"] % ("ResNet-34" if args.arch == ARCH else args.arch) + ", batch=%d per GPU" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,

@@ -32,8 +32,9 @@ typedef struct vpd_plan vpd_plan_t;
 const char* vpd_last_error(void);
 int vpd_abi_version(void);
 /* Element type of activations / packed weights / activation gradients this library was built with: "bf16" (libvpdhip.so: training and
- * inference) or "fp16" (libvpdhip_f16.so, the same sources with -DVPD_ELEM_F16: inference only -- vpd_plan_create refuses train != 0).
- * fp16 is the reference's own GPU precision (torch.cuda.amp.autocast + GradScaler: train_vpd_model.py:79,105; models/util.py:55-57). */
+ * inference) or "fp16" (libvpdhip_f16.so, the same sources with -DVPD_ELEM_F16).
+ * fp16 is the reference's own GPU precision (torch.cuda.amp.autocast + GradScaler: train_vpd_model.py:79,105; models/util.py:55-57);
+ * fp16 TRAINING uses a loss scale (vpd_plan_set_loss_scale). */
 const char* vpd_elem_dtype(void);
 
 /* Network + workspace description for one (arch, input, head) configuration.
@@ -121,6 +122,12 @@ int vpd_adamw_step(float* params, const float* grads, float* adam_m, float* adam
 int vpd_plan_adamw_step(vpd_plan_t* plan, float* params, const float* grads, float* adam_m, float* adam_v,
                         long long numel, double lr, double beta1, double beta2, double eps, double weight_decay,
                         int step, void* workspace, void* stream);
+
+/* Loss scale of this plan's following backward passes and optimizer steps (default 1 = none).  Replaces torch.cuda.amp.GradScaler
+ * (train_vpd_model.py:105; scaler.scale(loss).backward() / scaler.step(optimizer): models/util.py:55-57) for fp16 training on
+ * libvpdhip_f16.so: vpd_backward multiplies d(loss)/d(pred) by `scale` -- every gradient it produces is scale x its value --
+ * and vpd_plan_adamw_step reads gradients x 1 / scale.  A caller that reads the flat gradient buffer itself divides by the scale. */
+int vpd_plan_set_loss_scale(vpd_plan_t* plan, float scale);
 
 /* Lazy gradients for the fused train step (reference: models/util.py:50-58, where nothing looks at .grad between
  * loss.backward() and optimizer.step()).  vpd_plan_set_lazy_grads(plan, 1) arms the NEXT vpd_backward: the conv weight

@@ -30,19 +30,20 @@ def test_library_exports_every_declared_symbol():
     assert h.vpd_elem_dtype() == b"bf16"
 
 
-def test_fp16_library_exports_the_same_abi_and_refuses_train_plans():
-    """libvpdhip_f16.so = the same sources with fp16 elements (inference only): same symbols, same ABI version, and
-    vpd_plan_create(train != 0) fails with a message instead of building a plan that would need loss scaling."""
+def test_fp16_library_exports_the_same_abi():
+    """libvpdhip_f16.so = the same sources with fp16 elements: same symbols, same ABI version, its own element type; the loss
+    scale (fp16 training) is validated on the host."""
     from vpd_amd import _lib
     h = _lib.lib("fp16")
     for n in header_functions():
         assert getattr(h, n) is not None
     assert h.vpd_abi_version() == _lib.ABI_VERSION and h.vpd_elem_dtype() == b"fp16"
     p = C.c_void_p()
-    assert h.vpd_plan_create(b"resnet34", 5, 128, 128, 128, 0, 4, 1, C.byref(p)) != 0
-    assert b"inference only" in h.vpd_last_error()
-    _lib.check(h.vpd_plan_create(b"resnet34", 5, 128, 128, 128, 0, 4, 0, C.byref(p)), "create", "fp16")
+    _lib.check(h.vpd_plan_create(b"resnet34", 5, 128, 128, 128, 0, 4, 1, C.byref(p)), "create", "fp16")
     assert h.vpd_plan_param_numel(p) == 21356608      # (host-only call on the fp16 plan: ResNet-34, 5 channels, D = 128, no motion head)
+    assert h.vpd_plan_set_loss_scale(p, 256.0) == 0
+    for bad in (0.0, -1.0, float("inf"), float("nan")):
+        assert h.vpd_plan_set_loss_scale(p, bad) != 0 and b"loss scale" in h.vpd_last_error()
     h.vpd_plan_destroy(p)
     with pytest.raises(_lib.VpdHipError):
         _lib.lib("fp32")

@@ -43,6 +43,9 @@ def get_args():
     parser.add_argument('--gpu_augment', action='store_true',
                         help='(default behaviour, kept for compatibility) loaders hand over decoded u8 crops; ColorJitter / '
                              'mask noise / RandomResizedCrop / normalisation run on the GPU (vpd_amd/augment.py)')
+    parser.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16'],
+                        help='(this build) element type of the HIP path: bf16 (default, no loss scaling) or fp16 -- the reference\'s own '
+                             'GPU precision (fp16 autocast + GradScaler), here with a static loss scale (vpd_amd.models.util.LossScaler)')
     parser.add_argument('--no_augment', action='store_true',
                         help='escape hatch: fp32 batches from the CPU loaders with h-flips only -- NOT the reference '
                              'recipe, whose datasets always augment (vpd_dataset/common.py:85-92)')
@@ -68,7 +71,7 @@ def load_dataset(dataset, dataset_kwargs, emb_dir, penn_dir, no_test_video):
 
 def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, motion, encoder_arch, save_dir,
          model_select_window, checkpoint_frequency, pretrained, emb_dir, penn_dir, no_test_video, min_pose_score,
-         synthetic=None, synthetic_emb_dim=128, gpu_augment=False, no_augment=False):
+         synthetic=None, synthetic_emb_dim=128, gpu_augment=False, no_augment=False, dtype='bf16'):
     device = 'cuda'
     # The reference builds train AND val datasets with augment=True (vpd_dataset/single_frame.py:267-272,
     # common.py:85-92): ColorJitter, mask noise, RandomResizedCrop and flips are part of the recipe, so they are the
@@ -134,7 +137,7 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
     val_loader = DataLoader(val_dataset, batch_size, num_workers=num_load_workers, persistent_workers=False,
                             pin_memory=True)
 
-    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, flow_img is not None, device, pretrained=pretrained)
+    encoder = RGBF_EmbeddingModel(encoder_arch, emb_dim, flow_img is not None, device, pretrained=pretrained, dtype=dtype)
     augmenter = None
     if gpu_augment:
         from vpd_amd.augment import CropAugmenter
@@ -152,6 +155,7 @@ def main(dataset, num_epochs, batch_size, learning_rate, img_dim, flow_img, moti
             'use_flow': flow_img is not None, 'motion': motion,
             'embed_time': motion,      # apply_vpd_model.py:102 reads this key; the reference never writes it
             'emb_dim': emb_dim, 'encoder_arch': encoder_arch, 'rgb_mean_std': rgb_mean_std,
+            'dtype': dtype,            # not in the reference: element type of the HIP path (bf16 | fp16 + static loss scale)
             # not in the reference: which input pipeline produced the loss curves
             'augment': 'device: ColorJitter + mask noise + RandomResizedCrop + flip (reference recipe)' if gpu_augment
                        else 'cpu: h-flip only (--no_augment)'})

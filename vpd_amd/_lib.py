@@ -52,6 +52,7 @@ SIGNATURES = {
     "vpd_graph_launch_eval": (C.c_int, [vp, C.c_int, vp]),
     "vpd_plan_sync_errors": (C.c_int, [vp, vp, vp, C.POINTER(C.c_uint)]),
     "vpd_plan_set_lazy_grads": (C.c_int, [vp, C.c_int]),
+    "vpd_plan_set_loss_scale": (C.c_int, [vp, C.c_float]),
     "vpd_plan_bucket_scratch_range": (C.c_int, [vp, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "vpd_plan_grads_pending": (C.c_int, [vp]),
     "vpd_plan_materialize_grads": (C.c_int, [vp, vp, vp, vp]),

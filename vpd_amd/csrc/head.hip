@@ -260,3 +260,17 @@ hipError_t vpd_launch_mse(const float* e, const float* t, long n, float* de, flo
     hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, s, e, t, n, de, loss_step, loss_accum);
     return hipGetLastError();
 }
+
+
+// x *= s over n floats: the loss scale of fp16 training on d(loss)/d(pred) at the start of the backward pass (every gradient of the
+// pass is then S x its value -- backward is linear -- and the optimizer step multiplies by 1 / S: AdamHyper::gscale)
+__global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float s) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= s;
+}
+hipError_t vpd_launch_scale(float* x, long n, float s, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, n, s);
+    return hipGetLastError();
+}

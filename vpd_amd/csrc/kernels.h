@@ -68,9 +68,10 @@ struct PackDesc {                       // one convolution's weight tensors
     int Co, Ci, kh, kw, Kc, ntaps, stem;   // stem: 1 = 7x7 row-tap packing; 2 = not a conv: plain range (AdamW only)
     long long numel;                    // stem == 2: length of the range at src_off
 };
-struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps; };
+struct AdamHyper { float decay, omb1, b2, omb2, step_size, inv_sqrt_bc2, eps, gscale; };      // gscale: 1 / loss scale (fp16 training), else 1
 
 hipError_t vpd_launch_conv(const ConvParams& p, hipStream_t stream);
+hipError_t vpd_launch_scale(float* x, long n, float s, hipStream_t stream);      // head.hip: x *= s (the loss scale on d(loss)/d(pred))
 // conv_stream.hip: persistent streaming kernel for 1x1 convolutions with <= 256 input channels on many pixels
 bool vpd_conv1x1_stream_eligible(const ConvParams& p);
 hipError_t vpd_launch_conv1x1_stream(const ConvParams& p, hipStream_t stream);
@@ -165,11 +166,11 @@ hipError_t vpd_launch_pack_weights(const PackDesc* d_descs, int ndesc, const int
                                    const float* master, bf16_t* arena, hipStream_t s);
 hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
                                  float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
-                                 int step, hipStream_t s, const float* wg = nullptr);      // wg: conv gradients still in the scratch
+                                 int step, hipStream_t s, const float* wg = nullptr, float gscale = 1.f);      // wg: conv gradients still in the scratch
 hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int* d_blockmap, int nblocks,
                                    const float* wg, float* grads, hipStream_t s);
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
-                            double eps, double wd, int step, hipStream_t s);
+                            double eps, double wd, int step, hipStream_t s, float gscale = 1.f);
 
 #define ZR_MAX 16
 struct ZeroRanges {                     // 16-byte aligned ranges, lengths in float4

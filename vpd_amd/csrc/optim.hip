@@ -244,6 +244,7 @@ hipError_t vpd_launch_unpack_grads(const PackDesc* d_descs, int ndesc, const int
 // (explicit fma placement: the flat kernel and the fused AdamW + repack kernel must round identically)
 static __device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, const AdamHyper& h) {
 #pragma clang fp contract(off)
+    g *= h.gscale;      // 1 / loss scale: exact for the powers of two a LossScaler uses, and for 1
     p *= h.decay;
     m = fmaf(g - m, h.omb1, m);
     v = fmaf(h.omb2 * g, g, v * h.b2);
@@ -254,11 +255,11 @@ static __device__ __forceinline__ void adamw4(float4& pp, const float4& gg, floa
     adamw1(pp.x, gg.x, mm.x, vv.x, h); adamw1(pp.y, gg.y, mm.y, vv.y, h);
     adamw1(pp.z, gg.z, mm.z, vv.z, h); adamw1(pp.w, gg.w, mm.w, vv.w, h);
 }
-static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int step) {
+static AdamHyper adam_hyper(double lr, double b1, double b2, double eps, double wd, int step, float gscale) {
     const double bc1 = 1.0 - pow(b1, step);
     const double bc2 = 1.0 - pow(b2, step);
     return AdamHyper{(float)(1.0 - lr * wd), (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1),
-                     (float)(1.0 / sqrt(bc2)), (float)eps};
+                     (float)(1.0 / sqrt(bc2)), (float)eps, gscale};
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, float4* m, float4* v, long n4,
@@ -270,13 +271,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float4* p, const float4* g, 
     }
 }
 hipError_t vpd_launch_adamw(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
-                            double eps, double wd, int step, hipStream_t s) {
+                            double eps, double wd, int step, hipStream_t s, float gscale) {
     if (n % 4) return hipErrorInvalidValue;
     const long n4 = n / 4;
     long gsz = (n4 + 255) / 256;
     if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3(gsz < 1 ? 1 : (int)gsz), dim3(256), 0, s, (float4*)p, (const float4*)g,
-                       (float4*)m, (float4*)v, n4, adam_hyper(lr, b1, b2, eps, wd, step));
+                       (float4*)m, (float4*)v, n4, adam_hyper(lr, b1, b2, eps, wd, step, gscale));
     return hipGetLastError();
 }
 
@@ -370,12 +371,12 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const PackDesc* descs, 
 }
 hipError_t vpd_launch_adamw_pack(const PackDesc* d_descs, const int* d_blockmap, int nblocks, float* p, const float* g,
                                  float* m, float* v, bf16_t* arena, double lr, double b1, double b2, double eps, double wd,
-                                 int step, hipStream_t s, const float* wg) {
+                                 int step, hipStream_t s, const float* wg, float gscale) {
     if ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) |
          reinterpret_cast<size_t>(v)) & 15)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(adamw_pack_kernel, dim3(nblocks), dim3(256), 0, s, d_descs, d_blockmap, p, g, m, v, arena,
-                       adam_hyper(lr, b1, b2, eps, wd, step), wg);
+                       adam_hyper(lr, b1, b2, eps, wd, step, gscale), wg);
     return hipGetLastError();
 }
 

@@ -140,6 +140,7 @@ struct vpd_plan {
     bool wg_merge34 = true;     // layer4's grouped weight gradients wait for layer3's and share its launch (VPD_WG_MERGE=0, or the
                                 // data-parallel creation flag VPD_TRAIN_EARLY_BUCKET0: per stage)
     bool early_bucket0 = false;
+    float loss_scale = 1.f;     // vpd_plan_set_loss_scale: fp16 training (the reference's GradScaler, models/util.py:55-57)
     size_t wg2_tbl_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // task tables of the persistent weight-gradient launches (two per stage)
     void* wg2_cache[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // optional per-kernel-class timing (bench.py roofline): HIP events around every conv launch
@@ -224,11 +225,6 @@ TapSet conv_taps_fwd(const ConvInfo& c) {
 // ---------------------------------------------------------------------------
 extern "C" int vpd_plan_create(const char* arch, int c_in, int img_h, int img_w, int emb_dim, int motion,
                                int max_batch, int train, vpd_plan_t** out) {
-#ifdef VPD_ELEM_F16
-    // fp16 elements: inference only.  A train-mode fp16 path needs the reference's loss scaling (GradScaler, models/util.py:55-57):
-    // activation gradients of a sum-MSE over 256 crops reach 1e-7..1e-8 at the stem, below fp16's 6e-8 subnormal step
-    if (train) return fail("libvpdhip_f16.so is inference only (train plans need libvpdhip.so: bf16 elements)");
-#endif
     if (!arch || !out) return fail("null argument");
     std::vector<int> layers;
     int bottleneck = 0, base_width = 64;          // reference models/module.py:17-32 (ENCODER_ARCH)
@@ -1402,6 +1398,8 @@ extern "C" int vpd_backward(vpd_plan_t* p, const float* params, float* grads, in
     LCHECK(vpd_launch_zero_ranges(zr, s));
 
     // ---- head ----
+    if (p->loss_scale != 1.f)      // (fp16 training: vpd_plan_set_loss_scale)
+        LCHECK(vpd_launch_scale(c.f32(p->dpred_off), (long)n * (p->motion ? 2 * p->D : p->D), p->loss_scale, s));
     const float* demb = c.f32(p->dpred_off);
     if (p->motion) {
         const LinInfo* L = p->dec;
@@ -1817,7 +1815,8 @@ extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* gr
                                  reinterpret_cast<const int*>(ws + p->bmap_adam_off), (int)p->bmap_adam.size() / 2, params,
                                  grads, adam_m, adam_v, reinterpret_cast<bf16_t*>(ws + p->arena_off), lr, beta1, beta2,
                                  eps, weight_decay, step, s,
-                                 p->grads_in_scratch ? reinterpret_cast<const float*>(ws + p->wg_off) : nullptr));
+                                 p->grads_in_scratch ? reinterpret_cast<const float*>(ws + p->wg_off) : nullptr,
+                                 1.0f / p->loss_scale));
     p->grads_in_scratch = false;      // consumed (the scratch is rewritten by the next backward)
     LCHECK(vpd_launch_pack_weights(reinterpret_cast<const PackDesc*>(ws + p->desc_off), (int)p->descs.size(),
                                    reinterpret_cast<const int*>(ws + p->bmap_pack_off), p->nstem_pack_blocks, params,
@@ -1825,7 +1824,18 @@ extern "C" int vpd_plan_adamw_step(vpd_plan_t* p, float* params, const float* gr
     if (numel > p->nparam_padded)      // tensors the plan does not use (a motion head on a plan built without it)
         LCHECK(vpd_launch_adamw(params + p->nparam_padded, grads + p->nparam_padded, adam_m + p->nparam_padded,
                                 adam_v + p->nparam_padded, (long)(numel - p->nparam_padded), lr, beta1, beta2, eps,
-                                weight_decay, step, s));
+                                weight_decay, step, s, 1.0f / p->loss_scale));
+    return 0;
+}
+
+// Loss scale of the NEXT backward passes of this plan and of vpd_plan_adamw_step (fp16 training; the reference's GradScaler,
+// models/util.py:55-57, train_vpd_model.py:105): vpd_backward multiplies d(loss)/d(pred) by `scale`, so every gradient it leaves --
+// flat buffer, weight-gradient scratch, what a reducer sums -- is scale x its value (no fp16 activation gradient underflows), and
+// vpd_plan_adamw_step multiplies the gradients it reads by 1 / scale.  1 (the default) is exact arithmetic: nothing changes.
+extern "C" int vpd_plan_set_loss_scale(vpd_plan_t* p, float scale) {
+    if (!p) return fail("null plan");
+    if (!(scale > 0.f) || !(scale < 3.0e38f)) return fail("loss scale must be a positive finite number");
+    p->loss_scale = scale;
     return 0;
 }
 

@@ -148,6 +148,7 @@ class StudentEngine:
         # dtype: element type of activations / packed weights -- "bf16" (libvpdhip.so: training and inference) or "fp16"
         # (libvpdhip_f16.so: inference only; the reference's own GPU precision, train_vpd_model.py:79)
         self.dtype = dtype
+        self.loss_scale = 1.0      # set by models.util.LossScaler around a backward pass + optimizer step (fp16 training)
         self.L = lib(dtype)   # fail loudly right here if the HIP library is missing
         self.check = lambda rc, what="": check(rc, what, dtype)
         self.arch, self.c_in, self.emb_dim = arch, int(c_in), int(emb_dim)
@@ -329,11 +330,21 @@ class StudentEngine:
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
+        self.check(self.L.vpd_plan_set_loss_scale(pl.handle, float(self.loss_scale)), "vpd_plan_set_loss_scale")
         if lazy:      # (with bucket events the reducer sums the scratch ranges: GradBucketReducer.reduce(plan, lazy=True))
             self.check(self.L.vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
         self.check(self.L.vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
                                  self._stream()), "vpd_backward")
         return pl
+
+    def unscale_grads_(self):
+        """LossScaler.step() for an optimizer that reads p.grad: the flat gradient buffer (completed first) x 1 / loss scale."""
+        if self.loss_scale != 1.0:
+            self.materialize_grads()
+            self._grads.mul_(1.0 / self.loss_scale)
+            if self._step_plan is not None:
+                self.check(self.L.vpd_plan_set_loss_scale(self._step_plan.handle, 1.0), "vpd_plan_set_loss_scale")
+            self.loss_scale = 1.0
 
     @property
     def encoder_numel(self):
@@ -365,6 +376,7 @@ class StudentEngine:
             self._hip_version += 1
             pl.packed_version = self.weights_version()
         else:
+            self.unscale_grads_()      # (the flat kernel has no plan to ask for the loss scale)
             self.check(self.L.vpd_adamw_step(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
                                        numel, lr, betas[0], betas[1], eps, weight_decay, self.adam_step,
                                        self._stream()), "vpd_adamw_step")

@@ -7,7 +7,7 @@ import torch
 
 from .ddp import GradBucketReducer
 from .models.module import FCNet
-from .models.util import step
+from .models.util import LossScaler, step
 
 
 class _Loss:
@@ -164,6 +164,10 @@ class ModelTrainer:
         if optimizer is not None and eng.sync_errors():
             raise RuntimeError("a fused BatchNorm launch timed out at its in-launch grid barrier (the grid was not "
                                "resident): this epoch's results are invalid; set VPD_FUSED_BN=0 to use separate launches")
+        if optimizer is not None and scaler is not None and epoch_emb_loss != epoch_emb_loss:
+            raise FloatingPointError("non-finite training loss under fp16 with loss scale %g: an activation gradient left fp16's range "
+                                     "(the reference's GradScaler would have skipped those steps); use LossScaler(engine, init_scale=<smaller>)"
+                                     % scaler.get_scale())
         if self._reducer is not None:
             epoch_emb_loss, epoch_emb_n = self._reducer.all_reduce_scalars(epoch_emb_loss, epoch_emb_n)
         return epoch_emb_loss / epoch_emb_n
@@ -172,8 +176,10 @@ class ModelTrainer:
         params = list(self.encoder.parameters())
         if hasattr(self, 'fcn_time'):
             params.extend(self.fcn_time.parameters())
-        # scaler is None: bf16 operands with fp32 accumulation need no GradScaler
-        return FusedAdamW(params, self.encoder.engine, lr=learning_rate), None
+        # bf16 operands with fp32 accumulation need no GradScaler: scaler None.  A student built with dtype="fp16" gets the static
+        # LossScaler (the reference: GradScaler() on 'cuda', train_vpd_model.py:104-105)
+        eng = self.encoder.engine
+        return FusedAdamW(params, eng, lr=learning_rate), (LossScaler(eng) if eng.dtype == "fp16" else None)
 
     def save_model(self, save_dir, name):
         torch.save(self.encoder.state_dict(),
