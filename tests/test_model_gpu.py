@@ -300,13 +300,13 @@ sys.path.insert(0, {repo!r})
 from oracle import vpd_oracle as O
 from vpd_amd.models.rgb import RGBF_EmbeddingModel
 from vpd_amd.trainer import ModelTrainer
-sd = O.reference_init_state_dict("resnet34", 5, 32, 3)
-enc = RGBF_EmbeddingModel("resnet34", 32, True, "cuda")
+sd = O.reference_init_state_dict({arch!r}, 5, 32, 3)
+enc = RGBF_EmbeddingModel({arch!r}, 32, True, "cuda")
 enc.load_state_dict(sd)
 tr = ModelTrainer(enc, False)
 g = torch.Generator(device="cuda").manual_seed(4)
-img = torch.randn((256, 5, 128, 128), generator=g, device="cuda")
-tgt = torch.randn((256, 32), generator=g, device="cuda")
+img = torch.randn(({n}, 5, 128, 128), generator=g, device="cuda")
+tgt = torch.randn(({n}, 32), generator=g, device="cuda")
 enc.train()
 loss = tr._forward_loss(img, tgt, train=True)
 loss.backward()
@@ -317,11 +317,14 @@ print("LOSS", loss.item())
 """
 
 
-def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
+@pytest.mark.parametrize("arch,n", [("resnet34", 256), ("resnet50", 64)])
+def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path, arch, n):
     """Default path: the stride-1 3x3 data gradients of layers 2-4 add sum g and sum g*z of the BatchNorm that consumes
     their output to its rows (conv_epilogue.h, EPM 6 / 7) and the BatchNorm launch only finalizes and applies
     (bn_bwd_apply_fused_kernel); VPD_DGRAD_SUMS=0 is the separate reduce + barrier + apply launch.  Same g, same bf16
-    rounding points; the sums differ in their summation order and in sum g*xhat being formed from sum g*z in fp64."""
+    rounding points; the sums differ in their summation order and in sum g*xhat being formed from sum g*z in fp64.
+    resnet50: layer3 / layer4's conv3 and conv2 data gradients -- 1x1 on the ring GEMM / gather kernel (mode 6) and
+    3x3 -- carry the sums of bn2 / bn1 there."""
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -329,8 +332,8 @@ def test_batchnorm_backward_sums_taken_by_the_data_gradient(tmp_path):
     for flag in ("0", "1"):
         out = str(tmp_path / ("g%s.npy" % flag))
         env = dict(os.environ, VPD_DGRAD_SUMS=flag)
-        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out)], env=env, capture_output=True,
-                           text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", _STEP_SCRIPT.format(repo=repo, out=out, arch=arch, n=n)], env=env,
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         outs.append((np.load(out), float(r.stdout.split("LOSS")[1].split()[0])))
     (g0, l0), (g1, l1) = outs

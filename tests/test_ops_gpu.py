@@ -391,7 +391,11 @@ def test_batchnorm_backward_op_matches_autograd(shape):
     assert rel_l2(got, off) > 2 * 3e-3
 
 
-BNSUM_CASES = [("l3_ragged", 5, 256, 256, 8, 8), ("l2", 9, 128, 128, 16, 16), ("l1", 3, 64, 64, 16, 16), ("l4", 6, 512, 512, 4, 4)]
+BNSUM_CASES = [("l3_ragged", 5, 256, 256, 8, 8), ("l2", 9, 128, 128, 16, 16), ("l1", 3, 64, 64, 16, 16), ("l4", 6, 512, 512, 4, 4),
+               # 1x1 (kernel size as 7th field): the Bottleneck students' conv3 / conv1 data gradients of layer3 / layer4, whose epilogue
+               # (ring GEMM / gather kernel, mode 6) takes the sums of bn2 / bn1
+               ("r50_l3_conv3_1x1", 32, 1024, 256, 8, 8, 1), ("r50_l4_conv3_1x1", 64, 2048, 512, 4, 4, 1),
+               ("r50_l3_conv1_1x1", 8, 256, 1024, 8, 8, 1)]
 
 
 @pytest.mark.parametrize("case", BNSUM_CASES, ids=[c[0] for c in BNSUM_CASES])
@@ -400,11 +404,12 @@ def test_conv_epilogue_batchnorm_sums(case, accumulate):
     """Epilogue modes 6 / 7: the data gradient d it stores (or adds onto the identity path's gradient) and, from the same
     registers, sum g and sum g * z of the consuming BatchNorm with g = d * mask -- checked against float64 sums over the
     kernel's OWN stored output, so only the summation is in question (fp32 partials per block, fp64 across blocks)."""
-    name, n, ci, co, h, w = case
+    name, n, ci, co, h, w = case[:6]
+    k = case[6] if len(case) > 6 else 3
     L = _lib()
     g = torch.Generator().manual_seed(len(name) * 100 + n + accumulate)
     x = bf16_round(torch.randn(n, ci, h, w, generator=g))
-    wt = bf16_round(torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5)
+    wt = bf16_round(torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5)
     M = n * h * w
     z = bf16_round(torch.randn(M, co, generator=g))
     mask = torch.rand(M, co, generator=g) > 0.45
@@ -413,11 +418,11 @@ def test_conv_epilogue_batchnorm_sums(case, accumulate):
     y = old.to(torch.bfloat16).cuda().flatten().contiguous()
     zd, bits = z.to(torch.bfloat16).cuda().contiguous(), _mask_bits(mask).cuda()
     rows = torch.zeros(4, 2, co, dtype=torch.float64, device="cuda")
-    taps = tapset(3, 3, 0, 1, 0, 1, 0, 3, 1)
+    taps = tapset(3, 3, 0, 1, 0, 1, 0, 3, 1) if k == 3 else tapset(1, 1, 1, 1, 1, 1, 0, 1, 1)
     _check(L.vpd_op_conv2d_bnsums(ptr(xp), ptr(pack_fwd(wt)), ptr(y), ptr(zd), ptr(bits), ptr(rows), n, h + 2, w + 2, ci, h, w,
                                   ci, co, taps, accumulate, stream()))
     torch.cuda.synchronize()
-    ref = F.conv2d(x, wt, None, padding=1).permute(0, 2, 3, 1).reshape(M, co) + old
+    ref = F.conv2d(x, wt, None, padding=k // 2).permute(0, 2, 3, 1).reshape(M, co) + old
     d = y.view(M, co).float().cpu()
     assert rel_l2(d, ref) < REL_TOL
     gm = d.double() * mask

@@ -1608,7 +1608,9 @@ static bool halo_geom(const ConvParams& p, int BM, int hrows_max, HaloGeom* g) {
     else { g->kmask = 3; g->kshift = 2; g->rowmask = 1; }
     g->rH = 1.0f / (float)H; g->rW = 1.0f / (float)W; g->rWp = 1.0f / (float)(W + 2);
     static const int rot = getenv("VPD_PWS_ROT") ? atoi(getenv("VPD_PWS_ROT")) : 1;
-    g->rot = rot && p.Kc > 64;
+    // (not in the inference epilogue: there a crop's embedding must not depend on where in the batch it sits -- a batch, its split, its
+    //  ragged tail and its hipGraph launch agree bit for bit, tests/test_fullsize_gpu.py -- and the rotation is a function of the tile index)
+    g->rot = rot && p.Kc > 64 && conv_ep_mode(p) != 3;
     g->rnch = 1.0f / (float)(p.Kc / 64);
     return g->NHP <= hrows_max;
 }

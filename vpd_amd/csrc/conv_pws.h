@@ -49,7 +49,8 @@ struct HaloGeom {
     // 1-KB (layer4) pixels and weight rows at the same time -- a quarter / an eighth of the 128-byte lines; staggered, the
     // launch's requests cover all of them (layer3 / layer4 launches 4-6 % shorter, +1.3 % on the step:
     // profiles/r06_ab_chunk_rotation.txt).  The order is a function of the tile index alone, so results do not depend on
-    // the grid; each accumulator's fp32 summation order over chunks is rotated accordingly.
+    // the grid; each accumulator's fp32 summation order over chunks is rotated accordingly.  Training launches only: the inference
+    // forward keeps chunk order 0, 1, 2 ... for every tile, so that an embedding does not depend on the crop's position in its batch.
     int rot;             // 1: on (VPD_PWS_ROT=0 turns it off)
     float rnch;          // 1 / nchunks
 };

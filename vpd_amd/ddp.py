@@ -35,12 +35,32 @@ def wire_dtype():
     return torch.bfloat16 if w == "bf16" else torch.float32
 
 
+# wire buffers of the bf16 mode: one per (storage address, element count, dtype, device) for the life of the process -- the gradient
+# views a reducer sends are the same ranges of the same flat buffers every step, so nothing is allocated on the comm stream after the
+# first step (a fresh bf16 copy per bucket per step was allocator traffic next to the collectives)
+_WIRE_BUFFERS = {}
+
+
+def _wire_buffer(view, dtype):
+    key = (view.data_ptr(), view.numel(), dtype, str(view.device))
+    buf = _WIRE_BUFFERS.get(key)
+    if buf is None:
+        if len(_WIRE_BUFFERS) > 64:          # (plans were rebuilt: drop the buffers of the old workspaces)
+            _WIRE_BUFFERS.clear()
+        buf = _WIRE_BUFFERS[key] = torch.empty(view.shape, dtype=dtype, device=view.device)
+    return buf
+
+
 class _WireWork:
     """An all-reduce of `view` through a buffer of the wire dtype: wait(), then the summed values are copied back."""
 
     def __init__(self, view, group, async_op, dtype):
         self.view = view
-        self.buf = view if dtype == view.dtype else view.to(dtype)
+        if dtype == view.dtype:
+            self.buf = view
+        else:
+            self.buf = _wire_buffer(view, dtype)
+            self.buf.copy_(view)
         self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if not async_op:
             self._back()
@@ -88,7 +108,12 @@ def all_reduce_lazy(scratch_views, flat, small_idx, group=None, async_op=False):
             w = _WireWork(v, group, async_op, dt)
             if async_op:
                 works.append(w)
-    small = flat.index_select(0, small_idx)
+    # (the gathered message lives in a buffer kept per index table: the same address every step, so its wire buffer is reused too)
+    key = ("small", small_idx.data_ptr(), small_idx.numel(), str(flat.device))
+    small = _WIRE_BUFFERS.get(key)
+    if small is None:
+        small = _WIRE_BUFFERS[key] = torch.empty(small_idx.numel(), dtype=flat.dtype, device=flat.device)
+    torch.index_select(flat, 0, small_idx, out=small)
     w = _WireWork(small, group, async_op, dt)
     if async_op:
         works.append(w)
