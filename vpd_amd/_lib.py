@@ -102,12 +102,14 @@ def lib(dtype="bf16"):
         try:
             fn = getattr(h, sym)
         except AttributeError as e:
-            if ab_build and (sym.startswith("vpd_op_") or sym == "vpd_elem_dtype"):
+            # (an OLDER round's library, same-box A/B: the entry points added since are optional there -- engine.py asks hasattr)
+            if ab_build and (sym.startswith("vpd_op_") or sym in ("vpd_elem_dtype", "vpd_plan_set_loss_scale")):
                 continue
             raise VpdHipError("%s lacks symbol %s declared in include/vpd_hip.h" % (name, sym)) from e
         fn.restype = res
         fn.argtypes = args
-    if h.vpd_abi_version() != ABI_VERSION:
+    # (VPD_LIB_ALLOW_ABI=<n>: a same-box A/B against round n's library, whose train-step entry points have the same signatures)
+    if h.vpd_abi_version() != ABI_VERSION and not (ab_build and os.environ.get("VPD_LIB_ALLOW_ABI") == str(h.vpd_abi_version())):
         raise VpdHipError("%s ABI version %d != expected %d" % (name, h.vpd_abi_version(), ABI_VERSION))
     if hasattr(h, "vpd_elem_dtype") and h.vpd_elem_dtype().decode() != dtype:
         raise VpdHipError("%s was built with %s elements, %s asked for" % (path, h.vpd_elem_dtype().decode(), dtype))

@@ -330,7 +330,8 @@ class StudentEngine:
         ev = None
         if events is not None:
             ev = (C.c_void_p * len(events))(*[C.c_void_p(e) for e in events])
-        self.check(self.L.vpd_plan_set_loss_scale(pl.handle, float(self.loss_scale)), "vpd_plan_set_loss_scale")
+        if self.loss_scale != 1.0 or hasattr(self.L, "vpd_plan_set_loss_scale"):      # (absent only in an older A/B library)
+            self.check(self.L.vpd_plan_set_loss_scale(pl.handle, float(self.loss_scale)), "vpd_plan_set_loss_scale")
         if lazy:      # (with bucket events the reducer sums the scratch ranges: GradBucketReducer.reduce(plan, lazy=True))
             self.check(self.L.vpd_plan_set_lazy_grads(pl.handle, 1), "vpd_plan_set_lazy_grads")
         self.check(self.L.vpd_backward(pl.handle, _ptr(self.params), _ptr(self._grads), n, ev, _ptr(pl.workspace),
