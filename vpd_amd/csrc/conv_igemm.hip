@@ -1301,9 +1301,9 @@ static hipError_t launch_pws(const ConvParams& p, const HaloGeom& g, hipStream_t
     } };
 #endif
     bool geo_launched = false;
-    if (PIPE && NMW == 4) {
+    {
         static const int geo_on = getenv("VPD_PWS_GEO") ? atoi(getenv("VPD_PWS_GEO")) : 1;
-        geo_launched = geo_on && vpd_launch_pws_geo(BM, BN, HROWS, NS, q, g, sg, grid, block, lds, stream);
+        geo_launched = geo_on && vpd_launch_pws_geo(BM, BN, HROWS, NS, NMW, q, g, sg, grid, block, lds, stream);
     }
     if (!geo_launched) switch (conv_ep_mode(q)) {
         case 0: VPD_LAUNCH((conv3x3_pws_kernel<BM, BN, HROWS, NS, 0, NMW, PIPE>), grid, block, lds, stream, q, g, sg); break;

@@ -234,7 +234,7 @@ static __device__ __forceinline__ void pws_body(const ConvParams& p, const HaloG
     using SC = PwsSched<W_PER, HPASS, HT, A>;
     static_assert(HROWS % 8 == 0 && A >= 1 && HT >= 1 && SC::max_inflight() < 64, "ring / vmcnt geometry");
     static_assert(EPM == 0 || EPM == 1 || EPM == 2 || EPM == 3 || EPM == 6 || EPM == 7 || EPM == 8, "epilogue mode");
-    static_assert(WC == 0 || (PIPE && NMW == 4), "compile-time geometry: four pipelined MFMA waves only");
+    static_assert(WC == 0 || NMW == 4 || NMW == 8, "compile-time geometry: four or eight MFMA waves (always the two-set fragment pipeline)");
     constexpr unsigned OFF_W = 2u * HBUF * 2u;                       // bytes
     constexpr unsigned OFF_DUMP = OFF_W + NS * WSTAGE * 2u;
     constexpr unsigned OFF_RED = OFF_DUMP + 1024u;
@@ -792,5 +792,5 @@ __global__ __launch_bounds__((NMW + 4) * 64, (NMW + 4) / 4) void conv3x3_pws_ker
 // conv_pws_geo.hip: the compile-time-geometry instantiations (W = 16 / 8 on 256 x 64 tiles, W = 4 on 128 x 64 tiles; forward taps or
 // the data gradient's mirrored ones).  Returns false when (tile, W, taps, epilogue mode) has no such instantiation: the caller
 // launches the generic kernel.
-bool vpd_launch_pws_geo(int bm, int bn, int hrows, int ns, const ConvParams& q, const HaloGeom& g, const PwsGrid& sg, dim3 grid,
+bool vpd_launch_pws_geo(int bm, int bn, int hrows, int ns, int nmw, const ConvParams& q, const HaloGeom& g, const PwsGrid& sg, dim3 grid,
                         dim3 block, size_t lds, hipStream_t stream);
