@@ -1224,18 +1224,7 @@ static hipError_t launch_stem(const ConvParams& p, int TR, hipStream_t stream) {
 // conv3x3_pws_kernel (conv_pws.h): persistent blocks, one barrier per K-step.  VPD_PWS=0 restores conv3x3_ws_kernel.
 // ---------------------------------------------------------------------------
 // ring depths per tile class (NS = A + 2: two readable steps + A weight bundles in flight); -D overrides for same-box A/B builds
-#ifndef PWS_NS_C1
-#define PWS_NS_C1 4
-#endif
-#ifndef PWS_NS_C2
-#define PWS_NS_C2 5
-#endif
-#ifndef PWS_NS_C3
-#define PWS_NS_C3 7
-#endif
-#ifndef PWS_NS_C6
-#define PWS_NS_C6 5
-#endif
+// (ring depths PWS_NS_C*: conv_pws.h)
 int pws_cu_count() {
     // VPD_PWS_BLOCKS: pretend the device has this many CUs (tests: many tiles per block on small problems)
     static const int forced = getenv("VPD_PWS_BLOCKS") && atoi(getenv("VPD_PWS_BLOCKS")) > 0 ? atoi(getenv("VPD_PWS_BLOCKS")) : 0;

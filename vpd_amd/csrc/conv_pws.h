@@ -59,6 +59,20 @@ typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 int pws_cu_count();                                            // conv_igemm.hip (VPD_PWS_BLOCKS override)
+// ring depths NS of the tiles (timing classes 1, 2, 3, 6 of vpd_conv_kernel_class): weight stages in LDS = K-steps the loaders run ahead + 2
+#ifndef PWS_NS_C1
+#define PWS_NS_C1 4
+#endif
+#ifndef PWS_NS_C2
+#define PWS_NS_C2 5
+#endif
+#ifndef PWS_NS_C3
+#define PWS_NS_C3 9      // (round 6, with the geo K loop: 7 -> 9 stages, layer4 class -3 %, profiles/r06_ab_ring_depth.txt)
+#endif
+#ifndef PWS_NS_C6
+#define PWS_NS_C6 5
+#endif
+
 int vpd_conv_kernel_class(const ConvParams& p, HaloGeom* g);   // conv_igemm.hip
 
 struct PwsGrid {

@@ -41,11 +41,11 @@ bool vpd_launch_pws_geo(int bm, int bn, int hrows, int ns, int nmw, const ConvPa
     if (!fwd && !flip) return false;
     // (the swizzle key the kernel's bases are built from: halo_geom, conv_igemm.hip)
     if (q.Ws >= 8 ? !(g.kmask == 7 && g.kshift == 0 && g.rowmask == 0) : !(g.kmask == 3 && g.kshift == 2 && g.rowmask == 1)) return false;
-    if (nmw == 4 && bm == 256 && bn == 64 && hrows == 416 && ns == 5) {
-        if (q.Ws == 16) return launch_geo<256, 64, 416, 5, 16>(flip, q, g, sg, grid, block, lds, stream);
-        if (q.Ws == 8) return launch_geo<256, 64, 416, 5, 8>(flip, q, g, sg, grid, block, lds, stream);
-    } else if (nmw == 4 && bm == 128 && bn == 64 && hrows == 288 && ns == 7) {
-        if (q.Ws == 4) return launch_geo<128, 64, 288, 7, 4>(flip, q, g, sg, grid, block, lds, stream);
+    if (nmw == 4 && bm == 256 && bn == 64 && hrows == 416 && ns == PWS_NS_C6) {
+        if (q.Ws == 16) return launch_geo<256, 64, 416, PWS_NS_C6, 16>(flip, q, g, sg, grid, block, lds, stream);
+        if (q.Ws == 8) return launch_geo<256, 64, 416, PWS_NS_C6, 8>(flip, q, g, sg, grid, block, lds, stream);
+    } else if (nmw == 4 && bm == 128 && bn == 64 && hrows == 288 && ns == PWS_NS_C3) {
+        if (q.Ws == 4) return launch_geo<128, 64, 288, PWS_NS_C3, 4>(flip, q, g, sg, grid, block, lds, stream);
     }
     // (round 6, measured and removed -- profiles/r06_ab_geo8.txt: the same loop on the eight-wave 256 x 128 tile, whose 168-register
     //  budget it does not fit without spilling and whose two MFMA waves per SIMD already cover each other's reads, 676 vs 636 us per step
