@@ -156,7 +156,7 @@ def test_zero_crop_rank_joins_the_collective():
     assert (nbt0, nbt1) == (2, 1)               # the empty batch is not a BatchNorm step on rank 1
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, dtype="bf16"):
     import torch.distributed as dist
     from vpd_amd.ddp import shard_slice
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
@@ -170,10 +170,11 @@ def _rank_main(rank, world, port, q):
         img = O.synthetic_crops(10, 5, 64, 3)
         tgt = O.synthetic_targets(10, 32, False, 4)
         sl = shard_slice(10, rank, world)
-        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda", dtype=dtype)
         enc.load_state_dict(sd)
         tr = ModelTrainer(enc, False, process_group=dist.group.WORLD)
         opt, sc = tr.get_optimizer(5e-4)
+        assert (sc is None) == (dtype == "bf16")
         enc.train()
         loss = tr._forward_loss(img[sl], tgt[sl], train=True)
         loss.backward()
@@ -186,10 +187,12 @@ def _rank_main(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_two_ranks_on_one_gpu_sum_their_shard_gradients(dtype):
     """world_size 2 (two processes, both on this GPU, gloo transport): after the bucketed all-reduce every rank holds
     the SUM of the two shards' gradients (per-shard BatchNorm statistics, as SURVEY 8e), the epoch value is the
-    global sum-MSE per crop, and both ranks take the same AdamW step."""
+    global sum-MSE per crop, and both ranks take the same AdamW step.  fp16: the step inside epoch() runs through the
+    LossScaler -- the reducer sums gradients that are 256 x their value and the fused AdamW reads them x 1 / 256."""
     import torch.multiprocessing as mp
     from vpd_amd.ddp import shard_slice
     from vpd_amd.models.rgb import RGBF_EmbeddingModel
@@ -197,7 +200,7 @@ def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
@@ -213,7 +216,7 @@ def test_two_ranks_on_one_gpu_sum_their_shard_gradients():
     total, loss_sum = None, 0.0
     for r in range(2):
         sl = shard_slice(10, r, 2)
-        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda")
+        enc = RGBF_EmbeddingModel("resnet18", 32, True, "cuda", dtype=dtype)
         enc.load_state_dict(sd)
         tr = ModelTrainer(enc, False)
         enc.train()
