@@ -445,8 +445,12 @@ print("RESULT " + json.dumps(res))
 """
 
 
-@pytest.mark.parametrize("arch,n,env", [("resnet34", 256, {"VPD_DGRAD_SUMS": "0"}), ("resnet50", 64, {"VPD_DGRAD_SUMS": "0"})],
-                         ids=["r34_every_bn_backward_with_a_barrier", "r50_every_bn_backward_with_a_barrier"])
+@pytest.mark.parametrize("arch,n,env", [("resnet34", 256, {"VPD_DGRAD_SUMS": "0"}), ("resnet50", 64, {"VPD_DGRAD_SUMS": "0"}),
+                                        # the same with 16 CUs reserved (vpd_cu_budget: every persistent grid and the
+                                        # grid barrier sized to 240 CUs) -- the co-runner finds CUs whose LDS the step never takes
+                                        ("resnet34", 256, {"VPD_DGRAD_SUMS": "0", "VPD_RESERVE_CUS": "16"})],
+                         ids=["r34_every_bn_backward_with_a_barrier", "r50_every_bn_backward_with_a_barrier",
+                              "r34_every_bn_backward_with_a_barrier_16_cus_reserved"])
 def test_grid_barrier_kernels_on_a_busy_device(arch, n, env):
     """VERDICT r2 #5b: the fused BatchNorm backward (bn_bwd_fused_kernel, vpd_amd/csrc/sync.h) is an ordinary launch with an
     in-launch grid barrier: its blocks must all become resident while another stream's kernels (RCCL's all-reduce under
